@@ -1,0 +1,409 @@
+"""Sparse tensor, coordinate manager and layers of the MinkowskiEngine-compatible subset.
+
+Semantics = SURVEY.md Appendix A / oracle/me_oracle.py; every numeric op is a
+libapr_hip.so call (apr_amd.ops).  The modules keep MinkowskiEngine's parameter
+names (`kernel`, `bias`, `bn.*`) so reference checkpoints' state_dict keys load.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import AprHipError
+
+
+class CoordinateMapKey:
+    """Identifies a coordinate map of a manager by its tensor stride."""
+
+    __slots__ = ("stride",)
+
+    def __init__(self, stride: int):
+        self.stride = int(stride)
+
+    def get_tensor_stride(self):
+        return [self.stride] * 3
+
+    def __eq__(self, other):
+        return isinstance(other, CoordinateMapKey) and other.stride == self.stride
+
+    def __hash__(self):
+        return hash(self.stride)
+
+    def __repr__(self):
+        return f"CoordinateMapKey(tensor_stride={self.stride})"
+
+
+class CoordinateManager:
+    """Voxel-hash coordinate maps + cached kernel maps of one batched point set.
+
+    `maps[ts]` is an `ops.CoordMap`; `kernel_map(ts_in, ts_out, k, transpose)` is
+    the dense neighbour table the sparse-conv kernel consumes.
+    """
+
+    def __init__(self, coordinates: torch.Tensor):
+        self.maps = {1: ops.build_map(coordinates)}
+        self._kmaps = {}
+        self.device = coordinates.device
+
+    # -- coordinate maps -----------------------------------------------------
+    def _finalize(self):
+        pend = [m for m in self.maps.values() if m.n is None]
+        if pend:
+            ops.finalize_maps(pend)
+            m1 = self.maps[1]
+            if m1.n != m1.n_in:
+                raise AprHipError(
+                    f"SparseTensor: {m1.n_in - m1.n} duplicate coordinates; quantize first "
+                    "(ME.utils.sparse_quantize)")
+
+    def build_pyramid(self, strides):
+        """Enqueue all missing strided maps back to back and sync ONCE."""
+        for ts in sorted(strides):
+            if ts not in self.maps:
+                src = self.maps[ts // 2]
+                self.maps[ts] = ops.build_map(src.coords, floor_to=ts, n_in_dev=src.n_dev if src.n is None else None)
+        self._finalize()
+
+    def get_map(self, ts):
+        if ts not in self.maps:
+            self.build_pyramid([ts] if ts // 2 in self.maps else
+                               [s for s in (2 ** i for i in range(1, 12)) if s <= ts])
+        self._finalize()
+        return self.maps[ts]
+
+    def get_coordinates(self, key):
+        return self.get_map(key.stride if isinstance(key, CoordinateMapKey) else key).coords
+
+    def size(self, ts):
+        return self.get_map(ts).n
+
+    # -- kernel maps ---------------------------------------------------------
+    def kernel_map(self, ts_in, ts_out, kernel_size, transpose=False):
+        key = (ts_in, ts_out, kernel_size, transpose)
+        nbr = self._kmaps.get(key)
+        if nbr is None:
+            in_map, out_map = self.get_map(ts_in), self.get_map(ts_out)
+            # regular: c_in = c_out + o*ts_in ; transposed (coarse->fine): c_coarse = c_fine - o*ts_fine
+            scale = -ts_out if transpose else ts_in
+            nbr = ops.kernel_map(out_map, in_map, kernel_size, scale)
+            self._kmaps[key] = nbr
+        return nbr
+
+
+class SparseTensor:
+    def __init__(self, features, coordinates=None, coordinate_map_key=None, coordinate_manager=None,
+                 device=None, **unused):
+        if device is None:
+            device = features.device if features.is_cuda else None
+        if device is None and coordinates is not None and coordinates.is_cuda:
+            device = coordinates.device
+        if device is None:
+            raise AprHipError("SparseTensor: features/coordinates must live on the GPU (no CPU fallback)")
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise AprHipError("SparseTensor: device must be a GPU")
+        self.F = features.to(device=device, dtype=torch.float32)
+        if self.F.dim() != 2:
+            raise AprHipError("SparseTensor: features must be [N, C]")
+        if coordinates is not None:
+            if coordinates.dim() != 2 or coordinates.shape[1] != 4:
+                raise AprHipError("SparseTensor: coordinates must be [N, 1+3] (batch, x, y, z)")
+            if coordinates.shape[0] != self.F.shape[0]:
+                raise AprHipError("SparseTensor: coordinates / features row mismatch")
+            c = coordinates.to(device=device)
+            if c.dtype.is_floating_point:
+                c = torch.floor(c)
+            self.coordinate_manager = CoordinateManager(c.to(torch.int32).contiguous())
+            self.coordinate_map_key = CoordinateMapKey(1)
+        else:
+            if coordinate_manager is None or coordinate_map_key is None:
+                raise AprHipError("SparseTensor: need coordinates or (coordinate_map_key, coordinate_manager)")
+            self.coordinate_manager = coordinate_manager
+            self.coordinate_map_key = coordinate_map_key
+
+    # -- attributes the reference reads -----------------------------------------
+    @property
+    def C(self):
+        return self.coordinate_manager.get_coordinates(self.coordinate_map_key)
+
+    @property
+    def coordinates(self):
+        return self.C
+
+    @property
+    def features(self):
+        return self.F
+
+    @property
+    def tensor_stride(self):
+        return self.coordinate_map_key.get_tensor_stride()
+
+    @property
+    def device(self):
+        return self.F.device
+
+    @property
+    def D(self):
+        return 3
+
+    @property
+    def shape(self):
+        return self.F.shape
+
+    def __len__(self):
+        return self.F.shape[0]
+
+    def size(self):
+        return self.F.size()
+
+    @property
+    def decomposed_coordinates_and_features(self):
+        C = self.C
+        b = C[:, 0]
+        nb = int(b.max().item()) + 1 if len(C) else 0
+        coords, feats = [], []
+        for i in range(nb):
+            m = b == i
+            coords.append(C[m][:, 1:])
+            feats.append(self.F[m])
+        return coords, feats
+
+    @property
+    def decomposed_features(self):
+        return self.decomposed_coordinates_and_features[1]
+
+    @property
+    def decomposed_coordinates(self):
+        return self.decomposed_coordinates_and_features[0]
+
+    def _like(self, F, key=None):
+        return SparseTensor(F, coordinate_map_key=self.coordinate_map_key if key is None else key,
+                            coordinate_manager=self.coordinate_manager)
+
+    def _check_same_map(self, other):
+        if (other.coordinate_manager is not self.coordinate_manager
+                or other.coordinate_map_key != self.coordinate_map_key):
+            raise AprHipError("sparse tensors live on different coordinate maps")
+
+    def __iadd__(self, other):
+        self._check_same_map(other)
+        ops.affine_act(self.F, residual=other.F, out=self.F)
+        return self
+
+    def __add__(self, other):
+        self._check_same_map(other)
+        return self._like(ops.affine_act(self.F, residual=other.F))
+
+    def __repr__(self):
+        return f"SparseTensor(N={len(self)}, C={self.F.shape[1]}, {self.coordinate_map_key})"
+
+
+def _no_grad_guard(module):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters(recurse=False)):
+        raise AprHipError(
+            "apr_amd sparse ops are forward-only (backward is SURVEY 8(f) next-3): "
+            "call them under torch.no_grad()")
+
+
+class MinkowskiNetwork(nn.Module):
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+
+
+class _ConvBase(nn.Module):
+    TRANSPOSE = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, convolution_mode=None, dimension=None):
+        super().__init__()
+        if dimension not in (None, 3):
+            raise NotImplementedError("only 3-D sparse convolution (dimension=3)")
+        if dilation != 1:
+            raise NotImplementedError("dilation != 1 is not used by APR")
+        if kernel_size is None or kernel_size < 1 or kernel_size % 2 == 0:
+            raise ValueError(f"kernel_size must be odd and positive, got {kernel_size}")
+        if stride not in (1, 2):
+            raise NotImplementedError("stride must be 1 or 2")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dilation = kernel_size, stride, dilation
+        kv = kernel_size ** 3
+        self.kernel_volume = kv
+        self.use_mm = kv == 1 and stride == 1
+        shape = (in_channels, out_channels) if self.use_mm else (kv, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self._packed = None
+        self._packed_key = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.in_channels * self.kernel_volume)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def packed_weight(self):
+        k = (self.kernel.data_ptr(), self.kernel._version, self.kernel.device)
+        if self._packed_key != k:
+            self._packed = ops.pack_weights(self.kernel)
+            self._packed_key = k
+        return self._packed
+
+    def _maps(self, x: SparseTensor):
+        """-> (nbr or None, out tensor stride)."""
+        ts = x.coordinate_map_key.stride
+        cm = x.coordinate_manager
+        if self.use_mm:
+            return None, ts
+        if not self.TRANSPOSE:
+            ts_out = ts * self.stride
+            return cm.kernel_map(ts, ts_out, self.kernel_size, False), ts_out
+        if ts % self.stride != 0 or ts // self.stride < 1:
+            raise AprHipError("transposed convolution below tensor stride 1")
+        ts_out = ts // self.stride
+        if ts_out not in cm.maps:
+            raise AprHipError("transposed convolution needs the encoder's coordinate map of that stride")
+        return cm.kernel_map(ts, ts_out, self.kernel_size, self.stride != 1), ts_out
+
+    def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None):
+        """Raw fused launch on feature rows (used by the fused encoder plan)."""
+        if shift is None and self.bias is not None:
+            shift = self.bias.view(-1)
+        return ops.spconv(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
+                          self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
+                          relu=relu, out=out, n_out=n_out)
+
+    def forward(self, x: SparseTensor):
+        _no_grad_guard(self)
+        if x.F.shape[1] != self.in_channels:
+            raise AprHipError(f"conv expects {self.in_channels} input channels, got {x.F.shape[1]}")
+        nbr, ts_out = self._maps(x)
+        n_out = x.coordinate_manager.size(ts_out)
+        F = self.run(x.F, nbr, n_out)
+        return x._like(F, CoordinateMapKey(ts_out))
+
+    def extra_repr(self):
+        return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
+                f"stride={self.stride}")
+
+
+class MinkowskiConvolution(_ConvBase):
+    TRANSPOSE = False
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    TRANSPOSE = True
+
+
+def fold_bn(bn: nn.BatchNorm1d, mean=None, var=None):
+    """BatchNorm -> per-channel (scale, shift)."""
+    mean = bn.running_mean if mean is None else mean
+    var = bn.running_var if var is None else var
+    scale = torch.rsqrt(var + bn.eps)
+    if bn.weight is not None:
+        scale = scale * bn.weight
+    shift = -mean * scale
+    if bn.bias is not None:
+        shift = shift + bn.bias
+    return scale.contiguous(), shift.contiguous()
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """BatchNorm1d over all rows of F; state_dict prefix `.bn.`."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+        self._folded = None
+        self._folded_key = None
+
+    def folded(self):
+        """Eval-mode (scale, shift), cached until a parameter / buffer changes."""
+        bn = self.bn
+        key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+                    if t is not None)
+        if self._folded_key != key:
+            with torch.no_grad():
+                self._folded = fold_bn(bn)
+            self._folded_key = key
+        return self._folded
+
+    def forward(self, x: SparseTensor):
+        bn = self.bn
+        if torch.is_grad_enabled() and bn.weight is not None and bn.weight.requires_grad:
+            raise AprHipError("apr_amd sparse ops are forward-only: call under torch.no_grad()")
+        if self.training or not bn.track_running_stats:
+            mean, var = ops.bn_stats(x.F)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    n = x.F.shape[0]
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+                    bn.num_batches_tracked += 1
+            scale, shift = fold_bn(bn, mean, var)
+        else:
+            scale, shift = self.folded()
+        return x._like(ops.affine_act(x.F, scale=scale, shift=shift))
+
+
+class MinkowskiInstanceNorm(nn.Module):
+    """Per-cloud (batch index) mean/var over rows, learnable [1,C] affine, eps 1e-8."""
+
+    def __init__(self, num_features, dimension=None):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = 1e-8
+        self.weight = nn.Parameter(torch.ones(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+
+    def forward(self, x: SparseTensor):
+        _no_grad_guard(self)
+        b = x.C[:, 0]
+        nb = int(b.max().item()) + 1
+        # rows of one cloud are contiguous (collate order is preserved by first-occurrence maps)
+        counts = torch.bincount(b, minlength=nb).cpu().tolist()
+        out = torch.empty_like(x.F)
+        r0 = 0
+        for n in counts:
+            if n == 0:
+                continue
+            seg = x.F[r0:r0 + n]
+            mean, var = ops.bn_stats(seg)
+            scale = torch.rsqrt(var + self.eps) * self.weight.view(-1)
+            shift = self.bias.view(-1) - mean * scale
+            ops.affine_act(seg, scale=scale.contiguous(), shift=shift.contiguous(), out=out[r0:r0 + n])
+            r0 += n
+        return x._like(out)
+
+
+class MinkowskiReLU(nn.Module):
+    def forward(self, x):
+        return relu(x)
+
+
+def relu(x: SparseTensor):
+    return x._like(ops.affine_act(x.F, relu=True))
+
+
+def cat(*tensors):
+    if len(tensors) == 1 and isinstance(tensors[0], (list, tuple)):
+        tensors = tuple(tensors[0])
+    a = tensors[0]
+    for t in tensors[1:]:
+        a._check_same_map(t)
+    n = len(a)
+    ctot = sum(t.F.shape[1] for t in tensors)
+    out = torch.empty((n, ctot), dtype=torch.float32, device=a.F.device)
+    c0 = 0
+    for t in tensors:
+        c = t.F.shape[1]
+        ops.affine_act(t.F, out=out[:, c0:c0 + c])
+        c0 += c
+    return a._like(out)

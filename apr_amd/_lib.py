@@ -1,0 +1,98 @@
+"""ctypes binding of libapr_hip.so (the C ABI declared in include/apr_hip.h).
+
+This is the same stub a maintainer of the reference would add.
+torch is imported first so the library binds to the HIP runtime torch already
+loaded (both export SONAME libamdhip64.so.7); torch tensors only supply device
+pointers and the current stream.
+
+There is NO CPU fallback: if the library is missing or a call fails, an
+exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL so the HIP runtime is shared)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libapr_hip.so")
+
+_p = C.c_void_p
+_i32, _i64, _u64, _f32, _f64, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/apr_hip.h declares
+PROTOTYPES = {
+    "apr_last_error": (C.c_char_p, []),
+    "apr_version": (C.c_int, []),
+    "apr_device_count": (C.c_int, []),
+    "apr_hash_capacity": (_i64, [_i64]),
+    "apr_map_scratch_bytes": (_sz, [_i64]),
+    "apr_voxelize": (C.c_int, [_p, _i64, _f32, _i32, _p, _p]),
+    "apr_map_build": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "apr_kernel_map": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    "apr_spconv_packed_size": (_i64, [_i32, _i32, _i32]),
+    "apr_spconv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "apr_spconv_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "apr_bn_stats_scratch_bytes": (_sz, [_i64, _i32]),
+    "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "apr_l2_normalize": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
+    "apr_feature_nn": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p]),
+    "apr_nn_unpack": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "apr_ransac_scratch_bytes": (_sz, [_i64, _i64]),
+    "apr_ransac_pose": (C.c_int, [_p, _i64, _p, _i64, _p, _f64, _f64, _i64, _u64, _p, _sz, _p, _p]),
+    "apr_irls_pose": (C.c_int, [_p, _p, _p, _i64, _p, _p, _sz, _p]),
+    "apr_irls_scratch_bytes": (_sz, [_i64]),
+}
+
+_lib = None
+
+
+class AprHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libapr_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AprHipError(
+            f"{LIB_PATH} is missing: build it with `python -m apr_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().apr_last_error().decode()
+        raise AprHipError(f"libapr_hip error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_tensor(t, dtype, name):
+    if not t.is_cuda:
+        raise AprHipError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise AprHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise AprHipError(f"{name}: tensor must be contiguous")
+    return t

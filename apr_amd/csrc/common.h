@@ -1,0 +1,68 @@
+// Shared host/device helpers for libapr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/apr_hip.h"
+
+#define APR_API extern "C" __attribute__((visibility("default")))
+
+void apr_set_error(const char* fmt, ...);
+
+#define APR_CHECK_ARG(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      apr_set_error(__VA_ARGS__);     \
+      return APR_EINVAL;              \
+    }                                 \
+  } while (0)
+
+#define APR_HIP(call)                                                            \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      apr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return APR_EHIP;                                                           \
+    }                                                                            \
+  } while (0)
+
+#define APR_LAUNCH_CHECK() APR_HIP(hipGetLastError())
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- packed voxel key: (b:10 | x:18 | y:18 | z:18), x/y/z biased by 2^17 ----
+#define APR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define APR_AXIS_BIAS (1 << 17)
+#define APR_AXIS_RANGE (1 << 18)
+
+__host__ __device__ static inline bool apr_key_in_range(int b, int x, int y, int z) {
+  return (unsigned)b < 1024u && (unsigned)(x + APR_AXIS_BIAS) < (unsigned)APR_AXIS_RANGE &&
+         (unsigned)(y + APR_AXIS_BIAS) < (unsigned)APR_AXIS_RANGE &&
+         (unsigned)(z + APR_AXIS_BIAS) < (unsigned)APR_AXIS_RANGE;
+}
+
+__host__ __device__ static inline uint64_t apr_pack_key(int b, int x, int y, int z) {
+  return ((((uint64_t)(unsigned)b << 18 | (uint64_t)(unsigned)(x + APR_AXIS_BIAS)) << 18 |
+           (uint64_t)(unsigned)(y + APR_AXIS_BIAS))
+          << 18) |
+         (uint64_t)(unsigned)(z + APR_AXIS_BIAS);
+}
+
+__host__ __device__ static inline uint32_t apr_hash_u64(uint64_t k) {
+  // murmur3 finaliser
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// floor division / floor-to-multiple for possibly negative ints, m > 0
+__host__ __device__ static inline int apr_floor_to(int v, int m) {
+  int q = v / m;
+  if ((v % m) != 0 && v < 0) --q;
+  return q * m;
+}

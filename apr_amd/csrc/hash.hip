@@ -1,0 +1,262 @@
+// Voxel hashing, coordinate maps and kernel maps.
+//
+// HBM layout: an open-addressing table of `cap` uint64 keys + `cap` int32 values
+// (cap = power of two >= 2n, ~24 B per voxel), coordinates as int32 [n,4] rows
+// (one 16-B load per voxel) and the dense neighbour table nbr int32 [n_out,K].
+// All kernels are HBM/L2-latency bound integer work: one thread per row (or per
+// (row,offset) probe), 16-B coalesced row loads, wave64 ballot + popcount for
+// the compaction prefix sums.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ void k_voxelize(const float* __restrict__ xyz, int64_t n, float vs, int batch,
+                           int4* __restrict__ coords) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // fp32 division, correctly rounded: identical to numpy/torch float32 `xyz / vs`
+  float x = xyz[3 * i + 0] / vs, y = xyz[3 * i + 1] / vs, z = xyz[3 * i + 2] / vs;
+  coords[i] = make_int4(batch, (int)floorf(x), (int)floorf(y), (int)floorf(z));
+}
+
+__device__ inline int4 load_coord(const int4* coords, int64_t i, int floor_to) {
+  int4 c = coords[i];
+  if (floor_to > 0) {
+    c.y = apr_floor_to(c.y, floor_to);
+    c.z = apr_floor_to(c.z, floor_to);
+    c.w = apr_floor_to(c.w, floor_to);
+  }
+  return c;
+}
+
+// Insert every row; the slot keeps the smallest row index of its key.
+__global__ void k_insert(const int4* __restrict__ coords, int64_t n, const int* __restrict__ n_dev,
+                         int floor_to, unsigned long long* __restrict__ keys, int* __restrict__ vals,
+                         uint32_t mask, int* __restrict__ slot_of, int* __restrict__ status) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min((long long)n, (long long)*n_dev);
+  if (i >= n) return;
+  int4 c = load_coord(coords, i, floor_to);
+  if (!apr_key_in_range(c.x, c.y, c.z, c.w)) {
+    *status = 1;
+    slot_of[i] = -1;
+    return;
+  }
+  unsigned long long key = apr_pack_key(c.x, c.y, c.z, c.w);
+  uint32_t slot = apr_hash_u64(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long prev = keys[slot];
+    if (prev != key) {
+      if (prev != APR_KEY_EMPTY) {
+        slot = (slot + 1) & mask;
+        continue;
+      }
+      prev = atomicCAS(&keys[slot], APR_KEY_EMPTY, key);
+      if (prev != APR_KEY_EMPTY && prev != key) {
+        slot = (slot + 1) & mask;
+        continue;
+      }
+    }
+    atomicMin(&vals[slot], (int)i);
+    slot_of[i] = (int)slot;
+    return;
+  }
+  *status = 2;  // table full (cannot happen with cap >= 2n)
+  slot_of[i] = -1;
+}
+
+// flag[i] = row i is the first occurrence of its key; per-block counts.
+__global__ void k_flag_count(const int* __restrict__ vals, const int* __restrict__ slot_of,
+                             int64_t n, const int* __restrict__ n_dev, uint8_t* __restrict__ flags,
+                             int* __restrict__ block_counts) {
+  __shared__ int wave_cnt[kBlock / 64];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min((long long)n, (long long)*n_dev);
+  bool f = false;
+  if (i < n) {
+    int s = slot_of[i];
+    f = (s >= 0) && (vals[s] == (int)i);
+    flags[i] = f;
+  }
+  unsigned long long b = __ballot(f);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kBlock / 64; ++w) s += wave_cnt[w];
+    block_counts[blockIdx.x] = s;
+  }
+}
+
+// Single-workgroup exclusive scan of the block counts; total -> *n_out.
+__global__ void k_scan_blocks(const int* __restrict__ counts, int nblk, int* __restrict__ offsets,
+                              int* __restrict__ n_out) {
+  __shared__ int wave_sum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < nblk; base += blockDim.x) {
+    int idx = base + threadIdx.x;
+    int v = idx < nblk ? counts[idx] : 0;
+    int incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wave_sum[w];
+    int carry = carry_s;
+    if (idx < nblk) offsets[idx] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = carry_s;
+}
+
+// Compact the first-occurrence rows in row order and re-point the table at output rows.
+__global__ void k_compact(const int4* __restrict__ coords, int64_t n, const int* __restrict__ n_dev,
+                          int floor_to, const uint8_t* __restrict__ flags,
+                          const int* __restrict__ block_offsets, const int* __restrict__ slot_of,
+                          int* __restrict__ vals, int4* __restrict__ out_coords,
+                          long long* __restrict__ out_first) {
+  __shared__ int wave_cnt[kBlock / 64];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min((long long)n, (long long)*n_dev);
+  bool f = (i < n) && flags[i];
+  unsigned long long b = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = __popcll(b);
+  __syncthreads();
+  if (!f) return;
+  int pos = block_offsets[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+  out_coords[pos] = load_coord(coords, i, floor_to);
+  if (out_first) out_first[pos] = (long long)i;
+  vals[slot_of[i]] = pos;
+}
+
+__device__ inline int table_lookup(const unsigned long long* __restrict__ keys,
+                                   const int* __restrict__ vals, uint32_t mask,
+                                   unsigned long long key) {
+  uint32_t slot = apr_hash_u64(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long k = keys[slot];
+    if (k == key) return vals[slot];
+    if (k == APR_KEY_EMPTY) return -1;
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+
+// One thread per (out row, offset) probe; consecutive lanes -> consecutive offsets of
+// one row, so the nbr store is fully coalesced and the 16-B coordinate load is a
+// broadcast within the wave.
+__global__ void k_kernel_map(const int4* __restrict__ out_coords, int64_t n_out,
+                             const int* __restrict__ n_out_dev,
+                             const unsigned long long* __restrict__ keys,
+                             const int* __restrict__ vals, uint32_t mask, int ks, int scale,
+                             int* __restrict__ nbr) {
+  const int K = ks * ks * ks, h = ks / 2;
+  int64_t total = n_out * K;
+  if (n_out_dev) total = (int64_t)min((long long)n_out, (long long)*n_out_dev) * K;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t j = t / K;
+    int o = (int)(t - j * K);
+    int ox = o % ks - h, oy = (o / ks) % ks - h, oz = o / (ks * ks) - h;
+    int4 c = out_coords[j];
+    int x = c.y + ox * scale, y = c.z + oy * scale, z = c.w + oz * scale;
+    int r = -1;
+    if (apr_key_in_range(c.x, x, y, z)) r = table_lookup(keys, vals, mask, apr_pack_key(c.x, x, y, z));
+    nbr[t] = r;
+  }
+}
+
+}  // namespace
+
+APR_API int64_t apr_hash_capacity(int64_t n) {
+  int64_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+APR_API size_t apr_map_scratch_bytes(int64_t n) {
+  int64_t nblk = cdiv64(n > 0 ? n : 1, kBlock);
+  return align256(n * 4) + align256(n) + 2 * align256(nblk * 4) + 256;
+}
+
+APR_API int apr_voxelize(const float* xyz, int64_t n, float voxel_size, int32_t batch,
+                         int32_t* coords, void* stream) {
+  APR_CHECK_ARG(n >= 0 && voxel_size > 0.f, "apr_voxelize: bad n=%lld or voxel_size", (long long)n);
+  APR_CHECK_ARG(batch >= 0 && batch < 1024, "apr_voxelize: batch index %d outside [0,1024)", batch);
+  if (n == 0) return APR_OK;
+  hipLaunchKernelGGL(k_voxelize, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     xyz, n, voxel_size, batch, (int4*)coords);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_dev, int32_t floor_to,
+                          uint64_t* keys,
+                          int32_t* vals, int64_t cap, int32_t* out_coords, int64_t* out_first,
+                          int32_t* n_out, int32_t* status, void* scratch, size_t scratch_bytes,
+                          void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n >= 0 && n < (1ll << 31), "apr_map_build: n=%lld out of range", (long long)n);
+  APR_CHECK_ARG(cap >= 2 * n && (cap & (cap - 1)) == 0, "apr_map_build: cap=%lld must be a power of two >= 2n",
+                (long long)cap);
+  APR_CHECK_ARG(scratch_bytes >= apr_map_scratch_bytes(n), "apr_map_build: scratch too small");
+  APR_CHECK_ARG(floor_to >= 0, "apr_map_build: floor_to < 0");
+  APR_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, st));
+  APR_HIP(hipMemsetAsync(vals, 0x7F, (size_t)cap * 4, st));
+  APR_HIP(hipMemsetAsync(status, 0, 4, st));
+  if (n == 0) {
+    APR_HIP(hipMemsetAsync(n_out, 0, 4, st));
+    return APR_OK;
+  }
+  const int nblk = (int)cdiv64(n, kBlock);
+  char* p = (char*)scratch;
+  int* slot_of = (int*)p;
+  p += align256(n * 4);
+  uint8_t* flags = (uint8_t*)p;
+  p += align256(n);
+  int* blk_cnt = (int*)p;
+  p += align256((size_t)nblk * 4);
+  int* blk_off = (int*)p;
+  const uint32_t mask = (uint32_t)(cap - 1);
+  hipLaunchKernelGGL(k_insert, dim3(nblk), dim3(kBlock), 0, st, (const int4*)coords_in, n, n_dev,
+                     floor_to, (unsigned long long*)keys, vals, mask, slot_of, status);
+  hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(kBlock), 0, st, vals, slot_of, n, n_dev, flags, blk_cnt);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk_cnt, nblk, blk_off, n_out);
+  hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(kBlock), 0, st, (const int4*)coords_in, n, n_dev, floor_to,
+                     flags, blk_off, slot_of, vals, (int4*)out_coords, (long long*)out_first);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_kernel_map(const int32_t* out_coords, int64_t n_out, const int32_t* n_out_dev,
+                           const uint64_t* in_keys, const int32_t* in_vals, int64_t cap,
+                           int32_t kernel_size, int32_t scale, int32_t* nbr, void* stream) {
+  APR_CHECK_ARG(kernel_size >= 1 && (kernel_size & 1) && kernel_size <= 7,
+                "apr_kernel_map: kernel_size=%d must be odd and <= 7", kernel_size);
+  APR_CHECK_ARG((cap & (cap - 1)) == 0 && cap > 0, "apr_kernel_map: cap must be a power of two");
+  APR_CHECK_ARG(n_out >= 0, "apr_kernel_map: n_out < 0");
+  if (n_out == 0) return APR_OK;
+  const int K = kernel_size * kernel_size * kernel_size;
+  int64_t total = n_out * K;
+  int64_t nblk = cdiv64(total, kBlock);
+  if (nblk > 65536) nblk = 65536;
+  hipLaunchKernelGGL(k_kernel_map, dim3((unsigned)nblk), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const int4*)out_coords, n_out, n_out_dev, (const unsigned long long*)in_keys, in_vals,
+                     (uint32_t)(cap - 1), kernel_size, scale, nbr);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}

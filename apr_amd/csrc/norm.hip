@@ -1,0 +1,126 @@
+// Row-feature normalisation / elementwise kernels.
+// All HBM-bound: 16-B vector loads where the row stride allows, fp64 accumulation
+// for the batch statistics so training-mode BN matches torch's to ~1e-7.
+#include "common.h"
+
+namespace {
+
+constexpr int kRowsPerBlock = 256;
+
+// partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over this block's rows
+__global__ void k_bn_partial(const float* __restrict__ x, int64_t ld, int64_t n, int c,
+                             double* __restrict__ partial) {
+  __shared__ double s_sum[4][64], s_sq[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
+  const int64_t r1 = min((long long)(r0 + kRowsPerBlock), (long long)n);
+  double s = 0.0, s2 = 0.0;
+  if (col < c) {
+    for (int64_t r = r0 + ty; r < r1; r += 4) {
+      double v = (double)x[r * ld + col];
+      s += v;
+      s2 += v * v;
+    }
+  }
+  s_sum[ty][tx] = s;
+  s_sq[ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0 && col < c) {
+    double a = s_sum[0][tx] + s_sum[1][tx] + s_sum[2][tx] + s_sum[3][tx];
+    double b = s_sq[0][tx] + s_sq[1][tx] + s_sq[2][tx] + s_sq[3][tx];
+    partial[((int64_t)blockIdx.x * 2 + 0) * c + col] = a;
+    partial[((int64_t)blockIdx.x * 2 + 1) * c + col] = b;
+  }
+}
+
+__global__ void k_bn_finish(const double* __restrict__ partial, int nblk, int64_t n, int c,
+                            float* __restrict__ mean, float* __restrict__ var) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  double s = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[((int64_t)b * 2 + 0) * c + col];
+    s2 += partial[((int64_t)b * 2 + 1) * c + col];
+  }
+  double m = s / (double)n;
+  double v = s2 / (double)n - m * m;
+  mean[col] = (float)m;
+  var[col] = (float)(v > 0.0 ? v : 0.0);
+}
+
+__global__ void k_affine_act(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                             const float* __restrict__ scale, const float* __restrict__ shift,
+                             const float* __restrict__ residual, int64_t ldr, int relu,
+                             float* __restrict__ y, int64_t ldy) {
+  const int64_t total = n * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / c;
+    int col = (int)(t - r * c);
+    float v = x[r * ldx + col];
+    if (scale) v *= scale[col];
+    if (shift) v += shift[col];
+    if (residual) v += residual[r * ldr + col];
+    if (relu) v = fmaxf(v, 0.f);
+    y[r * ldy + col] = v;
+  }
+}
+
+// one wave per row; c <= 64 * 8
+__global__ void k_l2_normalize(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                               float* __restrict__ y, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float ss = 0.f;
+  for (int col = lane; col < c; col += 64) {
+    float v = x[row * ldx + col];
+    ss = fmaf(v, v, ss);
+  }
+  for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+  float nrm = sqrtf(ss);
+  for (int col = lane; col < c; col += 64) y[row * ldy + col] = x[row * ldx + col] / nrm;
+}
+
+}  // namespace
+
+APR_API size_t apr_bn_stats_scratch_bytes(int64_t n, int32_t c) {
+  return (size_t)cdiv64(n > 0 ? n : 1, kRowsPerBlock) * 2 * (size_t)c * sizeof(double);
+}
+
+APR_API int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c, float* mean, float* var,
+                         void* scratch, size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(n > 0 && c > 0 && ld >= c, "apr_bn_stats: bad shape n=%lld c=%d", (long long)n, c);
+  APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_bn_stats: scratch too small");
+  const int nblk = (int)cdiv64(n, kRowsPerBlock);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, n, c,
+                     (double*)scratch);
+  hipLaunchKernelGGL(k_bn_finish, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const double*)scratch, nblk, n, c, mean, var);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c, const float* scale,
+                           const float* shift, const float* residual, int64_t ldr, int32_t relu,
+                           float* y, int64_t ldy, void* stream) {
+  APR_CHECK_ARG(n >= 0 && c > 0 && ldx >= c && ldy >= c, "apr_affine_act: bad shape");
+  if (n == 0) return APR_OK;
+  int64_t nblk = cdiv64(n * c, 256);
+  if (nblk > 8192) nblk = 8192;
+  hipLaunchKernelGGL(k_affine_act, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, n, c,
+                     scale, shift, residual, ldr, relu, y, ldy);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_l2_normalize(const float* x, int64_t ldx, int64_t n, int32_t c, float* y, int64_t ldy,
+                             void* stream) {
+  APR_CHECK_ARG(n >= 0 && c > 0 && ldx >= c && ldy >= c, "apr_l2_normalize: bad shape");
+  if (n == 0) return APR_OK;
+  hipLaunchKernelGGL(k_l2_normalize, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     n, c, y, ldy);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}

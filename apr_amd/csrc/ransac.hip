@@ -1,0 +1,501 @@
+// RANSAC + Kabsch pose fit and IRLS pose refinement on the GPU
+// (K13).
+//
+// The reference hands N<=~15 k correspondences to open3d's CPU RANSAC
+// (FCGF_APR/scripts/test_apr.py:148-156: ransac_n = 4, edge-length checker 0.9,
+// distance checker = voxel_size, TransformationEstimationPointToPoint(False),
+// up to 4 000 000 iterations).  Here one thread owns one hypothesis: a
+// counter-based RNG picks its 4 correspondences (so the CPU oracle can replay the
+// exact stream), the cheap edge-length test runs first, survivors get a closed
+// form Kabsch (Horn quaternion, Jacobi eigen-solve of the 4x4 in fp64 registers),
+// the distance checker, and an append to the survivor list.  A persistent grid
+// of waves then scores each survivor against all correspondences (coalesced
+// 12-B point loads, fp64 transform, wave shuffle reduction), and a single
+// workgroup keeps the lexicographic best (inliers desc, rmse asc, iteration asc).
+#include "common.h"
+
+namespace {
+
+struct Hyp {
+  double T[12];  // row-major [R | t], 3x4
+  long long it;
+  int inliers;
+  int pad;
+  double err2;
+};
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__host__ __device__ inline uint32_t sample_index(uint64_t seed, uint64_t it, int slot, uint32_t n) {
+  uint64_t z = splitmix64(seed + (it * 4ull + (uint64_t)slot + 1ull) * 0x9E3779B97F4A7C15ull);
+  return (uint32_t)(((z >> 32) * (uint64_t)n) >> 32);
+}
+
+// Horn's closed-form absolute orientation: R,t minimising sum |R s_i + t - t_i|^2.
+// Equals Kabsch / Eigen::umeyama(with_scaling=false) whenever the optimum is unique.
+__device__ inline void kabsch4(const double s[4][3], const double t[4][3], double T[12]) {
+  double ms[3] = {0, 0, 0}, mt[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      ms[d] += s[i][d];
+      mt[d] += t[i][d];
+    }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    ms[d] *= 0.25;
+    mt[d] *= 0.25;
+  }
+  double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) S[a][b] += (s[i][a] - ms[a]) * (t[i][b] - mt[b]);
+  double A[4][4];
+  A[0][0] = S[0][0] + S[1][1] + S[2][2];
+  A[0][1] = S[1][2] - S[2][1];
+  A[0][2] = S[2][0] - S[0][2];
+  A[0][3] = S[0][1] - S[1][0];
+  A[1][1] = S[0][0] - S[1][1] - S[2][2];
+  A[1][2] = S[0][1] + S[1][0];
+  A[1][3] = S[2][0] + S[0][2];
+  A[2][2] = -S[0][0] + S[1][1] - S[2][2];
+  A[2][3] = S[1][2] + S[2][1];
+  A[3][3] = -S[0][0] - S[1][1] + S[2][2];
+  A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[3][0] = A[0][3];
+  A[2][1] = A[1][2]; A[3][1] = A[1][3]; A[3][2] = A[2][3];
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  // cyclic Jacobi, fully unrolled so A and V stay in registers
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q2 = p + 1; q2 < 4; ++q2) off += A[p][q2] * A[p][q2];
+    double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2] + A[3][3] * A[3][3];
+    if (off <= 1e-32 * diag || off == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q2 = p + 1; q2 < 4; ++q2) {
+        double apq = A[p][q2];
+        if (apq != 0.0) {
+          double theta = (A[q2][q2] - A[p][p]) / (2.0 * apq);
+          double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            double akp = A[k][p], akq = A[k][q2];
+            A[k][p] = c * akp - sn * akq;
+            A[k][q2] = sn * akp + c * akq;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            double apk = A[p][k], aqk = A[q2][k];
+            A[p][k] = c * apk - sn * aqk;
+            A[q2][k] = sn * apk + c * aqk;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            double vkp = V[k][p], vkq = V[k][q2];
+            V[k][p] = c * vkp - sn * vkq;
+            V[k][q2] = sn * vkp + c * vkq;
+          }
+        }
+      }
+  }
+  // eigenvector of the largest eigenvalue
+  double best = A[0][0];
+  double qw = V[0][0], qx = V[1][0], qy = V[2][0], qz = V[3][0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (A[j][j] > best) {
+      best = A[j][j];
+      qw = V[0][j]; qx = V[1][j]; qy = V[2][j]; qz = V[3][j];
+    }
+  double nq = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  qw *= nq; qx *= nq; qy *= nq; qz *= nq;
+  double R[3][3];
+  R[0][0] = 1 - 2 * (qy * qy + qz * qz); R[0][1] = 2 * (qx * qy - qw * qz); R[0][2] = 2 * (qx * qz + qw * qy);
+  R[1][0] = 2 * (qx * qy + qw * qz); R[1][1] = 1 - 2 * (qx * qx + qz * qz); R[1][2] = 2 * (qy * qz - qw * qx);
+  R[2][0] = 2 * (qx * qz - qw * qy); R[2][1] = 2 * (qy * qz + qw * qx); R[2][2] = 1 - 2 * (qx * qx + qy * qy);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    T[a * 4 + 0] = R[a][0]; T[a * 4 + 1] = R[a][1]; T[a * 4 + 2] = R[a][2];
+    T[a * 4 + 3] = mt[a] - (R[a][0] * ms[0] + R[a][1] * ms[1] + R[a][2] * ms[2]);
+  }
+}
+
+// tgt[i] = xyz1[corr[i]] as a dense [n0,3] array so scoring streams coalesced
+__global__ void k_gather_targets(const float* __restrict__ xyz1, int64_t n1, const long long* __restrict__ corr,
+                                 int64_t n0, float* __restrict__ tgt) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n0) return;
+  long long j = corr[i];
+  if (j < 0 || j >= n1) j = 0;
+  tgt[3 * i + 0] = xyz1[3 * j + 0];
+  tgt[3 * i + 1] = xyz1[3 * j + 1];
+  tgt[3 * i + 2] = xyz1[3 * j + 2];
+}
+
+__global__ void k_hypotheses(const float* __restrict__ xyz0, const float* __restrict__ tgt, uint32_t n0,
+                             double max_dist, double edge_ratio, long long it0, long long it1, uint64_t seed,
+                             Hyp* __restrict__ hyps, int* __restrict__ n_valid, int cap) {
+  long long it = it0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= it1) return;
+  double s[4][3], t[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t i = sample_index(seed, (uint64_t)it, j, n0);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      s[j][d] = (double)xyz0[3 * (int64_t)i + d];
+      t[j][d] = (double)tgt[3 * (int64_t)i + d];
+    }
+  }
+  // CorrespondenceCheckerBasedOnEdgeLength
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      double ds = sqrt((s[a][0] - s[b][0]) * (s[a][0] - s[b][0]) + (s[a][1] - s[b][1]) * (s[a][1] - s[b][1]) +
+                       (s[a][2] - s[b][2]) * (s[a][2] - s[b][2]));
+      double dt = sqrt((t[a][0] - t[b][0]) * (t[a][0] - t[b][0]) + (t[a][1] - t[b][1]) * (t[a][1] - t[b][1]) +
+                       (t[a][2] - t[b][2]) * (t[a][2] - t[b][2]));
+      if (ds < dt * edge_ratio || dt < ds * edge_ratio) return;
+    }
+  double T[12];
+  kabsch4(s, t, T);
+  // CorrespondenceCheckerBasedOnDistance
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double dx = T[0] * s[j][0] + T[1] * s[j][1] + T[2] * s[j][2] + T[3] - t[j][0];
+    double dy = T[4] * s[j][0] + T[5] * s[j][1] + T[6] * s[j][2] + T[7] - t[j][1];
+    double dz = T[8] * s[j][0] + T[9] * s[j][1] + T[10] * s[j][2] + T[11] - t[j][2];
+    if (sqrt(dx * dx + dy * dy + dz * dz) > max_dist) return;
+  }
+  int slot = atomicAdd(n_valid, 1);
+  if (slot < cap) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) hyps[slot].T[k] = T[k];
+    hyps[slot].it = it;
+    hyps[slot].inliers = 0;
+    hyps[slot].err2 = 0.0;
+  }
+}
+
+// Persistent waves: wave w scores hypotheses w, w + W, ... (exit is reached by every wave).
+__global__ __launch_bounds__(256) void k_score(const float* __restrict__ xyz0, const float* __restrict__ tgt,
+                                               int64_t n0, double max_dist, Hyp* __restrict__ hyps,
+                                               const int* __restrict__ n_valid, int cap) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nv = min(*n_valid, cap);
+  for (int h = wave; h < nv; h += nwaves) {
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = hyps[h].T[k];
+    int cnt = 0;
+    double e2 = 0.0;
+    for (int64_t i = lane; i < n0; i += 64) {
+      double sx = xyz0[3 * i], sy = xyz0[3 * i + 1], sz = xyz0[3 * i + 2];
+      double dx = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - (double)tgt[3 * i];
+      double dy = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - (double)tgt[3 * i + 1];
+      double dz = T[8] * sx + T[9] * sy + T[10] * sz + T[11] - (double)tgt[3 * i + 2];
+      double d2 = dx * dx + dy * dy + dz * dz;
+      if (sqrt(d2) < max_dist) {
+        ++cnt;
+        e2 += d2;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      cnt += __shfl_xor(cnt, d);
+      e2 += __shfl_xor(e2, d);
+    }
+    if (lane == 0) {
+      hyps[h].inliers = cnt;
+      hyps[h].err2 = e2;
+    }
+  }
+}
+
+__device__ inline bool better(int c1, double r1, long long i1, int c2, double r2, long long i2) {
+  if (c1 != c2) return c1 > c2;
+  if (r1 != r2) return r1 < r2;
+  return i1 < i2;
+}
+
+// best[0] carries the running best over chunks (inliers < 0 == none yet)
+__global__ void k_select(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                         Hyp* __restrict__ best, long long* __restrict__ total_valid) {
+  __shared__ int s_c[1024];
+  __shared__ double s_r[1024];
+  __shared__ long long s_i[1024];
+  __shared__ int s_h[1024];
+  const int nv = min(*n_valid, cap);
+  int bc = -1, bh = -1;
+  double br = 0.0;
+  long long bi = 0;
+  for (int h = threadIdx.x; h < nv; h += blockDim.x) {
+    int c = hyps[h].inliers;
+    double r = c > 0 ? sqrt(hyps[h].err2 / (double)c) : 0.0;
+    long long it = hyps[h].it;
+    if (bh < 0 || better(c, r, it, bc, br, bi)) {
+      bc = c; br = r; bi = it; bh = h;
+    }
+  }
+  s_c[threadIdx.x] = bc; s_r[threadIdx.x] = br; s_i[threadIdx.x] = bi; s_h[threadIdx.x] = bh;
+  __syncthreads();
+  for (int stride = blockDim.x / 2; stride >= 1; stride >>= 1) {
+    if (threadIdx.x < stride) {
+      int o = threadIdx.x + stride;
+      if (s_h[o] >= 0 && (s_h[threadIdx.x] < 0 ||
+                          better(s_c[o], s_r[o], s_i[o], s_c[threadIdx.x], s_r[threadIdx.x], s_i[threadIdx.x]))) {
+        s_c[threadIdx.x] = s_c[o]; s_r[threadIdx.x] = s_r[o]; s_i[threadIdx.x] = s_i[o]; s_h[threadIdx.x] = s_h[o];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *total_valid += *n_valid;
+    if (s_h[0] >= 0) {
+      double prev_r = best->inliers > 0 ? sqrt(best->err2 / (double)best->inliers) : 0.0;
+      if (best->inliers < 0 || better(s_c[0], s_r[0], s_i[0], best->inliers, prev_r, best->it)) *best = hyps[s_h[0]];
+    }
+  }
+}
+
+__global__ void k_init_best(Hyp* best, long long* total_valid) {
+#pragma unroll
+  for (int k = 0; k < 12; ++k) best->T[k] = (k % 5 == 0) ? 1.0 : 0.0;  // identity (open3d's default result)
+  best->it = -1;
+  best->inliers = -1;
+  best->err2 = 0.0;
+  *total_valid = 0;
+}
+
+// ---------------------------------------------------------------------------------
+// IRLS: est_quad_linear_robust, one 1024-thread workgroup, 20 iterations in-kernel.
+// ---------------------------------------------------------------------------------
+__device__ inline void solve6(double M[6][7]) {
+  // Gauss-Jordan with partial pivoting on the augmented 6x7 system (thread 0 only)
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    double mx = fabs(M[c][c]);
+    for (int r = c + 1; r < 6; ++r)
+      if (fabs(M[r][c]) > mx) {
+        mx = fabs(M[r][c]);
+        piv = r;
+      }
+    if (piv != c)
+      for (int k = 0; k < 7; ++k) {
+        double tmp = M[c][k];
+        M[c][k] = M[piv][k];
+        M[piv][k] = tmp;
+      }
+    double inv = 1.0 / M[c][c];
+    for (int k = 0; k < 7; ++k) M[c][k] *= inv;
+    for (int r = 0; r < 6; ++r)
+      if (r != c) {
+        double f = M[r][c];
+        for (int k = 0; k < 7; ++k) M[r][k] -= f * M[c][k];
+      }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_irls(const float* __restrict__ pts0, const float* __restrict__ pts1,
+                                               const float* __restrict__ weight0, int64_t n,
+                                               float* __restrict__ cur, float* __restrict__ w,
+                                               float* __restrict__ T_out) {
+  __shared__ double s_red[16][27];
+  __shared__ double s_M[6][7];
+  __shared__ float s_T[16];   // accumulated transform
+  __shared__ float s_Tc[12];  // current step [R|t]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int64_t i = tid; i < n; i += 1024) {
+    cur[3 * i] = pts0[3 * i]; cur[3 * i + 1] = pts0[3 * i + 1]; cur[3 * i + 2] = pts0[3 * i + 2];
+    w[i] = weight0 ? weight0[i] : 1.f;
+  }
+  if (tid < 16) s_T[tid] = (tid % 5 == 0) ? 1.f : 0.f;
+  __syncthreads();
+  float par = 1.0f;
+  for (int iter = 0; iter < 20; ++iter) {
+    if (iter > 0 && iter % 5 == 0) par *= 0.5f;
+    // normal equations: rows a0=[0,z,-y,1,0,0], a1=[-z,0,x,0,1,0], a2=[y,-x,0,0,0,1], all scaled by w
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    for (int64_t i = tid; i < n; i += 1024) {
+      double x = cur[3 * i], y = cur[3 * i + 1], z = cur[3 * i + 2];
+      double ww = (double)w[i] * (double)w[i];
+      double bx = (double)pts1[3 * i] - x, by = (double)pts1[3 * i + 1] - y, bz = (double)pts1[3 * i + 2] - z;
+      // AtA upper triangle (21) in row-major order, then Atb (6)
+      acc[0] += ww * (z * z + y * y);  // 00
+      acc[1] += ww * (-x * y);         // 01
+      acc[2] += ww * (-x * z);         // 02
+      acc[3] += 0.0;                   // 03
+      acc[4] += ww * (-z);             // 04
+      acc[5] += ww * (y);              // 05
+      acc[6] += ww * (z * z + x * x);  // 11
+      acc[7] += ww * (-y * z);         // 12
+      acc[8] += ww * (z);              // 13
+      acc[9] += 0.0;                   // 14
+      acc[10] += ww * (-x);            // 15
+      acc[11] += ww * (y * y + x * x); // 22
+      acc[12] += ww * (-y);            // 23
+      acc[13] += ww * (x);             // 24
+      acc[14] += 0.0;                  // 25
+      acc[15] += ww;                   // 33
+      acc[16] += 0.0;                  // 34
+      acc[17] += 0.0;                  // 35
+      acc[18] += ww;                   // 44
+      acc[19] += 0.0;                  // 45
+      acc[20] += ww;                   // 55
+      acc[21] += ww * (-z * by + y * bz);
+      acc[22] += ww * (z * bx - x * bz);
+      acc[23] += ww * (-y * bx + x * by);
+      acc[24] += ww * bx;
+      acc[25] += ww * by;
+      acc[26] += ww * bz;
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      double v = acc[k];
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+      if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double tot[27];
+      for (int k = 0; k < 27; ++k) {
+        double v = 0.0;
+        for (int wv = 0; wv < 16; ++wv) v += s_red[wv][k];
+        tot[k] = v;
+      }
+      int p = 0;
+      for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) {
+          s_M[r][c] = tot[p];
+          s_M[c][r] = tot[p];
+          ++p;
+        }
+      for (int r = 0; r < 6; ++r) s_M[r][6] = tot[21 + r];
+      double M[6][7];
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 7; ++c) M[r][c] = s_M[r][c];
+      solve6(M);
+      float x0 = (float)M[0][6], x1 = (float)M[1][6], x2 = (float)M[2][6];
+      float cx = cosf(x0), sx = sinf(x0), cy = cosf(x1), sy = sinf(x1), cz = cosf(x2), sz = sinf(x2);
+      // R = rot_z(x2) rot_y(x1) rot_x(x0)
+      float R[3][3];
+      R[0][0] = cz * cy; R[0][1] = cz * sy * sx - sz * cx; R[0][2] = cz * sy * cx + sz * sx;
+      R[1][0] = sz * cy; R[1][1] = sz * sy * sx + cz * cx; R[1][2] = sz * sy * cx - cz * sx;
+      R[2][0] = -sy;     R[2][1] = cy * sx;                R[2][2] = cy * cx;
+      for (int a = 0; a < 3; ++a) {
+        s_Tc[a * 4 + 0] = R[a][0]; s_Tc[a * 4 + 1] = R[a][1]; s_Tc[a * 4 + 2] = R[a][2];
+        s_Tc[a * 4 + 3] = (float)M[3 + a][6];
+      }
+      // trans = trans_curr @ trans
+      float Tn[12];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 4; ++b) {
+          float v = s_Tc[a * 4 + 0] * s_T[0 * 4 + b] + s_Tc[a * 4 + 1] * s_T[1 * 4 + b] + s_Tc[a * 4 + 2] * s_T[2 * 4 + b];
+          if (b == 3) v += s_Tc[a * 4 + 3];
+          Tn[a * 4 + b] = v;
+        }
+      for (int k = 0; k < 12; ++k) s_T[k] = Tn[k];
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 1024) {
+      float x = cur[3 * i], y = cur[3 * i + 1], z = cur[3 * i + 2];
+      float nx = s_Tc[0] * x + s_Tc[1] * y + s_Tc[2] * z + s_Tc[3];
+      float ny = s_Tc[4] * x + s_Tc[5] * y + s_Tc[6] * z + s_Tc[7];
+      float nz = s_Tc[8] * x + s_Tc[9] * y + s_Tc[10] * z + s_Tc[11];
+      cur[3 * i] = nx; cur[3 * i + 1] = ny; cur[3 * i + 2] = nz;
+      float dx = nx - pts1[3 * i], dy = ny - pts1[3 * i + 1], dz = nz - pts1[3 * i + 2];
+      w[i] = par / (sqrtf(dx * dx + dy * dy + dz * dz) + par);
+    }
+    __syncthreads();
+  }
+  if (tid < 16) T_out[tid] = s_T[tid];
+}
+
+constexpr int64_t kChunk = 1 << 20;
+
+}  // namespace
+
+APR_API size_t apr_ransac_scratch_bytes(int64_t n0, int64_t max_iter) {
+  int64_t cap = max_iter < kChunk ? max_iter : kChunk;
+  if (cap < 1) cap = 1;
+  return (size_t)cap * sizeof(Hyp) + sizeof(Hyp) + 64 + (size_t)n0 * 12 + 256;
+}
+
+APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1, const int64_t* corr,
+                            double max_dist, double edge_ratio, int64_t max_iter, uint64_t seed, void* scratch,
+                            size_t scratch_bytes, double* result_host, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n0 > 0 && n0 < (1ll << 31) && n1 > 0, "apr_ransac_pose: empty point set");
+  APR_CHECK_ARG(max_iter > 0 && max_dist > 0, "apr_ransac_pose: bad max_iter / max_dist");
+  APR_CHECK_ARG(scratch_bytes >= apr_ransac_scratch_bytes(n0, max_iter), "apr_ransac_pose: scratch too small");
+  const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
+  char* p = (char*)scratch;
+  Hyp* best = (Hyp*)p;
+  p += sizeof(Hyp);
+  long long* total_valid = (long long*)p;
+  p += 8;
+  int* n_valid = (int*)p;
+  p += 56;
+  Hyp* hyps = (Hyp*)p;
+  p += (size_t)cap * sizeof(Hyp);
+  float* tgt = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, best, total_valid);
+  hipLaunchKernelGGL(k_gather_targets, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz1, n1,
+                     (const long long*)corr, n0, tgt);
+  for (int64_t it0 = 0; it0 < max_iter; it0 += cap) {
+    const int64_t it1 = (it0 + cap < max_iter) ? it0 + cap : max_iter;
+    APR_HIP(hipMemsetAsync(n_valid, 0, 4, st));
+    hipLaunchKernelGGL(k_hypotheses, dim3((unsigned)cdiv64(it1 - it0, 256)), dim3(256), 0, st, xyz0, tgt,
+                       (uint32_t)n0, max_dist, edge_ratio, (long long)it0, (long long)it1, seed, hyps, n_valid,
+                       (int)cap);
+    hipLaunchKernelGGL(k_score, dim3(2048), dim3(256), 0, st, xyz0, tgt, n0, max_dist, hyps, n_valid, (int)cap);
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, hyps, n_valid, (int)cap, best, total_valid);
+  }
+  APR_LAUNCH_CHECK();
+  Hyp hb;
+  long long tv = 0;
+  APR_HIP(hipMemcpyAsync(&hb, best, sizeof(Hyp), hipMemcpyDeviceToHost, st));
+  APR_HIP(hipMemcpyAsync(&tv, total_valid, 8, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipStreamSynchronize(st));
+  for (int k = 0; k < 12; ++k) result_host[k] = hb.T[k];
+  result_host[12] = 0.0; result_host[13] = 0.0; result_host[14] = 0.0; result_host[15] = 1.0;
+  result_host[16] = (double)(hb.inliers < 0 ? 0 : hb.inliers);
+  result_host[17] = hb.inliers > 0 ? sqrt(hb.err2 / (double)hb.inliers) : 0.0;
+  result_host[18] = (double)hb.it;
+  result_host[19] = (double)tv;
+  return APR_OK;
+}
+
+APR_API size_t apr_irls_scratch_bytes(int64_t n) { return (size_t)n * 16 + 256 + 64; }
+
+APR_API int apr_irls_pose(const float* pts0, const float* pts1, const float* weight, int64_t n, float* T_host,
+                          void* scratch, size_t scratch_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n > 0, "apr_irls_pose: n <= 0");
+  APR_CHECK_ARG(scratch_bytes >= apr_irls_scratch_bytes(n), "apr_irls_pose: scratch too small");
+  float* T_dev = (float*)scratch;
+  float* cur = (float*)((char*)scratch + 64);
+  float* w = cur + 3 * n;
+  hipLaunchKernelGGL(k_irls, dim3(1), dim3(1024), 0, st, pts0, pts1, weight, n, cur, w, T_dev);
+  APR_LAUNCH_CHECK();
+  APR_HIP(hipMemcpyAsync(T_host, T_dev, 64, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipStreamSynchronize(st));
+  return APR_OK;
+}

@@ -1,0 +1,219 @@
+"""Sparse-voxel ResUNet encoder of FCGF_APR on the HIP operator library.
+
+Constructor arguments, sub-module names (= state_dict keys), channel tables and
+forward semantics follow /root/reference/FCGF_APR/model/resunet.py:10-251
+(ResUNet2 and its BN2/BN2B/BN2C/BN2D/BN2E/FatBN/IN2* variants), so
+`Model(in_channels, out_channels, bn_momentum=, normalize_feature=,
+conv1_kernel_size=, D=3)` and `model(x: SparseTensor) -> SparseTensor` are
+drop-in (call sites FCGF_APR/lib/trainer.py:41-47, scripts/test_apr.py:78-83).
+
+Two execution paths produce the same numbers:
+  * `forward_modular` walks the ME-style modules one op per launch (any mode);
+  * `forward_fused` (eval mode, BN everywhere) runs the whole encoder as 23
+    fused sparse-conv launches: eval BatchNorm folded into the conv epilogue,
+    residual add + ReLU fused, ME.cat removed by writing decoder/skip outputs
+    straight into column slices of the concat buffers, and the coordinate
+    pyramid (strides 2/4/8) built with a single host sync.
+"""
+import torch
+
+from ... import MinkowskiEngine as ME
+from ... import ops
+from ...MinkowskiEngine import MinkowskiFunctional as MEF
+from ...MinkowskiEngine.core import CoordinateMapKey
+from .common import get_norm
+from .residual_block import get_block
+
+
+class ResUNet2(ME.MinkowskiNetwork):
+    NORM_TYPE = None
+    BLOCK_NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 32, 64, 64, 128]
+
+    def __init__(self, in_channels=3, out_channels=32, bn_momentum=0.1, normalize_feature=None,
+                 conv1_kernel_size=None, D=3):
+        ME.MinkowskiNetwork.__init__(self, D)
+        NORM_TYPE, BLOCK_NORM_TYPE = self.NORM_TYPE, self.BLOCK_NORM_TYPE
+        CH, TR = self.CHANNELS, self.TR_CHANNELS
+        self.normalize_feature = normalize_feature
+
+        def conv(cin, cout, k, s, bias=False):
+            return ME.MinkowskiConvolution(in_channels=cin, out_channels=cout, kernel_size=k, stride=s,
+                                           dilation=1, bias=bias, dimension=D)
+
+        def conv_tr(cin, cout):
+            return ME.MinkowskiConvolutionTranspose(in_channels=cin, out_channels=cout, kernel_size=3, stride=2,
+                                                    dilation=1, bias=False, dimension=D)
+
+        def norm(c):
+            return get_norm(NORM_TYPE, c, bn_momentum=bn_momentum, D=D)
+
+        def block(c):
+            return get_block(BLOCK_NORM_TYPE, c, c, bn_momentum=bn_momentum, D=D)
+
+        self.conv1 = conv(in_channels, CH[1], conv1_kernel_size, 1)
+        self.norm1 = norm(CH[1])
+        self.block1 = block(CH[1])
+        self.conv2 = conv(CH[1], CH[2], 3, 2)
+        self.norm2 = norm(CH[2])
+        self.block2 = block(CH[2])
+        self.conv3 = conv(CH[2], CH[3], 3, 2)
+        self.norm3 = norm(CH[3])
+        self.block3 = block(CH[3])
+        self.conv4 = conv(CH[3], CH[4], 3, 2)
+        self.norm4 = norm(CH[4])
+        self.block4 = block(CH[4])
+        self.conv4_tr = conv_tr(CH[4], TR[4])
+        self.norm4_tr = norm(TR[4])
+        self.block4_tr = block(TR[4])
+        self.conv3_tr = conv_tr(CH[3] + TR[4], TR[3])
+        self.norm3_tr = norm(TR[3])
+        self.block3_tr = block(TR[3])
+        self.conv2_tr = conv_tr(CH[2] + TR[3], TR[2])
+        self.norm2_tr = norm(TR[2])
+        self.block2_tr = block(TR[2])
+        self.conv1_tr = conv(CH[1] + TR[2], TR[1], 1, 1)
+        self.final = conv(TR[1], out_channels, 1, 1, bias=True)
+        self.use_fused = True
+
+    # ------------------------------------------------------------------ modular
+    def forward_modular(self, x):
+        out_s1 = self.block1(self.norm1(self.conv1(x)))
+        out = MEF.relu(out_s1)
+        out_s2 = self.block2(self.norm2(self.conv2(out)))
+        out = MEF.relu(out_s2)
+        out_s4 = self.block3(self.norm3(self.conv3(out)))
+        out = MEF.relu(out_s4)
+        out_s8 = self.block4(self.norm4(self.conv4(out)))
+        out = MEF.relu(out_s8)
+
+        out = self.block4_tr(self.norm4_tr(self.conv4_tr(out)))
+        out_s4_tr = MEF.relu(out)
+        out = ME.cat(out_s4_tr, out_s4)
+
+        out = self.block3_tr(self.norm3_tr(self.conv3_tr(out)))
+        out_s2_tr = MEF.relu(out)
+        out = ME.cat(out_s2_tr, out_s2)
+
+        out = self.block2_tr(self.norm2_tr(self.conv2_tr(out)))
+        out_s1_tr = MEF.relu(out)
+        out = ME.cat(out_s1_tr, out_s1)
+
+        out = MEF.relu(self.conv1_tr(out))
+        out = self.final(out)
+        if self.normalize_feature:
+            return ME.SparseTensor(ops.l2_normalize(out.F), coordinate_map_key=out.coordinate_map_key,
+                                   coordinate_manager=out.coordinate_manager)
+        return out
+
+    # ------------------------------------------------------------------ fused
+    def _can_fuse(self):
+        return (self.use_fused and not self.training and self.NORM_TYPE == 'BN'
+                and self.BLOCK_NORM_TYPE == 'BN')
+
+    def forward_fused(self, x):
+        cm = x.coordinate_manager
+        if x.coordinate_map_key.stride != 1:
+            raise ValueError("encoder input must be at tensor stride 1")
+        cm.build_pyramid([2, 4, 8])
+        N1, N2, N3, N4 = (cm.size(s) for s in (1, 2, 4, 8))
+        CH, TR = self.CHANNELS, self.TR_CHANNELS
+        dev = x.F.device
+        k1 = self.conv1.kernel_size
+
+        def buf(n, c):
+            return torch.empty((n, c), dtype=torch.float32, device=dev)
+
+        # concat buffers: [decoder output | encoder skip]
+        cat1, cat2, cat3 = buf(N1, TR[2] + CH[1]), buf(N2, TR[3] + CH[2]), buf(N3, TR[4] + CH[3])
+        s1, s2, s4 = cat1[:, TR[2]:], cat2[:, TR[3]:], cat3[:, TR[4]:]
+
+        def stage(conv, norm, feats, nbr, n_out, blk, nbr_blk, out):
+            sc, sh = norm.folded()
+            a = conv.run(feats, nbr, n_out, scale=sc, shift=sh)
+            return blk.fused_eval(a, nbr_blk, out)
+
+        m11 = cm.kernel_map(1, 1, 3)
+        m22 = cm.kernel_map(2, 2, 3)
+        m44 = cm.kernel_map(4, 4, 3)
+        m88 = cm.kernel_map(8, 8, 3)
+        stage(self.conv1, self.norm1, x.F, cm.kernel_map(1, 1, k1) if k1 != 3 else m11, N1, self.block1, m11, s1)
+        stage(self.conv2, self.norm2, s1, cm.kernel_map(1, 2, 3), N2, self.block2, m22, s2)
+        stage(self.conv3, self.norm3, s2, cm.kernel_map(2, 4, 3), N3, self.block3, m44, s4)
+        s8 = stage(self.conv4, self.norm4, s4, cm.kernel_map(4, 8, 3), N4, self.block4, m88, buf(N4, CH[4]))
+        stage(self.conv4_tr, self.norm4_tr, s8, cm.kernel_map(8, 4, 3, True), N3, self.block4_tr, m44,
+              cat3[:, :TR[4]])
+        stage(self.conv3_tr, self.norm3_tr, cat3, cm.kernel_map(4, 2, 3, True), N2, self.block3_tr, m22,
+              cat2[:, :TR[3]])
+        stage(self.conv2_tr, self.norm2_tr, cat2, cm.kernel_map(2, 1, 3, True), N1, self.block2_tr, m11,
+              cat1[:, :TR[2]])
+        h = self.conv1_tr.run(cat1, None, N1, relu=True)
+        out = self.final.run(h, None, N1)
+        if self.normalize_feature:
+            out = ops.l2_normalize(out, out=out)
+        return ME.SparseTensor(out, coordinate_map_key=CoordinateMapKey(1), coordinate_manager=cm)
+
+    def forward(self, x):
+        if self._can_fuse():
+            return self.forward_fused(x)
+        return self.forward_modular(x)
+
+
+class ResUNetBN2(ResUNet2):
+    NORM_TYPE = 'BN'
+
+
+class ResUNetBN2B(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 64, 64, 64, 64]
+
+
+class ResUNetBN2C(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 64, 64, 64, 128]
+
+
+class ResUNetBN2D(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 64, 64, 128, 128]
+
+
+class ResUNetBN2E(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 128, 128, 128, 256]
+    TR_CHANNELS = [None, 64, 128, 128, 128]
+
+
+class ResUNetFatBN(ResUNet2):
+    NORM_TYPE = 'BN'
+    CHANNELS = [None, 32, 64, 128, 256]
+    TR_CHANNELS = [None, 128, 128, 128, 256]
+
+
+class ResUNetIN2(ResUNet2):
+    NORM_TYPE = 'BN'
+    BLOCK_NORM_TYPE = 'IN'
+
+
+class ResUNetIN2B(ResUNetBN2B):
+    NORM_TYPE = 'BN'
+    BLOCK_NORM_TYPE = 'IN'
+
+
+class ResUNetIN2C(ResUNetBN2C):
+    NORM_TYPE = 'BN'
+    BLOCK_NORM_TYPE = 'IN'
+
+
+class ResUNetIN2D(ResUNetBN2D):
+    NORM_TYPE = 'BN'
+    BLOCK_NORM_TYPE = 'IN'
+
+
+class ResUNetIN2E(ResUNetBN2E):
+    NORM_TYPE = 'BN'
+    BLOCK_NORM_TYPE = 'IN'

@@ -1,0 +1,252 @@
+"""Host-side operator layer: torch tensors in/out, every op a call into libapr_hip.so.
+
+torch supplies device memory and the current HIP stream only; there is no
+PyTorch fallback for any of these ops (they raise if handed CPU tensors or if the
+library is missing).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _f32(t, name):
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.AprHipError(f"{name}: need a float32 GPU tensor (no CPU fallback), got {t.dtype} on {t.device}")
+    return t
+
+
+def _rows(t, name):
+    """2-D row-major view (possibly a column slice of a wider buffer) -> (tensor, ld)."""
+    _f32(t, name)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise _lib.AprHipError(f"{name}: need a 2-D tensor with unit column stride")
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+# ----------------------------------------------------------------------------
+# voxel hashing / coordinate maps
+# ----------------------------------------------------------------------------
+
+def voxelize(xyz: torch.Tensor, voxel_size: float, batch: int = 0) -> torch.Tensor:
+    """xyz f32[n,3] -> int32 [n,4] (batch, floor(xyz / voxel_size))."""
+    xyz = _f32(xyz, "voxelize.xyz").contiguous()
+    n = xyz.shape[0]
+    coords = torch.empty((n, 4), dtype=torch.int32, device=xyz.device)
+    check(_lib_().apr_voxelize(ptr(xyz), n, float(voxel_size), int(batch), ptr(coords), stream()))
+    return coords
+
+
+class CoordMap:
+    """One coordinate map: unique int32 [n,4] rows + its hash table (key -> row)."""
+
+    __slots__ = ("coords", "keys", "vals", "cap", "n", "n_dev", "status", "first", "n_in")
+
+    def rows(self):
+        return self.coords[: self.n]
+
+
+def build_map(coords_in: torch.Tensor, floor_to: int = 0, n_in_dev=None, want_first=False) -> CoordMap:
+    """Enqueue a map build.  `m.n` is None until `finalize_maps` has synced."""
+    if not coords_in.is_cuda or coords_in.dtype != torch.int32 or coords_in.dim() != 2 or coords_in.shape[1] != 4:
+        raise _lib.AprHipError("build_map: coordinates must be an int32 [n,4] GPU tensor")
+    coords_in = coords_in.contiguous()
+    lib = _lib_()
+    n = coords_in.shape[0]
+    dev = coords_in.device
+    m = CoordMap()
+    m.cap = int(lib.apr_hash_capacity(n))
+    m.keys = torch.empty(m.cap, dtype=torch.int64, device=dev)
+    m.vals = torch.empty(m.cap, dtype=torch.int32, device=dev)
+    m.coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    m.first = torch.empty(n, dtype=torch.int64, device=dev) if want_first else None
+    m.n_dev = torch.empty(1, dtype=torch.int32, device=dev)
+    m.status = torch.empty(1, dtype=torch.int32, device=dev)
+    m.n = None
+    m.n_in = n
+    sb = int(lib.apr_map_scratch_bytes(n))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    check(lib.apr_map_build(ptr(coords_in), n, ptr(n_in_dev), int(floor_to), ptr(m.keys), ptr(m.vals), m.cap,
+                            ptr(m.coords), ptr(m.first), ptr(m.n_dev), ptr(m.status), ptr(scratch), sb, stream()))
+    return m
+
+
+def finalize_maps(maps):
+    """One host sync for any number of pending maps: fetch row counts + status flags."""
+    pend = [m for m in maps if m.n is None]
+    if not pend:
+        return
+    host = torch.cat([torch.cat([m.n_dev, m.status]) for m in pend]).cpu().numpy()
+    for i, m in enumerate(pend):
+        if host[2 * i + 1] != 0:
+            raise _lib.AprHipError(
+                "coordinate outside the packed voxel-key range (|xyz| < 2^17 voxels, batch < 1024)")
+        m.n = int(host[2 * i])
+        m.coords = m.coords[: m.n]
+        if m.first is not None:
+            m.first = m.first[: m.n]
+
+
+def kernel_map(out_map: CoordMap, in_map: CoordMap, kernel_size: int, scale: int) -> torch.Tensor:
+    """nbr int32 [n_out, k^3]; both maps must be finalized."""
+    lib = _lib_()
+    K = kernel_size ** 3
+    n_out = out_map.n
+    nbr = torch.empty((n_out, K), dtype=torch.int32, device=out_map.coords.device)
+    check(lib.apr_kernel_map(ptr(out_map.coords), n_out, None, ptr(in_map.keys), ptr(in_map.vals), in_map.cap,
+                             int(kernel_size), int(scale), ptr(nbr), stream()))
+    return nbr
+
+
+# ----------------------------------------------------------------------------
+# sparse convolution
+# ----------------------------------------------------------------------------
+
+def pack_weights(w: torch.Tensor) -> torch.Tensor:
+    """[K,cin,cout] (or [cin,cout] for kernel_size 1) -> kernel-native packed layout."""
+    w = _f32(w.detach(), "pack_weights.w")
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    w = w.contiguous()
+    K, cin, cout = w.shape
+    lib = _lib_()
+    wp = torch.empty(int(lib.apr_spconv_packed_size(K, cin, cout)), dtype=torch.float32, device=w.device)
+    check(lib.apr_spconv_pack_weights(ptr(w), K, cin, cout, ptr(wp), stream()))
+    return wp
+
+
+def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None):
+    """out[j] = act((sum_o x[nbr[j,o]] @ W[o]) * scale + shift + residual[j]).
+
+    x / residual / out may be column slices of wider row-major buffers.
+    """
+    x, ldi = _rows(x, "spconv.x")
+    if x.shape[1] != cin:
+        raise _lib.AprHipError(f"spconv: input has {x.shape[1]} channels, weight expects {cin}")
+    if nbr is not None:
+        if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.shape[1] != K:
+            raise _lib.AprHipError("spconv: nbr must be a contiguous int32 [n_out, K] tensor")
+        n_out = nbr.shape[0]
+    elif n_out is None:
+        n_out = x.shape[0]
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    out, ldo = _rows(out, "spconv.out")
+    if out.shape[0] != n_out or out.shape[1] != cout:
+        raise _lib.AprHipError("spconv: output shape mismatch")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "spconv.residual")
+        if residual.shape[0] != n_out or residual.shape[1] != cout:
+            raise _lib.AprHipError("spconv: residual shape mismatch")
+    check(_lib_().apr_spconv_fwd(ptr(x), ldi, ptr(nbr), n_out, K, cin, cout, ptr(wp), ptr(scale), ptr(shift),
+                                 ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------
+# normalisation / elementwise
+# ----------------------------------------------------------------------------
+
+def bn_stats(x):
+    x, ld = _rows(x, "bn_stats.x")
+    n, c = x.shape
+    lib = _lib_()
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty(c, dtype=torch.float32, device=x.device)
+    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    check(lib.apr_bn_stats(ptr(x), ld, n, c, ptr(mean), ptr(var), ptr(scratch), sb, stream()))
+    return mean, var
+
+
+def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
+    x, ldx = _rows(x, "affine_act.x")
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    out, ldy = _rows(out, "affine_act.out")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "affine_act.residual")
+    check(_lib_().apr_affine_act(ptr(x), ldx, n, c, ptr(scale), ptr(shift), ptr(residual), ldr, int(bool(relu)),
+                                 ptr(out), ldy, stream()))
+    return out
+
+
+def l2_normalize(x, out=None):
+    x, ldx = _rows(x, "l2_normalize.x")
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    out, ldy = _rows(out, "l2_normalize.out")
+    check(_lib_().apr_l2_normalize(ptr(x), ldx, n, c, ptr(out), ldy, stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------
+# matching / pose
+# ----------------------------------------------------------------------------
+
+def feature_nn(f0, f1, return_distance=False):
+    """Squared-L2 nearest neighbour of every row of f0 in f1 -> int64 [n0] (and d2 f32 [n0])."""
+    f0 = _f32(f0, "feature_nn.f0").contiguous()
+    f1 = _f32(f1, "feature_nn.f1").contiguous()
+    if f0.shape[1] != f1.shape[1]:
+        raise _lib.AprHipError("feature_nn: channel mismatch")
+    n0, c = f0.shape
+    n1 = f1.shape[0]
+    lib = _lib_()
+    best = torch.empty(n0, dtype=torch.int64, device=f0.device)
+    check(lib.apr_feature_nn(ptr(f0), n0, ptr(f1), n1, c, ptr(best), stream()))
+    idx = torch.empty(n0, dtype=torch.int64, device=f0.device)
+    d2 = torch.empty(n0, dtype=torch.float32, device=f0.device) if return_distance else None
+    check(lib.apr_nn_unpack(ptr(best), n0, ptr(idx), ptr(d2), stream()))
+    return (idx, d2) if return_distance else idx
+
+
+def ransac_pose(xyz0, xyz1, corr, max_dist, edge_ratio=0.9, max_iter=4000000, seed=0):
+    """GPU RANSAC + Kabsch.  Returns (T float64 [4,4] numpy, info dict).  Synchronises."""
+    xyz0 = _f32(xyz0, "ransac.xyz0").contiguous()
+    xyz1 = _f32(xyz1, "ransac.xyz1").contiguous()
+    if corr.dtype != torch.int64 or not corr.is_cuda:
+        raise _lib.AprHipError("ransac_pose: corr must be an int64 GPU tensor")
+    corr = corr.contiguous()
+    n0, n1 = xyz0.shape[0], xyz1.shape[0]
+    if corr.shape[0] != n0:
+        raise _lib.AprHipError("ransac_pose: one correspondence per source point expected")
+    lib = _lib_()
+    sb = int(lib.apr_ransac_scratch_bytes(n0, int(max_iter)))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=xyz0.device)
+    res = (C.c_double * 20)()
+    check(lib.apr_ransac_pose(ptr(xyz0), n0, ptr(xyz1), n1, ptr(corr), float(max_dist), float(edge_ratio),
+                              int(max_iter), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(scratch), sb, res, stream()))
+    r = np.array(list(res), dtype=np.float64)
+    T = r[:16].reshape(4, 4).copy()
+    info = dict(inliers=int(r[16]), rmse=float(r[17]), best_iteration=int(r[18]), n_valid=int(r[19]),
+                fitness=float(r[16]) / max(n0, 1))
+    return T, info
+
+
+def irls_pose(pts0, pts1, weight=None):
+    """est_quad_linear_robust on the GPU -> float32 [4,4] CPU tensor.  Synchronises."""
+    pts0 = _f32(pts0, "irls.pts0").contiguous()
+    pts1 = _f32(pts1, "irls.pts1").contiguous()
+    n = pts0.shape[0]
+    if weight is not None:
+        weight = _f32(weight, "irls.weight").contiguous().view(-1)
+    lib = _lib_()
+    sb = int(lib.apr_irls_scratch_bytes(n))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=pts0.device)
+    T = (C.c_float * 16)()
+    check(lib.apr_irls_pose(ptr(pts0), ptr(pts1), ptr(weight), n, T, ptr(scratch), sb, stream()))
+    return torch.tensor(list(T), dtype=torch.float32).view(4, 4)

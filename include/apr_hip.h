@@ -1,0 +1,182 @@
+/*
+ * apr_hip.h -- C ABI of libapr_hip.so, the MI355X (gfx950) implementation of the
+ * APR per-point feature-extraction hot path.
+ *
+ * Every entry point replaces one operator the reference reaches through a
+ * Python binding of third-party or in-tree native code; the citation next to
+ * each declaration is the reference interface it stands in for (paths relative
+ * to /root/reference).  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     nothing synchronises unless the doc says so.
+ *   - return value: 0 on success, negative APR_E* on error; apr_last_error()
+ *     returns a message for the calling thread.
+ *   - row-major tensors with an explicit leading dimension (`ld*`, in elements)
+ *     so a conv can read from / write into a column slice of a wider buffer
+ *     (fused ME.cat).
+ */
+#ifndef APR_HIP_H
+#define APR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APR_OK 0
+#define APR_EINVAL (-1)   /* bad argument / shape */
+#define APR_EHIP (-2)     /* HIP runtime error */
+#define APR_ERANGE (-3)   /* coordinate outside the packed-key range */
+
+const char* apr_last_error(void);
+int apr_version(void);
+/* Number of HIP devices visible; does not initialise a context. */
+int apr_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Voxel hashing / coordinate maps
+ *   replaces MinkowskiEngine's coordinate manager as used at
+ *   FCGF_APR/scripts/test_apr.py:132-137 (ME.SparseTensor(F, coordinates=C)),
+ *   FCGF_APR/lib/complement_data_loader.py:671-674,788-789
+ *   (ME.utils.sparse_quantize(xyz / voxel_size, return_index=True)) and the
+ *   implicit stride-2 maps of FCGF_APR/model/resunet.py:44,57,70.
+ *
+ * Key = (batch:10 | x:18 | y:18 | z:18) biased; open-addressing table of
+ * `cap` (power of two, >= 2n) uint64 keys + int32 values.
+ * ---------------------------------------------------------------------- */
+
+/* Capacity (entries) the table needs for n coordinates. */
+int64_t apr_hash_capacity(int64_t n);
+
+/* Scratch bytes apr_map_build needs for n input rows. */
+size_t apr_map_scratch_bytes(int64_t n);
+
+/* xyz f32[n,3] -> coords i32[n,4] = (batch, floor(x/vs), floor(y/vs), floor(z/vs)),
+ * fp32 division exactly as `xyz / voxel_size` on a float32 array. */
+int apr_voxelize(const float* xyz, int64_t n, float voxel_size, int32_t batch,
+                 int32_t* coords, void* stream);
+
+/* Build one coordinate map.
+ *   n_dev      nullable device row count: only min(n, *n_dev) rows are read, so a
+ *              pyramid of maps can be chained without a host sync per level.
+ *   coords_in  i32[n,4]; if `floor_to` > 0 the x,y,z columns are first floored to
+ *              a multiple of `floor_to` (stride-2 map of a map at stride floor_to/2).
+ *   keys/vals  hash table storage (cap entries each); on return the table maps
+ *              key -> OUTPUT row index.
+ *   out_coords i32[<=n,4]  unique coordinates in first-occurrence order.
+ *   out_first  i64[<=n]    input row of each output row (nullable)
+ *                          (== `index` of sparse_quantize(return_index=True)).
+ *   n_out      i32[1]      device counter; read it back after a stream sync.
+ *   status     i32[1]      device flag, set non-zero on key overflow (APR_ERANGE).
+ */
+int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_dev, int32_t floor_to,
+                  uint64_t* keys, int32_t* vals, int64_t cap,
+                  int32_t* out_coords, int64_t* out_first, int32_t* n_out,
+                  int32_t* status, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Kernel map (neighbour table) of one sparse convolution:
+ *   nbr[j, o] = row i of the input map with c_in[i] == c_out[j] + offset(o) * scale,
+ *   or -1.  offset(o) enumerates {-h..h}^3 x fastest.  scale = +ts_in for a
+ *   regular / strided conv; for a transposed conv pass the FINE map as
+ *   out_coords, the COARSE table as the input table and scale = -ts_fine.
+ *   n_out_dev (nullable): device row count, rows >= *n_out_dev are skipped.
+ *   replaces ME's kernel-map generation behind MinkowskiConvolution /
+ *   MinkowskiConvolutionTranspose (FCGF_APR/model/resunet.py:31-140).
+ */
+int apr_kernel_map(const int32_t* out_coords, int64_t n_out, const int32_t* n_out_dev,
+                   const uint64_t* in_keys, const int32_t* in_vals, int64_t cap,
+                   int32_t kernel_size, int32_t scale, int32_t* nbr, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Sparse convolution forward (gather -> MFMA -> fused epilogue), fp32.
+ *   out[j, :] = act( (sum_o in[nbr[j,o], :] @ W[o]) * scale + shift + residual[j, :] )
+ *   replaces MinkowskiConvolution / MinkowskiConvolutionTranspose forward
+ *   (+ the MinkowskiBatchNorm eval affine, residual add, MEF.relu and ME.cat
+ *   around it: FCGF_APR/model/resunet.py:142-185, residual_block.py:37-53).
+ *   nbr == NULL means K == 1 with the identity map (kernel_size 1: `F @ W`).
+ * ---------------------------------------------------------------------- */
+
+/* Floats needed for the packed copy of a [K,cin,cout] weight. */
+int64_t apr_spconv_packed_size(int32_t K, int32_t cin, int32_t cout);
+/* w f32[K,cin,cout] -> kernel-native layout (cin padded to a multiple of 4,
+ * cout to a multiple of 16). */
+int apr_spconv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout,
+                            float* w_packed, void* stream);
+
+int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_out,
+                   int32_t K, int32_t cin, int32_t cout, const float* w_packed,
+                   const float* scale, const float* shift,
+                   const float* residual, int64_t ldr, int32_t relu,
+                   float* out, int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Normalisation / elementwise on feature rows [n, c]
+ * ---------------------------------------------------------------------- */
+
+/* Per-channel batch statistics over rows (training-mode MinkowskiBatchNorm,
+ * FCGF_APR/model/common.py:6): mean[c], biased var[c].  fp64 accumulation. */
+int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c,
+                 float* mean, float* var, void* scratch, size_t scratch_bytes, void* stream);
+size_t apr_bn_stats_scratch_bytes(int64_t n, int32_t c);
+
+/* y = act(x * scale[c] + shift[c] (+ residual)); scale/shift/residual nullable. */
+int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c,
+                   const float* scale, const float* shift,
+                   const float* residual, int64_t ldr, int32_t relu,
+                   float* y, int64_t ldy, void* stream);
+
+/* Row L2 normalisation F / ||F||_2 (FCGF_APR/model/resunet.py:187-191). */
+int apr_l2_normalize(const float* x, int64_t ldx, int64_t n, int32_t c,
+                     float* y, int64_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Feature nearest neighbour (squared L2), replaces find_nn_gpu / pdist
+ *   (FCGF_APR/lib/eval.py:18-48, lib/metrics.py:22-29) and the feature KD-tree
+ *   search inside open3d's registration_ransac_based_on_feature_matching
+ *   (FCGF_APR/scripts/test_apr.py:148-156).
+ *   best[i] = (bits(d2) << 32) | j  minimising d2 = ||F0[i]-F1[j]||^2, ties ->
+ *   smallest j.  d2 is accumulated in a fixed fp32 order (4 interleaved fma
+ *   chains) so the C oracle reproduces it bit for bit.
+ *   `best` must be u64[n0]; it is initialised by the call.
+ * ---------------------------------------------------------------------- */
+int apr_feature_nn(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c,
+                   uint64_t* best, void* stream);
+/* Unpack: idx i64[n], d2 f32[n] (either nullable). */
+int apr_nn_unpack(const uint64_t* best, int64_t n, int64_t* idx, float* d2, void* stream);
+
+/* ------------------------------------------------------------------------
+ * RANSAC + Kabsch (SVD) pose from feature correspondences, replaces
+ *   open3d registration_ransac_based_on_feature_matching as called at
+ *   FCGF_APR/scripts/test_apr.py:148-156 and
+ *   Predator_APR/lib/benchmark_utils.py:213-225.
+ *   corr i64[n0]: target index of every source point (from apr_feature_nn).
+ *   Hypothesis `it` samples ransac_n=4 source indices from a counter-based RNG
+ *   (seed, it, slot); edge-length checker (ratio), Kabsch without scale in fp64,
+ *   distance checker; every surviving hypothesis is scored by the number of
+ *   correspondences within `max_dist` (then lower RMSE, then lower `it`).
+ *   result_host f64[20]: T (row-major 4x4), inliers, rmse, best_it, n_valid.
+ *   Synchronises the stream before returning.
+ * ---------------------------------------------------------------------- */
+size_t apr_ransac_scratch_bytes(int64_t n0, int64_t max_iter);
+int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1,
+                    const int64_t* corr, double max_dist, double edge_ratio,
+                    int64_t max_iter, uint64_t seed,
+                    void* scratch, size_t scratch_bytes, double* result_host, void* stream);
+
+/* Robust linearised 6-DoF pose (20 IRLS iterations), replaces
+ * est_quad_linear_robust (FCGF_APR/util/transform_estimation.py:89-116).
+ * pts0/pts1 f32[n,3] paired, weight f32[n] nullable; T_host f32[16]; syncs. */
+int apr_irls_pose(const float* pts0, const float* pts1, const float* weight, int64_t n,
+                  float* T_host, void* scratch, size_t scratch_bytes, void* stream);
+size_t apr_irls_scratch_bytes(int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APR_HIP_H */

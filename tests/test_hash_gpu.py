@@ -1,0 +1,93 @@
+"""Voxel hashing / coordinate maps / kernel maps: HIP vs oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from apr_amd import ops, synth
+from oracle import me_oracle as OME
+
+pytestmark = pytest.mark.gpu
+
+
+def _quantize_gpu(xyz, vs, dev):
+    c = ops.voxelize(torch.from_numpy(xyz).to(dev), vs, 0)
+    m = ops.build_map(c, want_first=True)
+    ops.finalize_maps([m])
+    return m
+
+
+@pytest.mark.parametrize("seed,small", [(0, True), (1, True), (0, False)])
+def test_sparse_quantize_matches_oracle(dev, seed, small):
+    xyz = synth.make_small_frame(seed) if small else synth.make_frame(seed)
+    oc, osel = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+    m = _quantize_gpu(xyz, 0.3, dev)
+    assert m.n == len(oc)
+    assert np.array_equal(m.first.cpu().numpy(), osel)
+    assert np.array_equal(m.coords[:, 1:].cpu().numpy(), oc)
+
+
+def test_sparse_quantize_shim_api(dev):
+    from apr_amd import MinkowskiEngine as ME
+    xyz = synth.make_small_frame(3)
+    oc, osel = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+    c, sel = ME.utils.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+    assert isinstance(c, np.ndarray) and np.array_equal(c, oc) and np.array_equal(sel, osel)
+    ct, selt = ME.utils.sparse_quantize(torch.from_numpy(xyz) / 0.3, return_index=True)
+    assert torch.is_tensor(selt) and np.array_equal(selt.numpy(), osel)
+    bc = ME.utils.batched_coordinates([oc, oc[:10]])
+    assert np.array_equal(bc.numpy(), OME.batched_coordinates([oc, oc[:10]]))
+
+
+def test_empty_and_duplicates(dev):
+    from apr_amd import MinkowskiEngine as ME
+    from apr_amd._lib import AprHipError
+    c = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    m = ops.build_map(c)
+    ops.finalize_maps([m])
+    assert m.n == 0
+    # all points in one voxel
+    xyz = np.full((1000, 3), 0.1, np.float32)
+    uc, sel = ME.utils.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+    assert len(uc) == 1 and sel[0] == 0
+    # duplicate coordinates handed to SparseTensor are an error, as in ME
+    C = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3]], dtype=torch.int32)
+    st = ME.SparseTensor(torch.ones(2, 1).to(dev), coordinates=C.to(dev))
+    with pytest.raises(AprHipError):
+        st.coordinate_manager.get_map(1)
+    # out-of-range coordinate
+    C = torch.tensor([[0, 1 << 20, 0, 0]], dtype=torch.int32)
+    st = ME.SparseTensor(torch.ones(1, 1).to(dev), coordinates=C.to(dev))
+    with pytest.raises(AprHipError):
+        st.coordinate_manager.get_map(1)
+
+
+def test_pyramid_and_kernel_maps(dev):
+    from apr_amd.MinkowskiEngine.core import CoordinateManager
+    C0 = OME.batched_coordinates([OME.sparse_quantize(synth.make_small_frame(s) / np.float32(0.3)) for s in (0, 5)])
+    ocm = OME.CoordinateManager(C0)
+    cm = CoordinateManager(torch.from_numpy(C0).to(dev))
+    cm.build_pyramid([2, 4, 8])
+    for ts in (1, 2, 4, 8):
+        assert np.array_equal(cm.get_map(ts).coords.cpu().numpy(), ocm.get_coords(ts)), ts
+    # regular + strided maps
+    for (ti, to, k) in [(1, 1, 3), (1, 1, 5), (1, 2, 3), (2, 2, 3), (2, 4, 3), (4, 4, 3), (4, 8, 3), (8, 8, 3)]:
+        nbr = cm.kernel_map(ti, to, k).cpu().numpy()
+        assert np.array_equal(nbr, ocm.get_map(ti, to, k)), (ti, to, k)
+    # transposed maps = forward strided map with in/out swapped
+    for (tc, tf) in [(8, 4), (4, 2), (2, 1)]:
+        nbr = cm.kernel_map(tc, tf, 3, True).cpu().numpy()
+        ref = OME.transpose_map(ocm.get_map(tf, tc, 3), len(ocm.get_coords(tf)))
+        assert np.array_equal(nbr, ref), (tc, tf)
+
+
+def test_negative_coordinates_floor(dev):
+    # floor semantics for negative coords (floor-to-multiple, not truncation)
+    rng = np.random.default_rng(0)
+    C0 = np.unique(np.concatenate([np.zeros((500, 1), np.int32),
+                                   rng.integers(-40, 40, size=(500, 3)).astype(np.int32)], 1), axis=0)
+    rng.shuffle(C0)
+    from apr_amd.MinkowskiEngine.core import CoordinateManager
+    cm = CoordinateManager(torch.from_numpy(C0).to(dev))
+    ocm = OME.CoordinateManager(C0)
+    for ts in (2, 4):
+        assert np.array_equal(cm.get_map(ts).coords.cpu().numpy(), ocm.get_coords(ts))

@@ -1,0 +1,155 @@
+"""Feature NN (bit-exact), RANSAC + Kabsch and IRLS pose vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from apr_amd import ops, synth
+from apr_amd.fcgf import registration
+from apr_amd.fcgf.lib.eval import find_nn_gpu
+from apr_amd.fcgf.util.transform_estimation import est_quad_linear_robust
+from oracle import match_pose_oracle as MO
+from oracle import me_oracle as OME
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n0,n1,c", [(5000, 5000, 32), (777, 3001, 32), (1500, 900, 128), (1000, 1000, 16),
+                                      (300, 700, 64), (257, 513, 20), (64, 1, 32)])
+def test_feature_nn_bit_exact(dev, n0, n1, c):
+    rng = np.random.default_rng(n0 + n1 + c)
+    F0 = rng.standard_normal((n0, c)).astype(np.float32)
+    F1 = rng.standard_normal((n1, c)).astype(np.float32)
+    F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+    F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    F1[n1 // 2] = F1[0]  # exact tie -> smallest index must win
+    oi, od = MO.feature_nn(F0, F1)
+    idx, d2 = ops.feature_nn(torch.from_numpy(F0).to(dev), torch.from_numpy(F1).to(dev), return_distance=True)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_find_nn_gpu_reference_api(dev):
+    """find_nn_gpu(F0, F1, nn_max_n=500) as called by find_corr (scripts/test_apr.py:52)."""
+    rng = np.random.default_rng(0)
+    F0 = torch.from_numpy(rng.standard_normal((1200, 32)).astype(np.float32))
+    F1 = torch.from_numpy(rng.standard_normal((900, 32)).astype(np.float32))
+    inds = find_nn_gpu(F0.to(dev), F1.to(dev), nn_max_n=500)
+    ref = MO.pdist(F0, F1, 'SquareL2').min(1)[1]
+    assert inds.device.type == "cpu" and inds.dtype == torch.int64
+    assert (inds == ref).float().mean() > 0.999   # torch's sum order may flip a near tie
+    inds2, d = find_nn_gpu(F0.to(dev), F1.to(dev), nn_max_n=500, return_distance=True, dist_type='L2')
+    assert d.shape == (1200, 1)
+    assert torch.allclose(d[:, 0], MO.pdist(F0, F1, 'L2').min(1)[0], rtol=1e-5, atol=1e-6)
+
+
+def _synthetic_pair(seed, n=3000, inlier=0.5, noise=0.03):
+    """Source points, a known rigid transform, and features whose NN is the true match for ~inlier of them."""
+    rng = np.random.default_rng(seed)
+    xyz0 = rng.uniform(-30, 30, size=(n, 3)).astype(np.float32)
+    a = np.deg2rad(rng.uniform(-20, 20))
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    t = rng.uniform(-5, 5, size=3)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    perm = rng.permutation(n)
+    xyz1 = np.empty_like(xyz0)
+    xyz1[perm] = (xyz0 @ R.T + t + rng.normal(0, noise, size=(n, 3))).astype(np.float32)
+    F0 = rng.standard_normal((n, 32)).astype(np.float32)
+    F1 = np.empty_like(F0)
+    F1[perm] = F0 + 0.05 * rng.standard_normal((n, 32)).astype(np.float32)
+    bad = rng.random(n) > inlier
+    F0[bad] = rng.standard_normal((int(bad.sum()), 32)).astype(np.float32)
+    return xyz0, xyz1, F0, F1, T
+
+
+@pytest.mark.parametrize("seed,inlier", [(0, 0.5), (1, 0.25), (2, 0.8)])
+def test_ransac_matches_oracle_and_ground_truth(dev, seed, inlier):
+    xyz0, xyz1, F0, F1, T_gt = _synthetic_pair(seed, inlier=inlier)
+    corr_o, _ = MO.feature_nn(F0, F1)
+    T_o, info_o = MO.ransac_feature_matching(xyz0, xyz1, corr_o, 0.3, 0.9, max_iter=60000, seed=seed)
+    T, info = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, ransac_n=4, edge_length=0.9,
+                                                    max_iteration=60000, seed=seed, return_info=True)
+    assert info["n_valid"] == info_o["n_valid"] > 0
+    assert info["inliers"] == info_o["inliers"]
+    assert info["best_iteration"] == info_o["best_iteration"]
+    rte, rre = registration.rte_rre(T, T_o)
+    assert rte < 1e-3 and rre < 1e-3          # bar: 1e-3 m / 1e-3 deg vs the CPU path
+    assert abs(info["rmse"] - info_o["rmse"]) < 1e-9
+    rte, rre = registration.rte_rre(T, T_gt)  # and it actually registers the pair
+    assert rte < 0.3 and rre < 1.0
+
+
+def test_ransac_no_valid_hypothesis_returns_identity(dev):
+    rng = np.random.default_rng(0)
+    xyz0 = rng.uniform(-30, 30, (500, 3)).astype(np.float32)
+    xyz1 = rng.uniform(-30, 30, (500, 3)).astype(np.float32)
+    corr = torch.from_numpy(rng.integers(0, 500, 500)).to(dev)
+    T, info = ops.ransac_pose(torch.from_numpy(xyz0).to(dev), torch.from_numpy(xyz1).to(dev), corr, 0.05, 0.99,
+                              max_iter=2000, seed=1)
+    T_o, info_o = MO.ransac_feature_matching(xyz0, xyz1, corr.cpu().numpy(), 0.05, 0.99, max_iter=2000, seed=1)
+    assert info["n_valid"] == info_o["n_valid"]
+    if info["n_valid"] == 0:
+        assert np.array_equal(T, np.eye(4))
+
+
+def test_ransac_full_reference_criteria(dev):
+    """The reference's criteria (4 000 000 iterations) on a KITTI-sized correspondence set; checked
+    against ground truth (the oracle would take hours at this size)."""
+    xyz0, xyz1, F0, F1, T_gt = _synthetic_pair(11, n=15000, inlier=0.2)
+    T, info = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, max_iteration=4000000, seed=5,
+                                                    return_info=True)
+    rte, rre = registration.rte_rre(T, T_gt)
+    assert rte < 0.2 and rre < 0.5 and info["inliers"] > 0.15 * 15000
+
+
+@pytest.mark.parametrize("seed,weighted", [(0, False), (1, True)])
+def test_irls_matches_oracle_and_recovers_pose(dev, seed, weighted):
+    rng = np.random.default_rng(seed)
+    n = 5000
+    p0 = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+    ang = np.deg2rad(rng.uniform(-3, 3, 3))
+    x = torch.tensor([[ang[0]], [ang[1]], [ang[2]], [0.4], [-0.3], [0.2]], dtype=torch.float32)
+    T_gt = MO._get_trans(x)
+    p1 = (torch.from_numpy(p0) @ T_gt[:3, :3].t() + T_gt[:3, 3]).numpy()
+    p1 += rng.normal(0, 0.01, p1.shape).astype(np.float32)
+    out = rng.random(n) < 0.1
+    p1[out] += rng.uniform(-5, 5, (int(out.sum()), 3)).astype(np.float32)
+    w = torch.from_numpy(rng.uniform(0.2, 1.0, (n, 1)).astype(np.float32)) if weighted else None
+    T_o = MO.est_quad_linear_robust(torch.from_numpy(p0), torch.from_numpy(p1), w)
+    T = est_quad_linear_robust(torch.from_numpy(p0), torch.from_numpy(p1), w)
+    assert T.dtype == torch.float32 and T.shape == (4, 4) and T.device.type == "cpu"
+    rte, rre = registration.rte_rre(T.numpy(), T_o.numpy())
+    assert rte < 1e-3 and rre < 1e-3
+    rte, rre = registration.rte_rre(T.numpy(), T_gt.numpy())
+    assert rte < 0.02 and rre < 0.05
+
+
+def test_end_to_end_pair_pipeline(dev):
+    """voxelise -> encode both frames -> feature NN -> RANSAC on a small synthetic pair, vs the oracle chain."""
+    from apr_amd import MinkowskiEngine as ME
+    from tests.helpers import model_pair, rel_l2
+    om, hm = model_pair("ResUNetBN2C", 32)
+    om.eval(); hm.eval()
+    xyz0, xyz1, T_gt = synth.make_pair(0, n_beams=16, n_azimuth=1250)
+    feats_o, feats_h, pts = [], [], []
+    for xyz in (xyz0, xyz1):
+        c, sel = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+        C = OME.batched_coordinates([c]); F = np.ones((len(C), 1), np.float32)
+        pts.append(xyz[sel])
+        with torch.no_grad():
+            feats_o.append(om(OME.SparseTensor(F, coordinates=C)).F.numpy())
+            # product path: GPU voxel hash end to end
+            cg = ops.voxelize(torch.from_numpy(xyz).to(dev), 0.3, 0)
+            m = ops.build_map(cg, want_first=True); ops.finalize_maps([m])
+            assert np.array_equal(m.first.cpu().numpy(), sel)
+            x = ME.SparseTensor(torch.ones((m.n, 1), device=dev), coordinates=m.coords)
+            feats_h.append(hm(x).F)
+    assert rel_l2(feats_h[0].cpu(), feats_o[0]) < 2e-5 and rel_l2(feats_h[1].cpu(), feats_o[1]) < 2e-5
+    # same features in -> identical correspondences and pose out
+    corr_o, _ = MO.feature_nn(feats_o[0], feats_o[1])
+    T_o, info_o = MO.ransac_feature_matching(pts[0], pts[1], corr_o, 0.3, 0.9, max_iter=20000, seed=3)
+    F0 = torch.from_numpy(feats_o[0]).to(dev); F1 = torch.from_numpy(feats_o[1]).to(dev)
+    T, info = registration.ransac_feature_matching(pts[0], pts[1], F0, F1, 0.3, max_iteration=20000, seed=3,
+                                                    return_info=True)
+    assert info["n_valid"] == info_o["n_valid"] and info["inliers"] == info_o["inliers"]
+    rte, rre = registration.rte_rre(T, T_o)
+    assert rte < 1e-3 and rre < 1e-3

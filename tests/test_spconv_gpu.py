@@ -1,0 +1,101 @@
+"""Sparse-conv / norm kernels vs the torch-CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from apr_amd import ops
+from oracle import me_oracle as OME
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_conv(x, nbr, W, scale=None, shift=None, residual=None, relu=False):
+    n_out = nbr.shape[0]
+    out = torch.zeros(n_out, W.shape[2], dtype=torch.float64)
+    xd, Wd = x.double(), W.double()
+    for o in range(nbr.shape[1]):
+        j = np.nonzero(nbr[:, o] >= 0)[0]
+        if len(j):
+            out.index_add_(0, torch.from_numpy(j), xd[torch.from_numpy(nbr[j, o].astype(np.int64))] @ Wd[o])
+    if scale is not None:
+        out = out * scale.double()
+    if shift is not None:
+        out = out + shift.double()
+    if residual is not None:
+        out = out + residual.double()
+    return torch.relu(out) if relu else out
+
+
+def _random_map(rng, n_in, n_out, K, density):
+    nbr = rng.integers(0, n_in, size=(n_out, K)).astype(np.int32)
+    nbr[rng.random((n_out, K)) > density] = -1
+    return nbr
+
+
+@pytest.mark.parametrize("cin,cout,K,n_in,n_out", [
+    (32, 32, 27, 3000, 3000), (32, 64, 27, 3000, 1100), (64, 64, 27, 5000, 5000), (64, 128, 27, 2000, 700),
+    (128, 128, 27, 900, 900), (256, 128, 27, 300, 900), (192, 64, 27, 900, 2500), (96, 64, 1, 4000, 4000),
+    (64, 32, 1, 4001, 4001), (384, 128, 27, 500, 1300), (1, 32, 125, 3000, 3000), (3, 32, 27, 1000, 1000),
+    (64, 64, 27, 70000, 70000), (32, 32, 27, 40000, 40000), (5, 7, 27, 333, 333), (64, 64, 27, 31, 31),
+])
+def test_spconv_matches_oracle(dev, cin, cout, K, n_in, n_out):
+    rng = np.random.default_rng(cin * 1000 + cout + K)
+    x = torch.from_numpy(rng.standard_normal((n_in, cin)).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32))
+    if K == 1:
+        nbr = None
+        nbr_o = np.arange(n_out, dtype=np.int32)[:, None]
+    else:
+        nbr = nbr_o = _random_map(rng, n_in, n_out, K, 0.27)
+    wp = ops.pack_weights(W.to(dev))
+    out = ops.spconv(x.to(dev), None if nbr is None else torch.from_numpy(nbr).to(dev), K, cin, cout, wp,
+                     n_out=n_out)
+    ref = _oracle_conv(x, nbr_o, W)
+    assert rel_l2(out.cpu(), ref) < 2e-6
+
+
+def test_spconv_fused_epilogue_and_slices(dev):
+    rng = np.random.default_rng(7)
+    n, cin, cout, K = 2111, 64, 64, 27
+    wide_in = torch.from_numpy(rng.standard_normal((n, cin + 32)).astype(np.float32)).to(dev)
+    x = wide_in[:, 32:]                      # column slice as input
+    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / 20).astype(np.float32))
+    nbr = _random_map(rng, n, n, K, 0.3)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32))
+    wide_out = torch.zeros((n, cout + 64), device=dev)
+    ops.spconv(x, torch.from_numpy(nbr).to(dev), K, cin, cout, ops.pack_weights(W.to(dev)), scale=scale.to(dev),
+               shift=shift.to(dev), residual=res.to(dev), relu=True, out=wide_out[:, 64:])
+    ref = _oracle_conv(x.cpu(), nbr, W, scale, shift, res, True)
+    assert rel_l2(wide_out[:, 64:].cpu(), ref) < 2e-6
+    assert float(wide_out[:, :64].abs().max()) == 0.0   # nothing written outside the slice
+
+
+def test_all_empty_offsets(dev):
+    n, c = 100, 32
+    nbr = torch.full((n, 27), -1, dtype=torch.int32, device=dev)
+    x = torch.ones((n, c), device=dev)
+    W = torch.ones((27, c, c), device=dev)
+    shift = torch.full((c,), 2.0, device=dev)
+    out = ops.spconv(x, nbr, 27, c, c, ops.pack_weights(W), shift=shift)
+    assert torch.equal(out.cpu(), torch.full((n, c), 2.0))
+
+
+def test_bn_stats_affine_l2(dev):
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy((rng.standard_normal((7777, 96)) * 3 + 5).astype(np.float32))
+    mean, var = ops.bn_stats(x.to(dev))
+    assert torch.allclose(mean.cpu(), x.double().mean(0).float(), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(var.cpu(), x.double().var(0, unbiased=False).float(), rtol=1e-5, atol=1e-6)
+    y = ops.affine_act(x.to(dev), scale=mean, shift=var, relu=True)
+    assert torch.allclose(y.cpu(), torch.relu(x * mean.cpu() + var.cpu()), rtol=1e-6, atol=1e-5)
+    z = ops.l2_normalize(x.to(dev))
+    assert rel_l2(z.cpu(), x / x.norm(dim=1, keepdim=True)) < 1e-6
+
+
+def test_cpu_tensors_fail_loudly():
+    from apr_amd._lib import AprHipError
+    with pytest.raises(AprHipError):
+        ops.affine_act(torch.ones(4, 4))
