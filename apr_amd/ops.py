@@ -124,6 +124,39 @@ def pack_weights(w: torch.Tensor) -> torch.Tensor:
     return wp
 
 
+class SpconvProfile:
+    """Optional per-launch HIP-event timing of the sparse-conv kernel (bench.py roofline leg).
+
+    Records (pairs P, cin, cout, mfma?, start, end) for every launch while active;
+    events are recorded on the current stream, i.e. the stream the kernel runs on.
+    """
+
+    def __init__(self):
+        self.records = []
+
+    def pairs(self, nbr, n_out):
+        if nbr is None:
+            return int(n_out)
+        return int((nbr >= 0).sum().item())  # not cached: map storage is recycled between pairs
+
+    def summary(self):
+        """-> dict with algorithmic bytes / flops and summed kernel time of the MFMA launches."""
+        torch.cuda.synchronize()
+        tot_b = tot_f = tot_ms = 0.0
+        n = 0
+        for (P, cin, cout, mfma, e0, e1) in self.records:
+            if not mfma:
+                continue
+            tot_b += 4.0 * P * (cin + cout) + 8.0 * P
+            tot_f += 2.0 * P * cin * cout
+            tot_ms += e0.elapsed_time(e1)
+            n += 1
+        return dict(launches=n, bytes=tot_b, flops=tot_f, ms=tot_ms)
+
+
+PROFILE = None  # set to a SpconvProfile to time launches
+
+
 def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None):
     """out[j] = act((sum_o x[nbr[j,o]] @ W[o]) * scale + shift + residual[j]).
 
@@ -148,8 +181,16 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         residual, ldr = _rows(residual, "spconv.residual")
         if residual.shape[0] != n_out or residual.shape[1] != cout:
             raise _lib.AprHipError("spconv: residual shape mismatch")
+    prof = PROFILE
+    if prof is not None:
+        P = prof.pairs(nbr, n_out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib_().apr_spconv_fwd(ptr(x), ldi, ptr(nbr), n_out, K, cin, cout, ptr(wp), ptr(scale), ptr(shift),
                                  ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
+    if prof is not None:
+        e1.record()
+        prof.records.append((P, cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0, e0, e1))
     return out
 
 

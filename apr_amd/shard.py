@@ -1,0 +1,49 @@
+"""Multi-GPU sharding of independent scan pairs.
+
+Pairs are independent units: rank r of W owns a contiguous block of the pair
+list and never exchanges data-path tensors.  The only collectives are the
+barrier around the timed region and one end-of-run gather of a few floats per
+rank (pairs done, seconds, max errors) -- RCCL over xGMI on the GPU box
+(backend "nccl"), gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of rank `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def rank_seeds(rank: int, count: int, per_rank: int = 64):
+    """Synthetic pair seeds of a rank: 64*rank + i (BASELINE config 4: 512 pairs over 8 GPUs)."""
+    return [per_rank * rank + i for i in range(count)]
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_stats(stats, device):
+    """all_gather a short list of floats per rank -> [world, len(stats)] tensor (CPU)."""
+    t = torch.tensor(list(stats), dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return t.cpu().unsqueeze(0)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu()
+
+
+def aggregate_throughput(stats_matrix):
+    """Whole-job pairs/s = total pairs / max seconds over ranks (columns: pairs, seconds, ...)."""
+    pairs = float(stats_matrix[:, 0].sum())
+    secs = float(stats_matrix[:, 1].max())
+    return pairs / secs if secs > 0 else 0.0

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- pairs/sec of the FCGF_APR hot path on MI355X (BASELINE.json metric).
+
+A "step" = one synthetic KITTI-shaped scan pair (2 x ~118 k points) through
+voxel hash -> sparse ResUNet encode (both frames) -> feature NN -> RANSAC(4 M
+iterations, the reference's criteria) + Kabsch, with the raw xyz of the pair
+already resident in HBM when the timed region starts (BASELINE config[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, independent pairs per rank (no data-path
+collective; RCCL only for the barrier and the max-over-ranks time), weak scaling.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="ResUNetBN2C")
+    ap.add_argument("--n-out", type=int, default=32)
+    ap.add_argument("--ransac-iters", type=int, default=4000000)
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(name, n_out, dev):
+    from apr_amd.fcgf.model import load_model
+    torch.manual_seed(0)
+    m = load_model(name)(1, n_out, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    g = torch.Generator().manual_seed(0)
+    for mod in m.modules():            # non-trivial eval-mode BN
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+    return m.to(dev).eval()
+
+
+def cpu_baseline(state_dict, name, n_out, pair, ransac_iters):
+    """The oracle (a CPU port of the reference path) timed on this box's host cores, one pair."""
+    from oracle import match_pose_oracle as MO
+    from oracle import me_oracle as OME
+    from oracle import resunet_oracle as OR
+    cores = MO.host_threads()      # this process's CPU share, not the host's core count
+    torch.set_num_threads(cores)
+    om = OR.MODELS[name](1, n_out, bn_momentum=0.05, normalize_feature=True, conv1_kernel_size=5, D=3)
+    om.load_state_dict({k: v.cpu() for k, v in state_dict.items()})
+    om.eval()
+    xyz0, xyz1 = pair
+    iters = min(ransac_iters, 400000)
+    t0 = time.perf_counter()
+    feats, pts = [], []
+    for xyz in (xyz0, xyz1):
+        c, sel = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+        C = OME.batched_coordinates([c])
+        with torch.no_grad():
+            feats.append(om(OME.SparseTensor(np.ones((len(C), 1), np.float32), coordinates=C)).F.numpy())
+        pts.append(xyz[sel])
+    t1 = time.perf_counter()
+    corr, _ = MO.feature_nn(feats[0], feats[1], nthreads=cores)
+    t2 = time.perf_counter()
+    MO.ransac_feature_matching(pts[0], pts[1], corr, 0.3, 0.9, max_iter=iters, seed=0)
+    t3 = time.perf_counter()
+    ransac_full = (t3 - t2) * (ransac_iters / iters)
+    total = (t1 - t0) + (t2 - t1) + ransac_full
+    return {"value": 1.0 / total, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": (f"1 pair: voxelise+encode 2 frames {t1 - t0:.2f}s, feature NN {t2 - t1:.2f}s, RANSAC "
+                       f"{iters} of {ransac_iters} iterations {t3 - t2:.2f}s scaled x{ransac_iters / iters:.0f}")}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from apr_amd import ops, shard, synth
+    from apr_amd.fcgf.pipeline import PairRegistration
+
+    model = build_model(args.model, args.n_out, dev)
+    pipe = PairRegistration(model, voxel_size=0.3, ransac_iters=args.ransac_iters)
+
+    # synthetic pairs of this rank (seeds 64*rank + i); upload before timing
+    host_pairs = [synth.make_pair(s)[:2] for s in shard.rank_seeds(rank, args.pool)]
+    pairs = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in host_pairs]
+    n_pts = float(np.mean([len(a) + len(b) for a, b in host_pairs])) / 2
+
+    def step(i):
+        a, b = pairs[i % len(pairs)]
+        return pipe(a, b, seed=i)
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        T, info = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, dev)   # RCCL all-reduce(MAX) of one double
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log(f"timed loop: {args.steps} steps in {elapsed:.3f}s")
+    out = {
+        "metric": "point-cloud pairs/sec (120k-pt KITTI frame, FCGF encode+match+SVD)",
+        "value": world * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "FCGF_APR encode+match+SVD, one 120k-point KITTI-shaped pair per step, voxel_size=0.3",
+                   "encoder": args.model, "feature_dim": args.n_out, "points_per_frame": int(n_pts),
+                   "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
+                   "pairs_per_step": 1, "sharding": f"{world} ranks x independent pairs"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass: HIP events around every sparse-conv launch, on the launch stream
+        prof = ops.SpconvProfile()
+        ops.PROFILE = prof
+        nprof = max(1, min(args.steps, 5))
+        for i in range(nprof):
+            a, b = pairs[i % len(pairs)]
+            coords, _, _, n0, _ = pipe.voxelize_pair(a, b)
+            pipe.encode_pair(coords, n0)
+        ops.PROFILE = None
+        s = prof.summary()
+        log(f"roofline pass: {s}")
+        gbs = s["bytes"] / (s["ms"] * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "k_spconv_mfma (sparse-conv gather->MFMA->fused epilogue)",
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None,
+            "launches_per_encode": s["launches"] // nprof,
+            "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
+            "avg_launch_us": 1000.0 * s["ms"] / s["launches"],
+            "mfma_tflops": s["flops"] / (s["ms"] * 1e-3) / 1e12,
+            "mfma_frac_of_f32_peak": s["flops"] / (s["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle on host cores) ...")
+        out["cpu_baseline"] = cpu_baseline(model.state_dict(), args.model, args.n_out, host_pairs[0],
+                                           args.ransac_iters)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,8 +25,9 @@ static inline float sqdist(const float* a, const float* b, int c) {
 }
 
 void nn_sqdist_argmin(const float* f0, int64_t n0, const float* f1, int64_t n1, int c,
-                      int64_t* idx, float* d2) {
-#pragma omp parallel for schedule(static)
+                      int64_t* idx, float* d2, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
   for (int64_t i = 0; i < n0; ++i) {
     float best = INFINITY;
     int64_t bj = -1;

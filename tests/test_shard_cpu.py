@@ -1,0 +1,52 @@
+"""N > 1 path on CPU: two gloo ranks shard the pair list, gather stats and agree on the aggregate."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from apr_amd import shard
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard.shard_range(11, rank, world)
+    seeds = shard.rank_seeds(rank, hi - lo)
+    secs = 1.0 + rank                       # rank 1 is slower
+    m = shard.gather_stats([hi - lo, secs, 1e-6 * (rank + 1)], torch.device("cpu"))
+    t = shard.max_over_ranks(secs, torch.device("cpu"))
+    dist.barrier()
+    q.put((rank, lo, hi, seeds, m.tolist(), t, shard.aggregate_throughput(m)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(30) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (r0, lo0, hi0, s0, m0, t0, a0), (r1, lo1, hi1, s1, m1, t1, a1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 6, 6, 11)                 # contiguous, covers all 11 pairs once
+    assert s0 == [0, 1, 2, 3, 4, 5] and s1 == [64, 65, 66, 67, 68]
+    assert m0 == m1 and m0[0][:2] == [6.0, 1.0] and m0[1][:2] == [5.0, 2.0]
+    assert t0 == t1 == 2.0                                        # max over ranks
+    assert abs(a0 - 11 / 2.0) < 1e-12 and a0 == a1
+
+
+def test_shard_range_edge_cases():
+    assert shard.shard_range(0, 0, 4) == (0, 0)
+    got = [shard.shard_range(10, r, 4) for r in range(4)]
+    assert got == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard.shard_range(512, 7, 8) == (448, 512)
+    assert shard.gather_stats([1, 2], torch.device("cpu")).shape == (1, 2)   # no process group: world of one
