@@ -85,7 +85,8 @@ def ptr(t):
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream (fast path: no Python Stream object)."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def require_gpu_tensor(t, dtype, name):

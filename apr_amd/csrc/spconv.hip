@@ -19,6 +19,8 @@
 //   * fp32 in / fp32 accumulate MFMA (exact f32; gfx950 has no xf32), so features
 //     match the fp32 oracle to ~1e-6.
 // Algorithmic bytes per launch: 4*P*(cin+cout) + 8*P, P = kernel-map pairs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -180,6 +182,253 @@ __global__ __launch_bounds__(256) void k_spconv_mfma(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// v2: pair-compacted, wave-autonomous kernel (the default).
+//
+// A workgroup still owns TM output rows x CN output channels, but instead of multiplying
+// zero-padded [TM x Cin] blocks for every offset it first compacts, per offset k, the
+// (input row, output row) pairs that exist (wave64 ballot + popcount into LDS lists), then
+//   * work item = (offset k, Cin chunk); items are dealt statically to the 4 waves;
+//   * a wave loads the item's weight piece W[k][chunk][CN] ONCE into registers (CK*CN*4 B,
+//     coalesced 16-B loads of the pre-packed layout) and walks that offset's pairs in groups
+//     of 16: the A fragments are gathered straight from global memory into the MFMA register
+//     layout (lane (r,q) loads in[idx_r][16j+4q..+3]; no LDS staging, no barrier),
+//     CK/4 x CN/16 v_mfma_f32_16x16x4_f32, and the 16 x CN result is added (ds_add_f32) into
+//     the wave's PRIVATE accumulator tile in LDS at the pairs' output rows;
+//   * one barrier, then the epilogue sums the 4 private tiles in fixed order, applies
+//     scale/shift/residual/ReLU and stores whole rows with 16-B stores.
+// MFMA work is padded only to 16 pairs per (tile, offset) (~1.3x) instead of ~2.2-2.7x for
+// the dense-tile form, there is no barrier in the main loop, and the summation order is
+// fixed (static item deal + in-order LDS adds per wave) => bitwise reproducible.
+// ---------------------------------------------------------------------------------------
+constexpr int kKMax = 27;
+
+
+template <int TM, int CN, int CK>
+__global__ __launch_bounds__(256, 2) void k_spconv_pairs(
+    const float* __restrict__ in, int64_t ldi, const int* __restrict__ nbr, int n_out, int K,
+    int cin, int cout, const float* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ residual, int64_t ldr, int relu,
+    float* __restrict__ out, int64_t ldo) {
+  constexpr int CB = CN / 16;   // 16-col blocks per wave item
+  constexpr int NJ = CK / 16;   // 16-wide k groups per chunk
+  constexpr int LDO = CN + 4;   // accumulator row stride (floats), 16-B aligned rows
+  static_assert(TM * kKMax <= 4 * TM * LDO, "nbr staging must fit in the accumulator region");
+
+  __shared__ __attribute__((aligned(16))) float s_acc[4 * TM * LDO];
+  __shared__ int s_in[kKMax * TM];
+  __shared__ __attribute__((aligned(4))) unsigned char s_row[kKMax * TM];
+  __shared__ int s_cnt[32];
+  __shared__ int s_act[32];
+  __shared__ int s_nact;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int lin = xcd * (nb >> 3) + min(xcd, nb & 7) + loc;
+  const int ncol = cout / CN;
+  const int tile_m = lin / ncol, tile_n = lin - tile_m * ncol;
+  const int row0 = tile_m * TM;
+  const int col0 = tile_n * CN;
+
+  // 1. stage this tile's slice of the neighbour table (coalesced) in the accumulator region
+  int* s_stage = reinterpret_cast<int*>(s_acc);
+  for (int t = tid; t < TM * K; t += 256) {
+    int r = t / K;
+    int row = row0 + r;
+    int v = -1;
+    if (row < n_out) v = nbr ? nbr[(int64_t)row0 * K + t] : row;
+    s_stage[t] = v;
+  }
+  __syncthreads();
+  // 2. per-offset compaction of (input row, local output row) pairs: ballot + popcount
+  for (int k = wave; k < K; k += 4) {
+    int cnt = 0;
+#pragma unroll
+    for (int base = 0; base < TM; base += 64) {
+      int r = base + lane;
+      int v = (r < TM) ? s_stage[r * K + k] : -1;
+      unsigned long long m = __ballot(v >= 0);
+      if (v >= 0) {
+        int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        s_in[k * TM + pos] = v;
+        s_row[k * TM + pos] = (unsigned char)r;
+      }
+      cnt += __popcll(m);
+    }
+    if (lane == 0) s_cnt[k] = cnt;
+  }
+  __syncthreads();
+  // 3. active offset list (wave 0) + zero the accumulators (everyone)
+  if (wave == 0) {
+    int c = (lane < K) ? s_cnt[lane] : 0;
+    unsigned long long m = __ballot(c > 0);
+    if (c > 0) s_act[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+    if (lane == 0) s_nact = __popcll(m);
+  }
+  for (int t = tid; t < 4 * TM * LDO / 4; t += 256)
+    reinterpret_cast<f32x4*>(s_acc)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int nact = s_nact;
+  const int nchunk = cin / CK;
+  const int cinG = cin >> 2;
+  float* my_acc = s_acc + wave * TM * LDO;
+
+  // 4. wave-autonomous main loop: no barriers.  A step = (item, 16-pair group).  Every step issues
+  //    exactly CB*NJ weight-fragment loads + NJ gather loads for the NEXT step into the other
+  //    register buffer before running its own MFMAs (the loop is unrolled by two so the buffers
+  //    swap by name, and the fixed load count lets the compiler wait with a counted vmcnt instead
+  //    of vmcnt(0)); a multi-group item re-reads its weight piece (L1 hit) to keep the count fixed.
+  const int nitems = nact * nchunk;
+  struct Desc { int item, g0, k, chunk, cnt; };
+  auto decode = [&](Desc& d) {
+    const int ai = d.item / nchunk;
+    d.chunk = d.item - ai * nchunk;
+    d.k = __builtin_amdgcn_readfirstlane(s_act[ai]);
+    d.cnt = __builtin_amdgcn_readfirstlane(s_cnt[d.k]);
+  };
+  // returns false when there is no further step (d is left unchanged so dummy loads stay valid)
+  auto advance = [&](Desc& d) -> bool {
+    if (d.g0 + 16 < d.cnt) {
+      d.g0 += 16;
+      return true;
+    }
+    if (d.item + 4 >= nitems) return false;
+    d.item += 4;
+    d.g0 = 0;
+    decode(d);
+    return true;
+  };
+  auto load = [&](const Desc& d, f32x4 (&bw)[CB][NJ], f32x4 (&aw)[NJ]) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int g = d.chunk * (CK / 4) + j * 4 + q;
+        bw[cb][j] = *reinterpret_cast<const f32x4*>(
+            wp + (((int64_t)d.k * cinG + g) * cout + col0 + cb * 16 + r16) * 4);
+      }
+    // padded pairs (p >= cnt) gather pair 0's row: their columns of D^T are never written back
+    const int p = d.g0 + r16;
+    const int idx = s_in[d.k * TM + (p < d.cnt ? p : 0)];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      aw[j] = *reinterpret_cast<const f32x4*>(in + (int64_t)idx * ldi + d.chunk * CK + j * 16 + q * 4);
+  };
+  auto compute = [&](const Desc& d, const f32x4 (&bw)[CB][NJ], const f32x4 (&aw)[NJ]) {
+    // D^T = W^T . A^T : lane (r16 = pair, q) ends up with 4 consecutive output channels of one pair
+    f32x4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[cb][j][t], aw[j][t], acc[cb], 0, 0, 0);
+    // read-modify-write into the wave-private tile (rows of one group are distinct: no atomics)
+    if (d.g0 + r16 < d.cnt) {
+      float* dst = my_acc + (int)s_row[d.k * TM + d.g0 + r16] * LDO + q * 4;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst + cb * 16);
+        *d4 = *d4 + acc[cb];
+      }
+    }
+  };
+
+  if (wave < nitems) {
+    f32x4 b0[CB][NJ], a0[NJ], b1[CB][NJ], a1[NJ];
+    Desc d0;
+    d0.item = wave;
+    d0.g0 = 0;
+    decode(d0);
+    load(d0, b0, a0);
+    while (true) {
+      Desc d1 = d0;
+      const bool more1 = advance(d1);
+      load(d1, b1, a1);          // prefetch (a harmless re-load of d0 when there is no next step)
+      compute(d0, b0, a0);
+      if (!more1) break;
+      d0 = d1;
+      const bool more0 = advance(d0);
+      load(d0, b0, a0);
+      compute(d1, b1, a1);
+      if (!more0) break;
+    }
+  }
+  __syncthreads();
+
+  // 5. epilogue: fixed-order sum of the 4 private tiles, fused affine/residual/ReLU, 16-B row stores
+  for (int e = tid; e < TM * (CN / 4); e += 256) {
+    const int r = e / (CN / 4), c4 = e - r * (CN / 4);
+    const int row = row0 + r;
+    if (row >= n_out) continue;
+    const int col = col0 + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&s_acc[(0 * TM + r) * LDO + c4 * 4]);
+    v += *reinterpret_cast<const f32x4*>(&s_acc[(1 * TM + r) * LDO + c4 * 4]);
+    v += *reinterpret_cast<const f32x4*>(&s_acc[(2 * TM + r) * LDO + c4 * 4]);
+    v += *reinterpret_cast<const f32x4*>(&s_acc[(3 * TM + r) * LDO + c4 * 4]);
+    if (scale) v *= *reinterpret_cast<const f32x4*>(scale + col);
+    if (shift) v += *reinterpret_cast<const f32x4*>(shift + col);
+    if (residual) v += *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + col);
+    if (relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (int64_t)row * ldo + col) = v;
+  }
+}
+
+// Small-Cin path (conv1: Cin = 1 or 3, K = 125 / 343): 0.5 FLOP/B, pure gather/stream work.
+// A workgroup stages its 64 rows' slice of the neighbour table in LDS with coalesced loads,
+// then 4 threads per row walk the offsets (one broadcast LDS read each) and keep 8 output
+// channels in registers; weights ([K,cin,cout], <= 32 KB) are read through L1.
+template <int CIN>
+__global__ __launch_bounds__(256) void k_spconv_smallcin(
+    const float* __restrict__ in, int64_t ldi, const int* __restrict__ nbr, int n_out, int K, int cout,
+    const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ residual, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo) {
+  extern __shared__ int s_nb[];   // [64][K]
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * 64;
+  const int rows = min(64, n_out - row0);
+  for (int t = tid; t < rows * K; t += 256) s_nb[t] = nbr[(int64_t)row0 * K + t];
+  __syncthreads();
+  const int r = tid >> 2, cg = tid & 3;
+  if (r >= rows) return;
+  for (int c0 = cg * 8; c0 < cout; c0 += 32) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+      const int idx = s_nb[r * K + k];
+      if (idx < 0) continue;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float x = in[(int64_t)idx * ldi + ci];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ((int64_t)k * CIN + ci) * cout + c0);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + ((int64_t)k * CIN + ci) * cout + c0 + 4);
+        acc[0] = fmaf(x, w0[0], acc[0]); acc[1] = fmaf(x, w0[1], acc[1]);
+        acc[2] = fmaf(x, w0[2], acc[2]); acc[3] = fmaf(x, w0[3], acc[3]);
+        acc[4] = fmaf(x, w1[0], acc[4]); acc[5] = fmaf(x, w1[1], acc[5]);
+        acc[6] = fmaf(x, w1[2], acc[6]); acc[7] = fmaf(x, w1[3], acc[7]);
+      }
+    }
+    const int64_t row = row0 + r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;
+      float v = acc[i] * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+      if (residual) v += residual[row * ldr + c];
+      if (relu) v = fmaxf(v, 0.f);
+      out[row * ldo + c] = v;
+    }
+  }
+}
+
 // Generic VALU path: any cin/cout/K (conv1 with cin = 1 or 3, odd channel counts).
 // One thread per (row, out channel); weights in the reference's [K,cin,cout] layout.
 __global__ void k_spconv_generic(const float* __restrict__ in, int64_t ldi,
@@ -235,6 +484,23 @@ int launch_mfma(const float* in, int64_t ldi, const int* nbr, int64_t n_out, int
   return APR_OK;
 }
 
+template <int TM, int CN, int CK>
+int launch_pairs(const float* in, int64_t ldi, const int* nbr, int64_t n_out, int K, int cin,
+                 int cout, const float* wp, const float* scale, const float* shift,
+                 const float* residual, int64_t ldr, int relu, float* out, int64_t ldo,
+                 hipStream_t st) {
+  int64_t tiles = cdiv64(n_out, TM) * (cout / CN);
+  hipLaunchKernelGGL((k_spconv_pairs<TM, CN, CK>), dim3((unsigned)tiles), dim3(256), 0, st, in, ldi,
+                     nbr, (int)n_out, K, cin, cout, wp, scale, shift, residual, ldr, relu, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 }  // namespace
 
 APR_API int64_t apr_spconv_packed_size(int32_t K, int32_t cin, int32_t cout) {
@@ -267,6 +533,31 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
   APR_CHECK_ARG(ldi >= cin && ldo >= cout, "apr_spconv_fwd: leading dimension smaller than channels");
   APR_CHECK_ARG(!residual || ldr >= cout, "apr_spconv_fwd: ldr < cout");
   if (n_out == 0) return APR_OK;
+  static const int s_impl = env_int("APR_SPCONV_IMPL", 2);      // 1 = dense-tile kernel, 2 = pair-compacted
+  static const int s_tm = env_int("APR_SPCONV_TM", 0);           // 0 = heuristic
+  const bool vec_ok = (ldi % 4) == 0 && (((uintptr_t)in) & 15) == 0 && (ldo % 4) == 0 &&
+                      (((uintptr_t)out) & 15) == 0 &&
+                      (!residual || ((ldr % 4) == 0 && (((uintptr_t)residual) & 15) == 0));
+  if (s_impl == 2 && use_mfma(K, cin, cout) && K <= kKMax && vec_ok) {
+#define APR_PAIRS(TM_, CN_, CK_)                                                                   \
+  return launch_pairs<TM_, CN_, CK_>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift,    \
+                                     residual, ldr, relu, out, ldo, st)
+    static const int s_ck = env_int("APR_SPCONV_CK", 0);
+    const bool cn64 = (cout % 64 == 0), ck64 = (cin % 64 == 0) && s_ck != 32;
+    // 64-row tiles halve the weight re-reads; use them once there are enough tiles to fill 256 CUs
+    const int tm = s_tm ? s_tm : ((n_out * (cout / (cn64 ? 64 : 32)) >= 64 * 400) ? 64 : 32);
+    if (tm == 64) {
+      if (cn64 && ck64) APR_PAIRS(64, 64, 64);
+      if (cn64) APR_PAIRS(64, 64, 32);
+      if (ck64) APR_PAIRS(64, 32, 64);
+      APR_PAIRS(64, 32, 32);
+    }
+    if (cn64 && ck64) APR_PAIRS(32, 64, 64);
+    if (cn64) APR_PAIRS(32, 64, 32);
+    if (ck64) APR_PAIRS(32, 32, 64);
+    APR_PAIRS(32, 32, 32);
+#undef APR_PAIRS
+  }
   if (use_mfma(K, cin, cout) && (ldi % 4) == 0 && (((uintptr_t)in) & 15) == 0) {
     const bool big = n_out >= 32768;
     if (cout % 64 == 0) {
@@ -298,6 +589,19 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
   }
   APR_CHECK_ARG(!use_mfma(K, cin, cout),
                 "apr_spconv_fwd: MFMA-shaped layer needs 16-B aligned input rows (ldi %% 4 == 0)");
+  if (nbr && (cin == 1 || cin == 3) && cout % 32 == 0 && (size_t)64 * K * 4 <= 64 * 1024 &&
+      (((uintptr_t)w_packed) & 15) == 0) {
+    const unsigned grid = (unsigned)cdiv64(n_out, 64);
+    const size_t lds = (size_t)64 * K * 4;
+    if (cin == 1)
+      hipLaunchKernelGGL(k_spconv_smallcin<1>, dim3(grid), dim3(256), lds, st, in, ldi, nbr, (int)n_out, K, cout,
+                         w_packed, scale, shift, residual, ldr, relu, out, ldo);
+    else
+      hipLaunchKernelGGL(k_spconv_smallcin<3>, dim3(grid), dim3(256), lds, st, in, ldi, nbr, (int)n_out, K, cout,
+                         w_packed, scale, shift, residual, ldr, relu, out, ldo);
+    APR_LAUNCH_CHECK();
+    return APR_OK;
+  }
   int64_t total = n_out * cout;
   hipLaunchKernelGGL(k_spconv_generic, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, in, ldi, nbr,
                      n_out, K, cin, cout, w_packed, scale, shift, residual, ldr, relu, out, ldo);

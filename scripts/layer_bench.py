@@ -1,0 +1,32 @@
+"""Time single sparse-conv layers on the real kernel maps of one synthetic pair (A/B tuning aid)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+from apr_amd import ops, synth
+from apr_amd.MinkowskiEngine.core import CoordinateManager
+dev = torch.device("cuda:0")
+xyz0, xyz1, _ = synth.make_pair(0)
+maps = []
+for b, xyz in enumerate((xyz0, xyz1)):
+    c = ops.voxelize(torch.from_numpy(xyz).to(dev), 0.3, b); maps.append(ops.build_map(c))
+ops.finalize_maps(maps)
+cm = CoordinateManager(torch.cat([m.coords for m in maps]))
+cm.build_pyramid([2, 4, 8])
+layers = [("b1 32>32 N1", 1, 1, 32, 32, False), ("b2tr 64>64 N1", 1, 1, 64, 64, False), ("c2tr 128>64 2>1", 2, 1, 128, 64, True),
+          ("c2 32>64 1>2", 1, 2, 32, 64, False), ("b2 64>64 N2", 2, 2, 64, 64, False), ("b3 128>128 N3", 4, 4, 128, 128, False),
+          ("b4 256>256 N4", 8, 8, 256, 256, False), ("c4tr 256>128 8>4", 8, 4, 256, 128, True)]
+for name, ti, to, cin, cout, tr in layers:
+    nbr = cm.kernel_map(ti, to, 3, tr)
+    P = int((nbr >= 0).sum())
+    x = torch.randn(cm.size(ti), cin, device=dev)
+    wp = ops.pack_weights(torch.randn(27, cin, cout, device=dev) * 0.05)
+    out = torch.empty(cm.size(to), cout, device=dev)
+    for _ in range(3): ops.spconv(x, nbr, 27, cin, cout, wp, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): ops.spconv(x, nbr, 27, cin, cout, wp, out=out)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1000 / 20
+    by = 4.0 * P * (cin + cout) + 8.0 * P
+    print(f"{name:18s} rows={cm.size(to):6d} P={P:7d} {us:7.1f} us  {by/us/1e3:7.1f} GB/s  {2.0*P*cin*cout/us/1e6:6.1f} TF", flush=True)
