@@ -1,0 +1,505 @@
+// Point-set index builds for the KPConv encoder (N1-N3):
+// barycentre grid subsampling, batched radius neighbours, brute-force kNN.
+//
+// The reference does these on the CPU, single-threaded, inside DataLoader workers
+// (unordered_map voxel grid: cpp_subsampling/grid_subsampling/grid_subsampling.cpp:5-107;
+// nanoflann KD-tree radius search: cpp_neighbors/neighbors/neighbors.cpp:211-333).  On the GPU
+// both become uniform-grid problems on top of the voxel hash of hash.hip:
+//   * cells = hash-unique (batch, ix, iy, iz) keys in first-occurrence order;
+//   * points are bucketed per cell (count -> exclusive scan -> fill);
+//   * grid subsample: one thread per cell re-orders its few points by input index and sums them
+//     in fp32 in that order, so the barycentres are BIT-IDENTICAL to the reference's sequential
+//     `point += p` accumulation (row order differs: libstdc++ unordered_map iteration order is
+//     not reproduced, parity is per cell);
+//   * radius search: one wave per query probes the 27 surrounding cells (cell edge = radius),
+//     lanes stride over the candidates, hits are ballot-compacted into LDS and rank-sorted by
+//     (d2, index); d2 = ((dx*dx) + dy*dy) + dz*dz in fp32 without contraction, `d2 < r*r`
+//     strictly -- nanoflann's L2_Simple_Adaptor / RadiusResultSet arithmetic.
+// All of it is integer / latency-bound work on a few 10^4 points: HBM traffic is negligible, the
+// point is to keep the index build on the device, stream-ordered in front of the encoder.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBatch = 64;
+constexpr int kHitCap = 1024;  // max neighbours per query the radius kernels can rank
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- per-cloud bounding-box minimum -------------------------------------------------------
+__global__ void k_cloud_min(const float* __restrict__ pts, const int* __restrict__ starts, int nb,
+                            float* __restrict__ mins /*[nb,3]*/) {
+  __shared__ float s[3][kBlock];
+  const int b = blockIdx.x;
+  const int lo = starts[b], hi = starts[b + 1];
+  float m[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  for (int i = lo + threadIdx.x; i < hi; i += kBlock)
+    for (int d = 0; d < 3; ++d) m[d] = fminf(m[d], pts[3 * (int64_t)i + d]);
+  for (int d = 0; d < 3; ++d) s[d][threadIdx.x] = m[d];
+  __syncthreads();
+  for (int st = kBlock / 2; st >= 1; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int d = 0; d < 3; ++d) s[d][threadIdx.x] = fminf(s[d][threadIdx.x], s[d][threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) mins[3 * b + threadIdx.x] = s[threadIdx.x][0];
+}
+
+__device__ inline int batch_of(const int* __restrict__ starts, int nb, int i) {
+  int b = 0;
+  while (b + 1 < nb && i >= starts[b + 1]) ++b;
+  return b;
+}
+
+// cell coordinates.  mode 0 (grid subsample): origin = floor(min * (1/dl)) * dl per cloud and
+// i = floor((p - origin) / dl), every step a separately rounded fp32 op as in the reference.
+// mode 1 (search grid): i = floor((p - min_b) / cell) -- any consistent grid works there.
+__global__ void k_cell_coords(const float* __restrict__ pts, int64_t n, const int* __restrict__ starts, int nb,
+                              const float* __restrict__ mins, float dl, int mode, int4* __restrict__ coords) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = batch_of(starts, nb, (int)i);
+  int c[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float o = mins[3 * b + d];
+    if (mode == 0) o = __fmul_rn(floorf(__fmul_rn(o, __fdiv_rn(1.0f, dl))), dl);
+    c[d] = (int)floorf(__fdiv_rn(__fsub_rn(pts[3 * i + d], o), dl));
+  }
+  coords[i] = make_int4(b, c[0], c[1], c[2]);
+}
+
+__device__ inline int table_lookup(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                   uint32_t mask, unsigned long long key) {
+  uint32_t slot = apr_hash_u64(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long k = keys[slot];
+    if (k == key) return vals[slot];
+    if (k == APR_KEY_EMPTY) return -1;
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+
+__global__ void k_cell_of(const int4* __restrict__ coords, int64_t n, const unsigned long long* __restrict__ keys,
+                          const int* __restrict__ vals, uint32_t mask, int* __restrict__ cell,
+                          int* __restrict__ cnt) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  int id = table_lookup(keys, vals, mask, apr_pack_key(c.x, c.y, c.z, c.w));
+  cell[i] = id;
+  if (id >= 0) atomicAdd(&cnt[id], 1);
+}
+
+// exclusive scan of cnt[0..n) -> start[0..n], single workgroup (n <= a few 10^5)
+__global__ void k_scan_excl(const int* __restrict__ cnt, const int* __restrict__ n_dev, int* __restrict__ start) {
+  __shared__ int wave_sum[16];
+  __shared__ int carry_s;
+  const int n = *n_dev;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < n; base += blockDim.x) {
+    int idx = base + threadIdx.x;
+    int v = idx < n ? cnt[idx] : 0;
+    int incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wave_sum[w];
+    int carry = carry_s;
+    if (idx < n) start[idx] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) start[n] = carry_s;
+}
+
+__global__ void k_fill(const int* __restrict__ cell, int64_t n, const int* __restrict__ start,
+                       int* __restrict__ cursor, int* __restrict__ sorted) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int id = cell[i];
+  if (id < 0) return;
+  sorted[start[id] + atomicAdd(&cursor[id], 1)] = (int)i;
+}
+
+// one thread per cell: order its points by input index, sum sequentially in fp32, scale by
+// (float)(1.0 / count)  (grid_subsampling.cpp:60-89).  Also counts cells per cloud.
+__global__ void k_barycentre(const float* __restrict__ pts, const int4* __restrict__ cell_coords,
+                             const int* __restrict__ n_cells_dev, const int* __restrict__ start,
+                             int* __restrict__ sorted, const float* __restrict__ feats, int fdim,
+                             float* __restrict__ out_pts, float* __restrict__ out_feats,
+                             int* __restrict__ out_len) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= *n_cells_dev) return;
+  const int lo = start[c], hi = start[c + 1];
+  for (int a = lo + 1; a < hi; ++a) {  // insertion sort by point index (cells hold a handful of points)
+    int v = sorted[a], p = a - 1;
+    while (p >= lo && sorted[p] > v) {
+      sorted[p + 1] = sorted[p];
+      --p;
+    }
+    sorted[p + 1] = v;
+  }
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int a = lo; a < hi; ++a) {
+    int64_t i = sorted[a];
+    sx = __fadd_rn(sx, pts[3 * i]);
+    sy = __fadd_rn(sy, pts[3 * i + 1]);
+    sz = __fadd_rn(sz, pts[3 * i + 2]);
+  }
+  const int count = hi - lo;
+  const float inv = (float)(1.0 / (double)count);
+  out_pts[3 * (int64_t)c] = __fmul_rn(sx, inv);
+  out_pts[3 * (int64_t)c + 1] = __fmul_rn(sy, inv);
+  out_pts[3 * (int64_t)c + 2] = __fmul_rn(sz, inv);
+  if (feats) {
+    const float fc = (float)count;
+    for (int f = 0; f < fdim; ++f) {
+      float s = 0.f;
+      for (int a = lo; a < hi; ++a) s = __fadd_rn(s, feats[(int64_t)sorted[a] * fdim + f]);
+      out_feats[(int64_t)c * fdim + f] = __fdiv_rn(s, fc);
+    }
+  }
+  atomicAdd(&out_len[cell_coords[c].x], 1);
+}
+
+// ---- radius search ---------------------------------------------------------------------------
+struct Grid {
+  const unsigned long long* keys;
+  const int* vals;
+  uint32_t mask;
+  const int* start;   // [ncell + 1]
+  const int* sorted;  // support indices bucketed by cell
+  const float* mins;  // [nb,3] per-cloud support minimum
+  float cell;
+};
+
+// MODE 0: count only.  MODE 1: fill + sort.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int64_t nq, const int* __restrict__ qstarts,
+                                                const float* __restrict__ s, int nb, Grid g, float r2,
+                                                int* __restrict__ counts, int* __restrict__ out, int width,
+                                                int64_t ld, int pad_value, int* __restrict__ status) {
+  __shared__ float s_d[4][kHitCap];
+  __shared__ int s_i[4][kHitCap];
+  __shared__ int s_lo[4][32], s_incl[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+  if (qi >= nq) return;
+  const int b = batch_of(qstarts, nb, (int)qi);
+  const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
+  const int cx = (int)floorf(__fdiv_rn(__fsub_rn(qx, g.mins[3 * b]), g.cell));
+  const int cy = (int)floorf(__fdiv_rn(__fsub_rn(qy, g.mins[3 * b + 1]), g.cell));
+  const int cz = (int)floorf(__fdiv_rn(__fsub_rn(qz, g.mins[3 * b + 2]), g.cell));
+  // lanes 0..26 each probe one neighbouring cell; the 27 (start, inclusive-count) pairs go to LDS
+  int c_lo = 0, c_n = 0;
+  if (lane < 27) {
+    const int x = cx + lane % 3 - 1, y = cy + (lane / 3) % 3 - 1, z = cz + lane / 9 - 1;
+    if (apr_key_in_range(b, x, y, z)) {
+      int id = table_lookup(g.keys, g.vals, g.mask, apr_pack_key(b, x, y, z));
+      if (id >= 0) {
+        c_lo = g.start[id];
+        c_n = g.start[id + 1] - c_lo;
+      }
+    }
+  }
+  int incl = c_n;
+  for (int d = 1; d < 32; d <<= 1) {   // all 64 lanes take part: no shuffle from an inactive lane
+    int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane < 27) {
+    s_lo[wave][lane] = c_lo;
+    s_incl[wave][lane] = incl;
+  }
+  const int total = __shfl(incl, 26);
+  int nhit = 0;
+  for (int base = 0; base < total; base += 64) {
+    const int t = base + lane;
+    bool hit = false;
+    float d2 = 0.f;
+    int sidx = -1;
+    if (t < total) {
+      int L = 0;                        // cell range holding candidate t: first L with incl[L] > t
+      while (s_incl[wave][L] <= t) ++L;
+      const int before = L ? s_incl[wave][L - 1] : 0;
+      sidx = g.sorted[s_lo[wave][L] + (t - before)];
+      const float dx = __fsub_rn(qx, s[3 * (int64_t)sidx]), dy = __fsub_rn(qy, s[3 * (int64_t)sidx + 1]),
+                  dz = __fsub_rn(qz, s[3 * (int64_t)sidx + 2]);
+      d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      hit = d2 < r2;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (MODE == 1 && hit) {
+      const int pos = nhit + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < kHitCap) {
+        s_d[wave][pos] = d2;
+        s_i[wave][pos] = sidx;
+      }
+    }
+    nhit += __popcll(m);
+  }
+  if (MODE == 0) {
+    if (lane == 0) counts[qi] = nhit;
+    return;
+  }
+  if (nhit > kHitCap) {
+    if (lane == 0) *status = 1;
+    nhit = kHitCap;
+  }
+  // rank sort by (d2, index); wave-private LDS rows, so no barrier is needed
+  for (int e = lane; e < nhit; e += 64) {
+    const float d = s_d[wave][e];
+    const int id = s_i[wave][e];
+    int rank = 0;
+    for (int o = 0; o < nhit; ++o) {
+      const float od = s_d[wave][o];
+      rank += (od < d || (od == d && s_i[wave][o] < id)) ? 1 : 0;
+    }
+    if (rank < width) out[qi * ld + rank] = id;
+  }
+  for (int e = nhit + lane; e < width; e += 64) out[qi * ld + e] = pad_value;
+}
+
+__global__ void k_max_int(const int* __restrict__ v, int64_t n, int* __restrict__ out) {
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, v[i]);
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// ---- brute-force kNN (k <= 16) for the overlap-attention graph ---------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ pts, int n, int k, int skip_first,
+                                             int* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x * 4 + wave;
+  if (qi >= n) return;
+  const float qx = pts[3 * qi], qy = pts[3 * qi + 1], qz = pts[3 * qi + 2];
+  float bd[KMAX];
+  int bi[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    bd[j] = __builtin_inff();
+    bi[j] = 0x7fffffff;
+  }
+  const int want = k + skip_first;
+  for (int i = lane; i < n; i += 64) {
+    const float dx = qx - pts[3 * i], dy = qy - pts[3 * i + 1], dz = qz - pts[3 * i + 2];
+    float d = fmaxf(dx * dx + dy * dy + dz * dz, 1e-12f);
+    int id = i;
+    // insert into the lane-local sorted list (ascending by (d, index))
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < want && (d < bd[j] || (d == bd[j] && id < bi[j]))) {
+        float td = bd[j]; int ti = bi[j];
+        bd[j] = d; bi[j] = id;
+        d = td; id = ti;
+      }
+    }
+  }
+  // merge: `want` rounds of wave arg-min over the lanes' list heads
+  for (int r = 0; r < want; ++r) {
+    float hd = bd[0];
+    int hi = bi[0];
+    float md = hd;
+    int mi = hi;
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+      float od = __shfl_xor(md, dd);
+      int oi = __shfl_xor(mi, dd);
+      if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+    }
+    if (hd == md && hi == mi) {  // this lane owns the winner: pop
+#pragma unroll
+      for (int j = 0; j + 1 < KMAX; ++j) { bd[j] = bd[j + 1]; bi[j] = bi[j + 1]; }
+      bd[KMAX - 1] = __builtin_inff();
+      bi[KMAX - 1] = 0x7fffffff;
+    }
+    if (lane == 0 && r >= skip_first) out[qi * k + (r - skip_first)] = (mi == 0x7fffffff) ? qi : mi;
+  }
+}
+
+struct GridWork {
+  int4* coords;
+  unsigned long long* keys;
+  int* vals;
+  int64_t cap;
+  int4* cell_coords;
+  int* n_cells;
+  int* status;
+  int* cell;
+  int* cnt;
+  int* start;
+  int* cursor;
+  int* sorted;
+  void* map_scratch;
+  size_t map_scratch_bytes;
+  int* starts_dev;
+  float* mins;
+};
+
+size_t grid_work_bytes(int64_t n) {
+  const int64_t cap = apr_hash_capacity(n);
+  return align256(n * 16) + align256(cap * 8) + align256(cap * 4) + align256(n * 16) + 256 + 256 + align256(n * 4) +
+         align256(n * 4) + align256((n + 1) * 4) + align256(n * 4) + align256(n * 4) +
+         align256(apr_map_scratch_bytes(n)) + align256((kMaxBatch + 1) * 4) + align256(kMaxBatch * 12) + 1024;
+}
+
+GridWork carve(void* scratch, int64_t n) {
+  GridWork w;
+  char* p = (char*)scratch;
+  w.cap = apr_hash_capacity(n);
+  auto take = [&](size_t bytes) {
+    void* r = p;
+    p += align256(bytes);
+    return r;
+  };
+  w.coords = (int4*)take(n * 16);
+  w.keys = (unsigned long long*)take(w.cap * 8);
+  w.vals = (int*)take(w.cap * 4);
+  w.cell_coords = (int4*)take(n * 16);
+  w.n_cells = (int*)take(256);
+  w.status = (int*)take(256);
+  w.cell = (int*)take(n * 4);
+  w.cnt = (int*)take(n * 4);
+  w.start = (int*)take((n + 1) * 4);
+  w.cursor = (int*)take(n * 4);
+  w.sorted = (int*)take(n * 4);
+  w.map_scratch_bytes = apr_map_scratch_bytes(n);
+  w.map_scratch = take(w.map_scratch_bytes);
+  w.starts_dev = (int*)take((kMaxBatch + 1) * 4);
+  w.mins = (float*)take(kMaxBatch * 12);
+  return w;
+}
+
+// points -> cells -> buckets.  mode as in k_cell_coords.
+int build_grid(const float* pts, int64_t n, const int32_t* lengths_host, int nb, float cell, int mode, GridWork& w,
+               hipStream_t st) {
+  int starts[kMaxBatch + 1];
+  starts[0] = 0;
+  for (int b = 0; b < nb; ++b) starts[b + 1] = starts[b] + lengths_host[b];
+  APR_CHECK_ARG(starts[nb] == n, "batch lengths sum to %d, expected %lld points", starts[nb], (long long)n);
+  APR_HIP(hipMemcpyAsync(w.starts_dev, starts, (nb + 1) * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_cloud_min, dim3(nb), dim3(kBlock), 0, st, pts, w.starts_dev, nb, w.mins);
+  const unsigned nblk = (unsigned)cdiv64(n, kBlock);
+  hipLaunchKernelGGL(k_cell_coords, dim3(nblk), dim3(kBlock), 0, st, pts, n, w.starts_dev, nb, w.mins, cell, mode,
+                     w.coords);
+  int rc = apr_map_build((const int32_t*)w.coords, n, nullptr, 0, (uint64_t*)w.keys, w.vals, w.cap,
+                         (int32_t*)w.cell_coords, nullptr, w.n_cells, w.status, w.map_scratch, w.map_scratch_bytes,
+                         st);
+  if (rc != APR_OK) return rc;
+  APR_HIP(hipMemsetAsync(w.cnt, 0, n * 4, st));
+  APR_HIP(hipMemsetAsync(w.cursor, 0, n * 4, st));
+  hipLaunchKernelGGL(k_cell_of, dim3(nblk), dim3(kBlock), 0, st, w.coords, n, w.keys, w.vals, (uint32_t)(w.cap - 1),
+                     w.cell, w.cnt);
+  hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, w.cnt, w.n_cells, w.start);
+  hipLaunchKernelGGL(k_fill, dim3(nblk), dim3(kBlock), 0, st, w.cell, n, w.start, w.cursor, w.sorted);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+}  // namespace
+
+APR_API size_t apr_grid_subsample_scratch_bytes(int64_t n) { return grid_work_bytes(n > 0 ? n : 1); }
+
+APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
+                               const float* feats, int32_t fdim, float* out_pts, float* out_feats,
+                               int32_t* out_lengths_host, void* scratch, size_t scratch_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n > 0 && n < (1ll << 31) && nb > 0 && nb <= kMaxBatch && dl > 0.f, "apr_grid_subsample: bad arguments");
+  APR_CHECK_ARG(scratch_bytes >= grid_work_bytes(n), "apr_grid_subsample: scratch too small");
+  for (int b = 0; b < nb; ++b) APR_CHECK_ARG(lengths_host[b] > 0, "apr_grid_subsample: empty cloud in batch");
+  GridWork w = carve(scratch, n);
+  int rc = build_grid(pts, n, lengths_host, nb, dl, 0, w, st);
+  if (rc != APR_OK) return rc;
+  int* out_len_dev = w.cursor;  // cursor is dead after k_fill; reuse its first nb ints
+  APR_HIP(hipMemsetAsync(out_len_dev, 0, kMaxBatch * 4, st));
+  hipLaunchKernelGGL(k_barycentre, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, st, pts, w.cell_coords,
+                     w.n_cells, w.start, w.sorted, feats, fdim, out_pts, out_feats, out_len_dev);
+  APR_LAUNCH_CHECK();
+  int status = 0;
+  APR_HIP(hipMemcpyAsync(out_lengths_host, out_len_dev, nb * 4, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipMemcpyAsync(&status, w.status, 4, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipStreamSynchronize(st));
+  if (status != 0) {
+    apr_set_error("apr_grid_subsample: cell index outside the packed-key range");
+    return APR_ERANGE;
+  }
+  return APR_OK;
+}
+
+APR_API size_t apr_radius_scratch_bytes(int64_t nq, int64_t ns) {
+  return grid_work_bytes(ns > 0 ? ns : 1) + align256((nq > 0 ? nq : 1) * 4) + align256((kMaxBatch + 1) * 4) + 512;
+}
+
+APR_API int apr_radius_neighbors(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                                 const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb, float radius,
+                                 int32_t limit, int32_t* out, int64_t out_ld, int32_t* width_host,
+                                 void* scratch, size_t scratch_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(nq > 0 && ns > 0 && nq < (1ll << 31) && ns < (1ll << 31) && nb > 0 && nb <= kMaxBatch && radius > 0.f,
+                "apr_radius_neighbors: bad arguments");
+  APR_CHECK_ARG(scratch_bytes >= apr_radius_scratch_bytes(nq, ns), "apr_radius_neighbors: scratch too small");
+  GridWork w = carve(scratch, ns);
+  char* p = (char*)scratch + grid_work_bytes(ns);
+  int* counts = (int*)p;
+  p += align256(nq * 4);
+  int* qstarts = (int*)p;
+  p += align256((kMaxBatch + 1) * 4);
+  int* maxc = (int*)p;
+  int rc = build_grid(supports, ns, s_lengths_host, nb, radius, 1, w, st);
+  if (rc != APR_OK) return rc;
+  int qs[kMaxBatch + 1];
+  qs[0] = 0;
+  for (int b = 0; b < nb; ++b) qs[b + 1] = qs[b] + q_lengths_host[b];
+  APR_CHECK_ARG(qs[nb] == nq, "apr_radius_neighbors: query batch lengths sum to %d, expected %lld", qs[nb], (long long)nq);
+  APR_HIP(hipMemcpyAsync(qstarts, qs, (nb + 1) * 4, hipMemcpyHostToDevice, st));
+  Grid g{w.keys, w.vals, (uint32_t)(w.cap - 1), w.start, w.sorted, w.mins, radius};
+  const float r2 = radius * radius;
+  const unsigned grid = (unsigned)cdiv64(nq, 4);
+  // counting pass: the reference pads every row to the global maximum neighbour count and the
+  // caller then keeps the first `limit` columns, so width = min(max_count, limit)
+  int width = 0;
+  APR_HIP(hipMemsetAsync(maxc, 0, 4, st));
+  hipLaunchKernelGGL(k_radius<0>, dim3(grid), dim3(256), 0, st, queries, nq, qstarts, supports, nb, g, r2, counts,
+                     (int*)nullptr, 0, (int64_t)0, 0, w.status);
+  hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, st, counts, nq, maxc);
+  APR_HIP(hipMemcpyAsync(&width, maxc, 4, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipStreamSynchronize(st));
+  if (limit > 0 && width > limit) width = limit;
+  *width_host = width;
+  if (out == nullptr) return APR_OK;  // size query only
+  APR_CHECK_ARG(width <= out_ld, "apr_radius_neighbors: need %d columns, buffer rows hold %lld", width,
+                (long long)out_ld);
+  if (width == 0) return APR_OK;
+  APR_HIP(hipMemsetAsync(w.status, 0, 4, st));
+  hipLaunchKernelGGL(k_radius<1>, dim3(grid), dim3(256), 0, st, queries, nq, qstarts, supports, nb, g, r2, counts, out,
+                     width, out_ld, (int)ns, w.status);
+  APR_LAUNCH_CHECK();
+  int status = 0;
+  APR_HIP(hipMemcpyAsync(&status, w.status, 4, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipStreamSynchronize(st));
+  if (status != 0) {
+    apr_set_error("apr_radius_neighbors: a query has more than %d neighbours within the radius", kHitCap);
+    return APR_ERANGE;
+  }
+  return APR_OK;
+}
+
+APR_API int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && k > 0 && k + skip_first <= 16, "apr_knn: need n > 0 and k + skip_first <= 16");
+  hipLaunchKernelGGL(k_knn<16>, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, (hipStream_t)stream, pts, n, k,
+                     skip_first, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}

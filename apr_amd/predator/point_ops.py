@@ -1,0 +1,79 @@
+"""Device-tensor wrappers of the point-set kernels (grid subsample, radius neighbours, kNN)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream
+
+
+def _lens(lengths):
+    a = np.ascontiguousarray(np.asarray(lengths, dtype=np.int32).reshape(-1))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _pts(t, name):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 3:
+        raise _lib.AprHipError(f"{name}: need a float32 [N,3] GPU tensor")
+    return t.contiguous()
+
+
+def grid_subsample(points, lengths, dl, features=None):
+    """-> (sub_points [M,3], sub_lengths int32 numpy [B][, sub_features])."""
+    lib = _lib.load()
+    points = _pts(points, "grid_subsample.points")
+    n = points.shape[0]
+    la, lp = _lens(lengths)
+    out = torch.empty_like(points)
+    fdim, of = 0, None
+    if features is not None:
+        features = features.to(torch.float32).contiguous()
+        fdim = features.shape[1]
+        of = torch.empty_like(features)
+    sb = int(lib.apr_grid_subsample_scratch_bytes(n))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=points.device)
+    out_len = np.zeros(len(la), np.int32)
+    check(lib.apr_grid_subsample(ptr(points), n, lp, len(la), float(dl), ptr(features), fdim, ptr(out), ptr(of),
+                                 out_len.ctypes.data_as(C.c_void_p), ptr(scratch), sb, stream()))
+    m = int(out_len.sum())
+    if features is not None:
+        return out[:m], out_len, of[:m]
+    return out[:m], out_len
+
+
+def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, limit=0):
+    """int32 [Nq, width] neighbour table sorted by distance, padded with len(supports)."""
+    lib = _lib.load()
+    queries, supports = _pts(queries, "radius.queries"), _pts(supports, "radius.supports")
+    nq, ns = queries.shape[0], supports.shape[0]
+    qa, qp = _lens(q_lengths)
+    sa, sp = _lens(s_lengths)
+    if len(qa) != len(sa):
+        raise _lib.AprHipError("radius_neighbors: query / support batch counts differ")
+    sb = int(lib.apr_radius_scratch_bytes(nq, ns))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=queries.device)
+    width = C.c_int32(0)
+    if limit <= 0:   # unknown width: size query first
+        check(lib.apr_radius_neighbors(ptr(queries), nq, ptr(supports), ns, qp, sp, len(qa), float(radius), 0, None, 0,
+                                       C.byref(width), ptr(scratch), sb, stream()))
+        cap = max(int(width.value), 1)
+    else:
+        cap = int(limit)
+    out = torch.empty((nq, cap), dtype=torch.int32, device=queries.device)
+    check(lib.apr_radius_neighbors(ptr(queries), nq, ptr(supports), ns, qp, sp, len(qa), float(radius), int(limit),
+                                   ptr(out), cap, C.byref(width), ptr(scratch), sb, stream()))
+    w = int(width.value)
+    return out if w == cap else out[:, :w].contiguous()
+
+
+def knn(points, k, skip_first=True):
+    """int32 [N,k] nearest neighbours inside one cloud (the point itself dropped when skip_first)."""
+    lib = _lib.load()
+    points = _pts(points, "knn.points")
+    n = points.shape[0]
+    out = torch.empty((n, k), dtype=torch.int32, device=points.device)
+    check(lib.apr_knn(ptr(points), n, int(k), 1 if skip_first else 0, ptr(out), stream()))
+    return out

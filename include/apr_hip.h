@@ -176,6 +176,41 @@ int apr_irls_pose(const float* pts0, const float* pts1, const float* weight, int
                   float* T_host, void* scratch, size_t scratch_bytes, void* stream);
 size_t apr_irls_scratch_bytes(int64_t n);
 
+/* ------------------------------------------------------------------------
+ * Point-set index builds of the KPConv encoder (Predator_APR)
+ * ---------------------------------------------------------------------- */
+
+/* Barycentre grid subsampling of a batch of clouds; replaces
+ *   cpp_wrappers.cpp_subsampling.grid_subsampling.subsample_batch(points, batches, sampleDl=)
+ *   (Predator_APR/cpp_wrappers/cpp_subsampling/wrapper.cpp:75-82 ->
+ *    grid_subsampling/grid_subsampling.cpp:5-107,109-211).
+ *   pts f32[n,3] (clouds concatenated), lengths_host i32[nb] (HOST), dl = cell size.
+ *   out_pts f32[<=n,3], out_feats (nullable) f32[<=n,fdim], out_lengths_host i32[nb] (HOST).
+ *   Barycentres are bit-identical to the reference's; rows come in first-occurrence order of the
+ *   cells instead of libstdc++ unordered_map order.  Synchronises the stream. */
+size_t apr_grid_subsample_scratch_bytes(int64_t n);
+int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
+                       const float* feats, int32_t fdim, float* out_pts, float* out_feats,
+                       int32_t* out_lengths_host, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Batched radius neighbours, sorted by distance; replaces
+ *   cpp_wrappers.cpp_neighbors.radius_neighbors.batch_query(queries, supports, q_batches, s_batches, radius=)
+ *   (Predator_APR/cpp_wrappers/cpp_neighbors/wrapper.cpp:71-75 -> neighbors/neighbors.cpp:211-333)
+ *   followed by the `[:, :limit]` truncation of datasets/dataloader.py:66-68.
+ *   out i32[nq, out_ld]; columns [0,width) of every row are written: neighbour indices into the
+ *   concatenated supports, ascending distance, padded with ns.  width = min(max_count, limit)
+ *   (limit <= 0: no limit) is returned in *width_host.  out == NULL: size query only.
+ *   Synchronises the stream. */
+size_t apr_radius_scratch_bytes(int64_t nq, int64_t ns);
+int apr_radius_neighbors(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                         const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb, float radius,
+                         int32_t limit, int32_t* out, int64_t out_ld, int32_t* width_host,
+                         void* scratch, size_t scratch_bytes, void* stream);
+
+/* k nearest neighbours inside one cloud (brute force, k + skip_first <= 16); replaces the dense
+ * square_distance + topk(k+1)[..., 1:] of Predator_APR/models/gcn.py:19-23.  out i32[n,k]. */
+int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
