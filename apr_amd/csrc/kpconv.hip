@@ -1,0 +1,408 @@
+// KPConv encoder + overlap-attention kernels (K10, K11).
+//
+// KPConv (Predator_APR/models/blocks.py:229-374, rigid / linear influence / sum aggregation):
+//   out[q] = ( sum_k ( sum_h w[q,k,h] * x[nbr[q,h]] ) @ W[k] ) / max(#{h : sum_c x[nbr[q,h],c] > 0}, 1)
+//   w[q,k,h] = max(0, 1 - |s[nbr[q,h]] - q - kp[k]| / extent)
+// The reference materialises [N,H,15,3] differences and two batched matmuls.  Here step 1 (the
+// kernel-point correlation) is one wave per query on the fp32 MFMA: A = w[k][h] computed on the
+// fly in registers (M = 16 >= 15 kernel points, K = neighbours), B = neighbour features gathered
+// straight from HBM with one 16-B load per lane (channel permutation c = 4*r + cb makes every
+// gathered row a single 256-B coalesced read AND every output row a 16-B store), already
+// divided by the neighbour count.  Step 2 is the dense [Nq, 15*Cin] x [15*Cin, Cout] GEMM on the
+// sparse-conv MFMA kernel (identity map).  The remaining kernels are the small gather / reduce
+// ops of the blocks and of the overlap-attention module; none materialises an N x N tensor.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kKP = 15;
+constexpr int kMaxH = 128;
+
+__global__ void k_row_sums(const float* __restrict__ x, int64_t ld, int64_t n, int c, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float s = 0.f;
+  for (int j = lane; j < c; j += 64) s += x[row * ld + j];
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (lane == 0) out[row] = s;
+}
+
+__device__ inline float kp_weight(float dx, float dy, float dz, float kx, float ky, float kz, float inv_extent) {
+  const float ex = dx - kx, ey = dy - ky, ez = dz - kz;
+  const float d2 = ex * ex + ey * ey + ez * ez;
+  return fmaxf(1.f - sqrtf(d2) * inv_extent, 0.f);
+}
+
+// Step 1, MFMA form.  One wave per query; Cin % 64 == 0; NG = 64-channel groups per pass.
+template <int NG>
+__global__ __launch_bounds__(256) void k_kpconv_weighted_mfma(
+    const float* __restrict__ q_pts, const float* __restrict__ s_pts, const int* __restrict__ nbr, int H,
+    const float* __restrict__ x, int64_t ldx, int cin, const float* __restrict__ kp, float extent,
+    const float* __restrict__ rowsum, float* __restrict__ wf, int64_t ldwf, int nq, int ns) {
+  __shared__ int s_idx[4][kMaxH];
+  __shared__ float s_diff[4][kMaxH][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, qd = lane >> 4;
+  const int qi = blockIdx.x * 4 + wave;
+  if (qi >= nq) return;
+  const float qx = q_pts[3 * (int64_t)qi], qy = q_pts[3 * (int64_t)qi + 1], qz = q_pts[3 * (int64_t)qi + 2];
+  int cnt = 0;
+  for (int h = lane; h < kMaxH; h += 64) {
+    int idx = -1;
+    float dx = 1e6f, dy = 1e6f, dz = 1e6f;
+    if (h < H) {
+      idx = nbr[(int64_t)qi * H + h];
+      if (idx >= 0 && idx < ns) {
+        dx = s_pts[3 * (int64_t)idx] - qx;
+        dy = s_pts[3 * (int64_t)idx + 1] - qy;
+        dz = s_pts[3 * (int64_t)idx + 2] - qz;
+        cnt += rowsum[idx] > 0.f ? 1 : 0;
+      } else {
+        idx = -1;  // shadow neighbour: zero feature row, point at +1e6 => zero influence
+      }
+    }
+    s_idx[wave][h] = idx;
+    s_diff[wave][h][0] = dx; s_diff[wave][h][1] = dy; s_diff[wave][h][2] = dz;
+  }
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+  const float inv_num = 1.f / (float)max(cnt, 1);
+  const float inv_extent = 1.f / extent;
+  const bool kvalid = r16 < kKP;
+  const float kx = kvalid ? kp[3 * r16] : 0.f, ky = kvalid ? kp[3 * r16 + 1] : 0.f, kz = kvalid ? kp[3 * r16 + 2] : 0.f;
+  const int nsteps = (H + 3) >> 2;
+  for (int g0 = 0; g0 < cin / 64; g0 += NG) {
+    f32x4 acc[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[g][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < nsteps; ++st) {
+      const int h = st * 4 + qd;
+      const int idx = s_idx[wave][h];
+      float w = 0.f;
+      if (kvalid && idx >= 0)
+        w = kp_weight(s_diff[wave][h][0], s_diff[wave][h][1], s_diff[wave][h][2], kx, ky, kz, inv_extent);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (idx >= 0 && g0 + g < cin / 64)
+          b = *reinterpret_cast<const f32x4*>(x + (int64_t)idx * ldx + (g0 + g) * 64 + r16 * 4);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[g][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b[cb], acc[g][cb], 0, 0, 0);
+      }
+    }
+    // D[k = 4*qd + i][col r16 of block cb] <-> channel (g0+g)*64 + 4*r16 + cb
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g0 + g >= cin / 64) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = qd * 4 + i;
+        if (k < kKP) {
+          f32x4 v = {acc[g][0][i] * inv_num, acc[g][1][i] * inv_num, acc[g][2][i] * inv_num, acc[g][3][i] * inv_num};
+          *reinterpret_cast<f32x4*>(wf + (int64_t)qi * ldwf + (int64_t)k * cin + (g0 + g) * 64 + r16 * 4) = v;
+        }
+      }
+    }
+  }
+}
+
+// Step 1, VALU form for any Cin (the first layer has Cin = 1).  One thread per (query, kernel point).
+__global__ void k_kpconv_weighted_generic(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                          const int* __restrict__ nbr, int H, const float* __restrict__ x, int64_t ldx,
+                                          int cin, const float* __restrict__ kp, float extent,
+                                          const float* __restrict__ rowsum, float* __restrict__ wf, int64_t ldwf,
+                                          int nq, int ns) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nq * kKP) return;
+  const int qi = (int)(t / kKP), k = (int)(t - (int64_t)qi * kKP);
+  const float qx = q_pts[3 * (int64_t)qi], qy = q_pts[3 * (int64_t)qi + 1], qz = q_pts[3 * (int64_t)qi + 2];
+  const float kx = kp[3 * k], ky = kp[3 * k + 1], kz = kp[3 * k + 2];
+  const float inv_extent = 1.f / extent;
+  int cnt = 0;
+  for (int h = 0; h < H; ++h) {
+    const int idx = nbr[(int64_t)qi * H + h];
+    if (idx >= 0 && idx < ns && rowsum[idx] > 0.f) ++cnt;
+  }
+  const float inv_num = 1.f / (float)max(cnt, 1);
+  for (int c0 = 0; c0 < cin; c0 += 8) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nc = min(8, cin - c0);
+    for (int h = 0; h < H; ++h) {
+      const int idx = nbr[(int64_t)qi * H + h];
+      if (idx < 0 || idx >= ns) continue;
+      const float w = kp_weight(s_pts[3 * (int64_t)idx] - qx, s_pts[3 * (int64_t)idx + 1] - qy,
+                                s_pts[3 * (int64_t)idx + 2] - qz, kx, ky, kz, inv_extent);
+      if (w == 0.f) continue;
+      for (int c = 0; c < nc; ++c) acc[c] = fmaf(w, x[(int64_t)idx * ldx + c0 + c], acc[c]);
+    }
+    for (int c = 0; c < nc; ++c) wf[(int64_t)qi * ldwf + (int64_t)k * cin + c0 + c] = acc[c] * inv_num;
+  }
+}
+
+// out[q,:] = max_h x_pad[inds[q,h],:]  (x_pad = x plus a zero shadow row; blocks.py:86-102)
+// mode 1: out[q,:] = x_pad[inds[q,0],:]  (closest_pool, blocks.py:71-83)
+__global__ void k_gather_pool(const float* __restrict__ x, int64_t ldx, int ns, int c, const int* __restrict__ inds,
+                              int H, int64_t nq, int mode, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = nq * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t qi = t / c;
+    const int col = (int)(t - qi * c);
+    float m;
+    if (mode == 1) {
+      const int idx = inds[qi * H];
+      m = (idx >= 0 && idx < ns) ? x[(int64_t)idx * ldx + col] : 0.f;
+    } else {
+      m = -__builtin_inff();
+      for (int h = 0; h < H; ++h) {
+        const int idx = inds[qi * H + h];
+        m = fmaxf(m, (idx >= 0 && idx < ns) ? x[(int64_t)idx * ldx + col] : 0.f);
+      }
+    }
+    out[qi * ldo + col] = m;
+  }
+}
+
+// edge features of the DGCNN-style self attention: row (i,j) = [f_i, f_nbr(i,j) - f_i]   (gcn.py:9-35)
+__global__ void k_edge_features(const float* __restrict__ f, int64_t ldf, int n, int c, const int* __restrict__ knn,
+                                int k, float* __restrict__ out) {
+  const int64_t total = (int64_t)n * k * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(t % c);
+    const int64_t e = t / c;
+    const int i = (int)(e / k);
+    const int j = knn[e];
+    const float fi = f[(int64_t)i * ldf + col];
+    out[e * 2 * c + col] = fi;
+    out[e * 2 * c + c + col] = f[(int64_t)j * ldf + col] - fi;
+  }
+}
+
+// out[i,:] = max_j act(y[i*k + j,:] * scale + shift)   (InstanceNorm2d + LeakyReLU + max over k)
+__global__ void k_group_max(const float* __restrict__ y, int64_t ldy, int n, int k, int c,
+                            const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                            float* __restrict__ out, int64_t ldo) {
+  const int64_t total = (int64_t)n * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / c), col = (int)(t - (int64_t)i * c);
+    const float sc = scale ? scale[col] : 1.f, sh = shift ? shift[col] : 0.f;
+    float m = -__builtin_inff();
+    for (int j = 0; j < k; ++j) {
+      float v = y[((int64_t)i * k + j) * ldy + col] * sc + sh;
+      v = v > 0.f ? v : v * slope;
+      m = fmaxf(m, v);
+    }
+    out[(int64_t)i * ldo + col] = m;
+  }
+}
+
+// Multi-head attention with channel layout c = d * heads + h (gcn.py:94-116):
+//   out[n, d*heads+h] = sum_m softmax_m( sum_d q[n,d,h] k[m,d,h] / sqrt(dim) ) v[m,d,h]
+// One workgroup per (n, h): scores in LDS (M <= 4096), two-pass softmax, fp32.
+__global__ __launch_bounds__(256) void k_mha(const float* __restrict__ q, const float* __restrict__ kk,
+                                             const float* __restrict__ v, int n, int m, int dim, int heads,
+                                             float* __restrict__ out) {
+  extern __shared__ float s_sc[];  // [m] scores + [dim] query
+  float* s_q = s_sc + m;
+  __shared__ float s_red[256];
+  const int ni = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int c = dim * heads;
+  for (int d = threadIdx.x; d < dim; d += 256) s_q[d] = q[(int64_t)ni * c + d * heads + h];
+  __syncthreads();
+  const float scl = 1.f / sqrtf((float)dim);
+  float mx = -__builtin_inff();
+  for (int j = threadIdx.x; j < m; j += 256) {
+    float s = 0.f;
+    for (int d = 0; d < dim; ++d) s = fmaf(s_q[d], kk[(int64_t)j * c + d * heads + h], s);
+    s *= scl;
+    s_sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  s_red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  mx = s_red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    float e = expf(s_sc[j] - mx);
+    s_sc[j] = e;
+    sum += e;
+  }
+  s_red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+    __syncthreads();
+  }
+  const float inv = 1.f / s_red[0];
+  for (int d = threadIdx.x; d < dim; d += 256) {
+    float a = 0.f;
+    for (int j = 0; j < m; ++j) a = fmaf(s_sc[j], v[(int64_t)j * c + d * heads + h], a);
+    out[(int64_t)ni * c + d * heads + h] = a * inv;
+  }
+}
+
+// s[n] = sum_m softmax_m( <a[n,:], b[m,:]> / temperature ) * w[m]    (architectures.py:176-181)
+__global__ __launch_bounds__(256) void k_softmax_matvec(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ w, int n, int m, int c,
+                                                        float temperature, float* __restrict__ out) {
+  extern __shared__ float s_sc[];  // [m] + [c]
+  float* s_a = s_sc + m;
+  __shared__ float s_red[256];
+  const int ni = blockIdx.x;
+  for (int d = threadIdx.x; d < c; d += 256) s_a[d] = a[(int64_t)ni * c + d];
+  __syncthreads();
+  float mx = -__builtin_inff();
+  for (int j = threadIdx.x; j < m; j += 256) {
+    float s = 0.f;
+    for (int d = 0; d < c; ++d) s = fmaf(s_a[d], b[(int64_t)j * c + d], s);
+    s /= temperature;
+    s_sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  s_red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+    __syncthreads();
+  }
+  mx = s_red[0];
+  __syncthreads();
+  float num = 0.f, den = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    float e = expf(s_sc[j] - mx);
+    den += e;
+    num = fmaf(e, w[j], num);
+  }
+  s_red[threadIdx.x] = den;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+    __syncthreads();
+  }
+  den = s_red[0];
+  __syncthreads();
+  s_red[threadIdx.x] = num;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[ni] = s_red[0] / den;
+}
+
+// y = clamp(sigmoid(x), 0, 1) with NaN / Inf -> 0   (architectures.py:131-134, 203-207)
+__global__ void k_score_head(const float* __restrict__ x, int64_t ldx, int64_t n, float* __restrict__ y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 1.f / (1.f + expf(-x[i * ldx]));
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  if (isnan(v) || isinf(v)) v = 0.f;
+  y[i] = v;
+}
+
+}  // namespace
+
+APR_API int apr_row_sums(const float* x, int64_t ld, int64_t n, int32_t c, float* out, void* stream) {
+  APR_CHECK_ARG(n >= 0 && c > 0 && ld >= c, "apr_row_sums: bad shape");
+  if (n == 0) return APR_OK;
+  hipLaunchKernelGGL(k_row_sums, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, n, c, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_kpconv_weighted(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr,
+                                int32_t H, const float* x, int64_t ldx, int32_t cin, const float* kernel_points,
+                                int32_t n_kp, float extent, const float* rowsum, float* wf, int64_t ldwf, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n_kp == kKP, "apr_kpconv_weighted: built for %d kernel points, got %d", kKP, n_kp);
+  APR_CHECK_ARG(nq >= 0 && ns > 0 && H > 0 && cin > 0 && extent > 0.f, "apr_kpconv_weighted: bad arguments");
+  APR_CHECK_ARG(ldx >= cin && ldwf >= (int64_t)kKP * cin, "apr_kpconv_weighted: leading dimension too small");
+  if (nq == 0) return APR_OK;
+  const bool vec = cin % 64 == 0 && H <= kMaxH && ldx % 4 == 0 && ldwf % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)wf)) & 15) == 0;
+  if (vec) {
+    const unsigned grid = (unsigned)cdiv64(nq, 4);
+    if (cin >= 256)
+      hipLaunchKernelGGL(k_kpconv_weighted_mfma<4>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, x, ldx, cin,
+                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
+    else if (cin == 128)
+      hipLaunchKernelGGL(k_kpconv_weighted_mfma<2>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, x, ldx, cin,
+                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
+    else
+      hipLaunchKernelGGL(k_kpconv_weighted_mfma<1>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, x, ldx, cin,
+                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
+  } else {
+    hipLaunchKernelGGL(k_kpconv_weighted_generic, dim3((unsigned)cdiv64(nq * kKP, 256)), dim3(256), 0, st, q_pts, s_pts,
+                       nbr, H, x, ldx, cin, kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
+  }
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_gather_pool(const float* x, int64_t ldx, int64_t ns, int32_t c, const int32_t* inds, int32_t H,
+                            int64_t nq, int32_t mode, float* out, int64_t ldo, void* stream) {
+  APR_CHECK_ARG(nq >= 0 && ns >= 0 && c > 0 && H > 0 && ldx >= c && ldo >= c && (mode == 0 || mode == 1),
+                "apr_gather_pool: bad arguments");
+  if (nq == 0) return APR_OK;
+  int64_t nblk = cdiv64(nq * c, 256);
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(k_gather_pool, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)ns, c, inds, H,
+                     nq, mode, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_edge_features(const float* f, int64_t ldf, int32_t n, int32_t c, const int32_t* knn, int32_t k,
+                              float* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && c > 0 && k > 0 && ldf >= c, "apr_edge_features: bad arguments");
+  int64_t nblk = cdiv64((int64_t)n * k * c, 256);
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(k_edge_features, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, f, ldf, n, c, knn, k, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_group_max(const float* y, int64_t ldy, int32_t n, int32_t k, int32_t c, const float* scale,
+                          const float* shift, float slope, float* out, int64_t ldo, void* stream) {
+  APR_CHECK_ARG(n > 0 && k > 0 && c > 0 && ldy >= c && ldo >= c, "apr_group_max: bad arguments");
+  int64_t nblk = cdiv64((int64_t)n * c, 256);
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(k_group_max, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, y, ldy, n, k, c, scale, shift,
+                     slope, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
+                    float* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0, "apr_mha: bad arguments");
+  APR_CHECK_ARG((size_t)(m + dim) * 4 <= 60 * 1024, "apr_mha: at most %d keys supported", (60 * 1024) / 4 - dim);
+  hipLaunchKernelGGL(k_mha, dim3((unsigned)(n * heads)), dim3(256), (size_t)(m + dim) * 4, (hipStream_t)stream, q, k, v,
+                     n, m, dim, heads, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_softmax_matvec(const float* a, const float* b, const float* w, int32_t n, int32_t m, int32_t c,
+                               float temperature, float* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && c > 0 && temperature > 0.f, "apr_softmax_matvec: bad arguments");
+  APR_CHECK_ARG((size_t)(m + c) * 4 <= 60 * 1024, "apr_softmax_matvec: m + c too large for LDS");
+  hipLaunchKernelGGL(k_softmax_matvec, dim3((unsigned)n), dim3(256), (size_t)(m + c) * 4, (hipStream_t)stream, a, b, w, n,
+                     m, c, temperature, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_score_head(const float* x, int64_t ldx, int64_t n, float* y, void* stream) {
+  APR_CHECK_ARG(n >= 0 && ldx >= 1, "apr_score_head: bad arguments");
+  if (n == 0) return APR_OK;
+  hipLaunchKernelGGL(k_score_head, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, y);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}

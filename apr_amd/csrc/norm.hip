@@ -51,7 +51,7 @@ __global__ void k_bn_finish(const double* __restrict__ partial, int nblk, int64_
 
 __global__ void k_affine_act(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
                              const float* __restrict__ scale, const float* __restrict__ shift,
-                             const float* __restrict__ residual, int64_t ldr, int relu,
+                             const float* __restrict__ residual, int64_t ldr, int relu, float slope,
                              float* __restrict__ y, int64_t ldy) {
   const int64_t total = n * c;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -62,7 +62,8 @@ __global__ void k_affine_act(const float* __restrict__ x, int64_t ldx, int64_t n
     if (scale) v *= scale[col];
     if (shift) v += shift[col];
     if (residual) v += residual[r * ldr + col];
-    if (relu) v = fmaxf(v, 0.f);
+    if (relu == 1) v = fmaxf(v, 0.f);
+    else if (relu == 2) v = v > 0.f ? v : v * slope;
     y[r * ldy + col] = v;
   }
 }
@@ -104,13 +105,13 @@ APR_API int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c, float
 
 APR_API int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c, const float* scale,
                            const float* shift, const float* residual, int64_t ldr, int32_t relu,
-                           float* y, int64_t ldy, void* stream) {
+                           float negative_slope, float* y, int64_t ldy, void* stream) {
   APR_CHECK_ARG(n >= 0 && c > 0 && ldx >= c && ldy >= c, "apr_affine_act: bad shape");
   if (n == 0) return APR_OK;
   int64_t nblk = cdiv64(n * c, 256);
   if (nblk > 8192) nblk = 8192;
   hipLaunchKernelGGL(k_affine_act, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, n, c,
-                     scale, shift, residual, ldr, relu, y, ldy);
+                     scale, shift, residual, ldr, relu, negative_slope, y, ldy);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

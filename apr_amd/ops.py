@@ -210,7 +210,8 @@ def bn_stats(x):
     return mean, var
 
 
-def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
+def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None, leaky=None):
+    """y = act(x*scale + shift + residual); relu=True -> ReLU, leaky=slope -> LeakyReLU(slope)."""
     x, ldx = _rows(x, "affine_act.x")
     n, c = x.shape
     if out is None:
@@ -219,8 +220,9 @@ def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
     ldr = 0
     if residual is not None:
         residual, ldr = _rows(residual, "affine_act.residual")
-    check(_lib_().apr_affine_act(ptr(x), ldx, n, c, ptr(scale), ptr(shift), ptr(residual), ldr, int(bool(relu)),
-                                 ptr(out), ldy, stream()))
+    mode = 2 if leaky is not None else int(bool(relu))
+    check(_lib_().apr_affine_act(ptr(x), ldx, n, c, ptr(scale), ptr(shift), ptr(residual), ldr, mode,
+                                 float(leaky or 0.0), ptr(out), ldy, stream()))
     return out
 
 

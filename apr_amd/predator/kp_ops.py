@@ -1,0 +1,110 @@
+"""Tensor-level wrappers of the KPConv / overlap-attention kernels (all libapr_hip.so calls)."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib, ops
+from .._lib import check, ptr, stream
+
+
+def _i32(t, name):
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    if not t.is_cuda:
+        raise _lib.AprHipError(f"{name}: need a GPU index tensor")
+    return t.contiguous()
+
+
+def linear(x, wp_info, shift=None, relu=False, out=None):
+    """x [N,cin] @ W (packed by `pack_linear`) (+ shift) -> [N,cout] on the sparse-conv GEMM path."""
+    wp, cin, cout = wp_info
+    return ops.spconv(x, None, 1, cin, cout, wp, shift=shift, relu=relu, out=out, n_out=x.shape[0])
+
+
+def pack_linear(w_in_out):
+    """[cin, cout] weight -> (packed, cin, cout)."""
+    w = w_in_out.detach().to(torch.float32).contiguous()
+    return ops.pack_weights(w), w.shape[0], w.shape[1]
+
+
+def row_sums(x):
+    x, ld = ops._rows(x, "row_sums.x")
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.load().apr_row_sums(ptr(x), ld, x.shape[0], x.shape[1], ptr(out), stream()))
+    return out
+
+
+def kpconv_weighted(q_pts, s_pts, nbr, x, kernel_points, extent):
+    """KPConv step 1 -> weighted features [Nq, ld] (ld = 15*cin rounded up to 32), already / neighbour count."""
+    nbr = _i32(nbr, "kpconv.nbr")
+    x, ldx = ops._rows(x, "kpconv.x")
+    nq, ns, cin = q_pts.shape[0], s_pts.shape[0], x.shape[1]
+    kk = kernel_points.shape[0] * cin
+    ld = (kk + 31) // 32 * 32
+    wf = torch.zeros((nq, ld), dtype=torch.float32, device=x.device) if ld != kk else \
+        torch.empty((nq, ld), dtype=torch.float32, device=x.device)
+    rs = row_sums(x)
+    check(_lib.load().apr_kpconv_weighted(ptr(q_pts.contiguous()), nq, ptr(s_pts.contiguous()), ns, ptr(nbr), nbr.shape[1],
+                                          ptr(x), ldx, cin, ptr(kernel_points.contiguous()), kernel_points.shape[0],
+                                          float(extent), ptr(rs), ptr(wf), ld, stream()))
+    return wf
+
+
+def gather_pool(x, inds, mode):
+    """mode 'max' -> max_pool(x, inds); 'closest' -> closest_pool(x, inds)."""
+    inds = _i32(inds, "gather_pool.inds")
+    x, ldx = ops._rows(x, "gather_pool.x")
+    nq, c = inds.shape[0], x.shape[1]
+    out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().apr_gather_pool(ptr(x), ldx, x.shape[0], c, ptr(inds), inds.shape[1], nq,
+                                      1 if mode == "closest" else 0, ptr(out), c, stream()))
+    return out
+
+
+def edge_features(f, knn):
+    knn = _i32(knn, "edge_features.knn")
+    f, ldf = ops._rows(f, "edge_features.f")
+    n, c = f.shape
+    out = torch.empty((n * knn.shape[1], 2 * c), dtype=torch.float32, device=f.device)
+    check(_lib.load().apr_edge_features(ptr(f), ldf, n, c, ptr(knn), knn.shape[1], ptr(out), stream()))
+    return out
+
+
+def group_max(y, n, k, scale, shift, slope):
+    y, ldy = ops._rows(y, "group_max.y")
+    c = y.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=y.device)
+    check(_lib.load().apr_group_max(ptr(y), ldy, n, k, c, ptr(scale), ptr(shift), float(slope), ptr(out), c, stream()))
+    return out
+
+
+def mha(q, k, v, heads):
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    n, c = q.shape
+    out = torch.empty_like(q)
+    check(_lib.load().apr_mha(ptr(q), ptr(k), ptr(v), n, k.shape[0], c // heads, heads, ptr(out), stream()))
+    return out
+
+
+def softmax_matvec(a, b, w, temperature):
+    a, b, w = a.contiguous(), b.contiguous(), w.contiguous().view(-1)
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    check(_lib.load().apr_softmax_matvec(ptr(a), ptr(b), ptr(w), a.shape[0], b.shape[0], a.shape[1], float(temperature),
+                                         ptr(out), stream()))
+    return out
+
+
+def score_head(x_col):
+    """x_col: a [N] column view (stride allowed) -> clamp(sigmoid(x)) with NaN/Inf -> 0."""
+    n = x_col.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=x_col.device)
+    check(_lib.load().apr_score_head(ptr(x_col), x_col.stride(0), n, ptr(out), stream()))
+    return out
+
+
+def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=None):
+    """Per-channel normalisation over all rows, no affine (InstanceNorm1d on [1,C,N]) + activation."""
+    mean, var = ops.bn_stats(x)
+    scale = torch.rsqrt(var + eps)
+    shift = -mean * scale
+    return ops.affine_act(x, scale=scale, shift=shift, residual=residual, relu=relu, leaky=leaky, out=out)

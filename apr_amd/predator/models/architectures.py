@@ -1,0 +1,133 @@
+"""KPFCNN: KPConv encoder + overlap attention + nearest-upsample decoder on the HIP operator library.
+
+Constructor (`KPFCNN(config)` reading the attributes listed in SURVEY 5.6), sub-module / parameter
+names and `forward(batch) -> (feats_f [N0,32] unit norm, scores_overlap [N0], scores_saliency [N0])`
+follow /root/reference/Predator_APR/models/architectures.py:9-212; a reference `state_dict` loads
+unchanged.  `batch` is the dict built by `collate_fn_descriptor` (points / neighbors / pools /
+upsamples / stack_lengths / features), index tensors int32 or int64, everything on the GPU.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .. import kp_ops
+from .blocks import block_decider
+from .gcn import GCN, _Packed, conv1x1
+
+
+class KPFCNN(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        layer = 0
+        r = config.first_subsampling_dl * config.conv_radius
+        in_dim = config.in_feats_dim
+        out_dim = config.first_feats_dim
+        self.final_feats_dim = config.final_feats_dim
+        self.K = config.num_kernel_points
+        self.epsilon = torch.nn.Parameter(torch.tensor(-5.0))
+        self.condition = config.condition_feature
+        self.add_cross_overlap = config.add_cross_score
+
+        self.encoder_blocks = nn.ModuleList()
+        self.encoder_skip_dims = []
+        self.encoder_skips = []
+        for block_i, block in enumerate(config.architecture):
+            if ('equivariant' in block) and (not out_dim % 3 == 0):
+                raise ValueError('Equivariant block but features dimension is not a factor of 3')
+            if np.any([tmp in block for tmp in ['pool', 'strided', 'upsample', 'global']]):
+                self.encoder_skips.append(block_i)
+                self.encoder_skip_dims.append(in_dim)
+            if 'upsample' in block:
+                break
+            self.encoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim // 2 if 'simple' in block else out_dim
+            if 'pool' in block or 'strided' in block:
+                layer += 1
+                r *= 2
+                out_dim *= 2
+
+        gnn_feats_dim = config.gnn_feats_dim
+        self.bottle = nn.Conv1d(in_dim, gnn_feats_dim, kernel_size=1, bias=True)
+        self.gnn = GCN(config.num_head, gnn_feats_dim, config.dgcnn_k, config.nets)
+        self.proj_gnn = nn.Conv1d(gnn_feats_dim, gnn_feats_dim, kernel_size=1, bias=True)
+        self.proj_score = nn.Conv1d(gnn_feats_dim, 1, kernel_size=1, bias=True)
+
+        out_dim = gnn_feats_dim + 2 if self.add_cross_overlap else gnn_feats_dim + 1
+        self.decoder_blocks = nn.ModuleList()
+        self.decoder_concats = []
+        start_i = 0
+        for block_i, block in enumerate(config.architecture):
+            if 'upsample' in block:
+                start_i = block_i
+                break
+        for block_i, block in enumerate(config.architecture[start_i:]):
+            if block_i > 0 and 'upsample' in config.architecture[start_i + block_i - 1]:
+                in_dim += self.encoder_skip_dims[layer]
+                self.decoder_concats.append(block_i)
+            self.decoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim
+            if 'upsample' in block:
+                layer -= 1
+                r *= 0.5
+                out_dim = out_dim // 2
+        self._c = [_Packed(), _Packed(), _Packed()]
+
+    def regular_score(self, score):
+        score = torch.where(torch.isnan(score), torch.zeros_like(score), score)
+        return torch.where(torch.isinf(score), torch.zeros_like(score), score)
+
+    @torch.no_grad()
+    def forward(self, batch):
+        x = batch['features'].clone().detach()
+        len_src_c = int(batch['stack_lengths'][-1][0])
+        pcd_c = batch['points'][-1]
+        src_pcd_c, tgt_pcd_c = pcd_c[:len_src_c], pcd_c[len_src_c:]
+
+        # 1. joint encoder
+        skip_x = []
+        for block_i, block_op in enumerate(self.encoder_blocks):
+            if block_i in self.encoder_skips:
+                skip_x.append(x)
+            x = block_op(x, batch)
+
+        # 2. bottleneck projection (rows: [N_c, C])
+        feats_c = conv1x1(x, self.bottle, self._c[0])
+        unconditioned_feats = feats_c
+
+        # 3. overlap attention between the two clouds
+        src_feats_c, tgt_feats_c = self.gnn(src_pcd_c.contiguous(), tgt_pcd_c.contiguous(),
+                                            feats_c[:len_src_c], feats_c[len_src_c:])
+        feats_c = torch.cat([src_feats_c, tgt_feats_c], dim=0)
+        feats_c = conv1x1(feats_c, self.proj_gnn, self._c[1])
+        scores_c_raw = conv1x1(feats_c, self.proj_score, self._c[2])          # [N_c, 1]
+        feats_gnn_norm = ops.l2_normalize(feats_c)
+        feats_gnn_raw = feats_c
+
+        # 4. cross saliency: softmax(<src, tgt> / T) @ scores, both directions, never forming N x N
+        src_n, tgt_n = feats_gnn_norm[:len_src_c], feats_gnn_norm[len_src_c:]
+        src_s, tgt_s = scores_c_raw[:len_src_c], scores_c_raw[len_src_c:]
+        temperature = float(torch.exp(self.epsilon) + 0.03)
+        s1 = kp_ops.softmax_matvec(src_n, tgt_n, tgt_s, temperature)
+        s2 = kp_ops.softmax_matvec(tgt_n, src_n, src_s, temperature)
+        scores_saliency = torch.cat((s1, s2), dim=0).unsqueeze(1)
+
+        if self.condition and self.add_cross_overlap:
+            x = torch.cat([scores_c_raw, scores_saliency, feats_gnn_raw], dim=1)
+        elif self.condition and not self.add_cross_overlap:
+            x = torch.cat([scores_c_raw, feats_gnn_raw], dim=1)
+        elif not self.condition and self.add_cross_overlap:
+            x = torch.cat([scores_c_raw, scores_saliency, unconditioned_feats], dim=1)
+        else:
+            x = torch.cat([scores_c_raw, unconditioned_feats], dim=1)
+
+        # 5. decoder
+        for block_i, block_op in enumerate(self.decoder_blocks):
+            if block_i in self.decoder_concats:
+                x = torch.cat([x, skip_x.pop()], dim=1)
+            x = block_op(x, batch)
+        x = x.contiguous()
+        feats_f = ops.l2_normalize(x[:, :self.final_feats_dim])
+        scores_overlap = kp_ops.score_head(x[:, self.final_feats_dim])
+        scores_saliency = kp_ops.score_head(x[:, self.final_feats_dim + 1])
+        return feats_f, scores_overlap, scores_saliency

@@ -125,10 +125,11 @@ int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c,
                  float* mean, float* var, void* scratch, size_t scratch_bytes, void* stream);
 size_t apr_bn_stats_scratch_bytes(int64_t n, int32_t c);
 
-/* y = act(x * scale[c] + shift[c] (+ residual)); scale/shift/residual nullable. */
+/* y = act(x * scale[c] + shift[c] (+ residual)); scale/shift/residual nullable.
+ * relu: 0 none, 1 ReLU, 2 LeakyReLU(negative_slope) (Predator_APR/models/blocks.py:489,574). */
 int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c,
                    const float* scale, const float* shift,
-                   const float* residual, int64_t ldr, int32_t relu,
+                   const float* residual, int64_t ldr, int32_t relu, float negative_slope,
                    float* y, int64_t ldy, void* stream);
 
 /* Row L2 normalisation F / ||F||_2 (FCGF_APR/model/resunet.py:187-191). */
@@ -210,6 +211,45 @@ int apr_radius_neighbors(const float* queries, int64_t nq, const float* supports
 /* k nearest neighbours inside one cloud (brute force, k + skip_first <= 16); replaces the dense
  * square_distance + topk(k+1)[..., 1:] of Predator_APR/models/gcn.py:19-23.  out i32[n,k]. */
 int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * KPConv encoder + overlap attention (Predator_APR/models/blocks.py, gcn.py, architectures.py)
+ * ---------------------------------------------------------------------- */
+
+/* out[i] = sum_c x[i,c]  (neighbour-count normaliser of KPConv, blocks.py:369-372). */
+int apr_row_sums(const float* x, int64_t ld, int64_t n, int32_t c, float* out, void* stream);
+
+/* KPConv step 1 (blocks.py:269-289,326-329,347-372): kernel-point correlation
+ *   wf[q, k*cin + c] = ( sum_h max(0, 1 - |s[nbr[q,h]] - q - kp[k]| / extent) * x[nbr[q,h], c] ) / num[q]
+ *   num[q] = max(#{h : rowsum[nbr[q,h]] > 0}, 1); nbr entries >= ns (or < 0) are shadow neighbours.
+ * Step 2 is apr_spconv_fwd(wf, nbr = NULL, K = 1, cin = 15*cin, cout) with the [15,cin,cout] weights. */
+int apr_kpconv_weighted(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr,
+                        int32_t H, const float* x, int64_t ldx, int32_t cin, const float* kernel_points,
+                        int32_t n_kp, float extent, const float* rowsum, float* wf, int64_t ldwf, void* stream);
+
+/* mode 0: max_pool(x, inds) (blocks.py:86-102); mode 1: closest_pool(x, inds) (blocks.py:71-83).
+ * Index ns addresses an implicit all-zero shadow row. */
+int apr_gather_pool(const float* x, int64_t ldx, int64_t ns, int32_t c, const int32_t* inds, int32_t H,
+                    int64_t nq, int32_t mode, float* out, int64_t ldo, void* stream);
+
+/* get_graph_feature (gcn.py:9-35) as rows: out[(i*k + j), :] = [f_i, f_knn(i,j) - f_i], f32 [n*k, 2c]. */
+int apr_edge_features(const float* f, int64_t ldf, int32_t n, int32_t c, const int32_t* knn, int32_t k,
+                      float* out, void* stream);
+
+/* out[i,:] = max_j leaky(y[i*k+j,:] * scale + shift)  (InstanceNorm2d + LeakyReLU(0.2) + max, gcn.py:67-72). */
+int apr_group_max(const float* y, int64_t ldy, int32_t n, int32_t k, int32_t c, const float* scale,
+                  const float* shift, float slope, float* out, int64_t ldo, void* stream);
+
+/* Multi-head softmax attention, channel c = d*heads + h (gcn.py:94-116). q f32[n,dim*heads], k/v f32[m,...]. */
+int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
+            float* out, void* stream);
+
+/* out[i] = sum_j softmax_j(<a_i, b_j> / temperature) * w[j]  (cross saliency, architectures.py:176-181). */
+int apr_softmax_matvec(const float* a, const float* b, const float* w, int32_t n, int32_t m, int32_t c,
+                       float temperature, float* out, void* stream);
+
+/* y[i] = clamp(sigmoid(x[i*ldx]), 0, 1), NaN/Inf -> 0  (architectures.py:131-134,203-207). */
+int apr_score_head(const float* x, int64_t ldx, int64_t n, float* y, void* stream);
 
 #ifdef __cplusplus
 }
