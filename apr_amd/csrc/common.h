@@ -66,3 +66,30 @@ __host__ __device__ static inline int apr_floor_to(int v, int m) {
   if ((v % m) != 0 && v < 0) --q;
   return q * m;
 }
+
+// ---- internal helpers shared between translation units (not exported) ----
+struct AprSearchGrid {
+  const unsigned long long* keys;
+  const int* vals;
+  uint32_t mask;
+  const int* start;   // [ncell + 1]
+  const int* sorted;  // point indices bucketed by cell
+  const float* mins;  // [3] cloud minimum = grid origin
+  float cell;
+};
+size_t apr_internal_grid_bytes(int64_t n);
+int apr_internal_search_grid(const float* pts, int64_t n, float cell, void* scratch, AprSearchGrid* out,
+                             hipStream_t st);
+
+__device__ static inline int apr_table_lookup(const unsigned long long* __restrict__ keys,
+                                              const int* __restrict__ vals, uint32_t mask,
+                                              unsigned long long key) {
+  uint32_t slot = apr_hash_u64(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long k = keys[slot];
+    if (k == key) return vals[slot];
+    if (k == APR_KEY_EMPTY) return -1;
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}

@@ -438,6 +438,25 @@ APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengt
   return APR_OK;
 }
 
+// internal (not part of the C ABI): uniform search grid over one cloud, used by the geometric
+// RANSAC validation in ransac.hip
+size_t apr_internal_grid_bytes(int64_t n) { return grid_work_bytes(n > 0 ? n : 1); }
+int apr_internal_search_grid(const float* pts, int64_t n, float cell, void* scratch, AprSearchGrid* out,
+                             hipStream_t st) {
+  GridWork w = carve(scratch, n);
+  int32_t len = (int32_t)n;
+  int rc = build_grid(pts, n, &len, 1, cell, 1, w, st);
+  if (rc != APR_OK) return rc;
+  out->keys = w.keys;
+  out->vals = w.vals;
+  out->mask = (uint32_t)(w.cap - 1);
+  out->start = w.start;
+  out->sorted = w.sorted;
+  out->mins = w.mins;
+  out->cell = cell;
+  return APR_OK;
+}
+
 APR_API size_t apr_radius_scratch_bytes(int64_t nq, int64_t ns) {
   return grid_work_bytes(ns > 0 ? ns : 1) + align256((nq > 0 ? nq : 1) * 4) + align256((kMaxBatch + 1) * 4) + 512;
 }

@@ -428,9 +428,147 @@ __global__ __launch_bounds__(1024) void k_irls(const float* __restrict__ pts0, c
   if (tid < 16) T_out[tid] = s_T[tid];
 }
 
+// ---- open3d 0.10/0.11 semantics: geometric validation of the first `max_validation` survivors ----
+// rank[h] = number of survivors with a smaller iteration index (survivors are appended unordered)
+__global__ void k_rank_by_iteration(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                    int max_validation, int* __restrict__ selected) {
+  const int nv = min(*n_valid, cap);
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= nv) return;
+  const long long it = hyps[h].it;
+  int rank = 0;
+  for (int o = 0; o < nv; ++o) rank += hyps[o].it < it ? 1 : 0;
+  selected[h] = rank < max_validation ? 1 : 0;
+}
+
+// One wave per selected survivor: every transformed source point looks for its nearest target point
+// within max_dist in a uniform grid (cell = max_dist): inlier count + sum of squared NN distances
+// (GetRegistrationResultAndCorrespondences of open3d <= 0.11).
+__global__ __launch_bounds__(256) void k_score_geometric(const float* __restrict__ xyz0, int64_t n0,
+                                                         const float* __restrict__ xyz1, AprSearchGrid g,
+                                                         double max_dist, Hyp* __restrict__ hyps,
+                                                         const int* __restrict__ n_valid, int cap,
+                                                         const int* __restrict__ selected) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nv = min(*n_valid, cap);
+  const float md2 = (float)(max_dist * max_dist);
+  for (int h = wave; h < nv; h += nwaves) {
+    if (!selected[h]) {
+      if (lane == 0) hyps[h].inliers = -1;
+      continue;
+    }
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = hyps[h].T[k];
+    int cnt = 0;
+    double e2 = 0.0;
+    for (int64_t i = lane; i < n0; i += 64) {
+      const double sx = xyz0[3 * i], sy = xyz0[3 * i + 1], sz = xyz0[3 * i + 2];
+      const float px = (float)(T[0] * sx + T[1] * sy + T[2] * sz + T[3]);
+      const float py = (float)(T[4] * sx + T[5] * sy + T[6] * sz + T[7]);
+      const float pz = (float)(T[8] * sx + T[9] * sy + T[10] * sz + T[11]);
+      const int cx = (int)floorf((px - g.mins[0]) / g.cell), cy = (int)floorf((py - g.mins[1]) / g.cell),
+                cz = (int)floorf((pz - g.mins[2]) / g.cell);
+      float best = md2;
+      bool found = false;
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int x = cx + dx, y = cy + dy, z = cz + dz;
+            if (!apr_key_in_range(0, x, y, z)) continue;
+            const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, x, y, z));
+            if (id < 0) continue;
+            for (int a = g.start[id]; a < g.start[id + 1]; ++a) {
+              const int j = g.sorted[a];
+              const float ex = px - xyz1[3 * (int64_t)j], ey = py - xyz1[3 * (int64_t)j + 1],
+                          ez = pz - xyz1[3 * (int64_t)j + 2];
+              const float d2 = ex * ex + ey * ey + ez * ez;
+              if (d2 < best) {
+                best = d2;
+                found = true;
+              }
+            }
+          }
+      if (found) {
+        ++cnt;
+        e2 += (double)best;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      cnt += __shfl_xor(cnt, d);
+      e2 += __shfl_xor(e2, d);
+    }
+    if (lane == 0) {
+      hyps[h].inliers = cnt;
+      hyps[h].err2 = e2;
+    }
+  }
+}
+
 constexpr int64_t kChunk = 1 << 20;
 
 }  // namespace
+
+APR_API size_t apr_ransac_geometric_scratch_bytes(int64_t n0, int64_t n1, int64_t max_iter) {
+  return apr_ransac_scratch_bytes(n0, max_iter) + (size_t)(max_iter < kChunk ? max_iter : kChunk) * 4 + 256 +
+         apr_internal_grid_bytes(n1) + 256;
+}
+
+APR_API int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1,
+                                      const int64_t* corr, double max_dist, double edge_ratio, int64_t max_iter,
+                                      int64_t max_validation, uint64_t seed, void* scratch, size_t scratch_bytes,
+                                      double* result_host, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n0 > 0 && n0 < (1ll << 31) && n1 > 0 && n1 < (1ll << 31), "apr_ransac_pose_geometric: empty point set");
+  APR_CHECK_ARG(max_iter > 0 && max_iter <= kChunk && max_validation > 0 && max_dist > 0,
+                "apr_ransac_pose_geometric: need 0 < max_iter <= %lld and max_validation > 0", (long long)kChunk);
+  APR_CHECK_ARG(scratch_bytes >= apr_ransac_geometric_scratch_bytes(n0, n1, max_iter),
+                "apr_ransac_pose_geometric: scratch too small");
+  const int64_t cap = max_iter;
+  char* p = (char*)scratch;
+  Hyp* best = (Hyp*)p;
+  p += sizeof(Hyp);
+  long long* total_valid = (long long*)p;
+  p += 8;
+  int* n_valid = (int*)p;
+  p += 56;
+  Hyp* hyps = (Hyp*)p;
+  p += (size_t)cap * sizeof(Hyp);
+  float* tgt = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  p = (char*)tgt + (size_t)n0 * 12;
+  int* selected = (int*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  p = (char*)selected + (size_t)cap * 4;
+  void* grid_scratch = (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  AprSearchGrid g;
+  int rc = apr_internal_search_grid(xyz1, n1, (float)max_dist, grid_scratch, &g, st);
+  if (rc != APR_OK) return rc;
+  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, best, total_valid);
+  hipLaunchKernelGGL(k_gather_targets, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz1, n1,
+                     (const long long*)corr, n0, tgt);
+  APR_HIP(hipMemsetAsync(n_valid, 0, 4, st));
+  hipLaunchKernelGGL(k_hypotheses, dim3((unsigned)cdiv64(max_iter, 256)), dim3(256), 0, st, xyz0, tgt, (uint32_t)n0,
+                     max_dist, edge_ratio, 0ll, (long long)max_iter, seed, hyps, n_valid, (int)cap);
+  hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, hyps, n_valid, (int)cap,
+                     (int)(max_validation < (1ll << 30) ? max_validation : (1ll << 30)), selected);
+  hipLaunchKernelGGL(k_score_geometric, dim3(1024), dim3(256), 0, st, xyz0, n0, xyz1, g, max_dist, hyps, n_valid,
+                     (int)cap, selected);
+  hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, hyps, n_valid, (int)cap, best, total_valid);
+  APR_LAUNCH_CHECK();
+  Hyp hb;
+  long long tv = 0;
+  APR_HIP(hipMemcpyAsync(&hb, best, sizeof(Hyp), hipMemcpyDeviceToHost, st));
+  APR_HIP(hipMemcpyAsync(&tv, total_valid, 8, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipStreamSynchronize(st));
+  for (int k = 0; k < 12; ++k) result_host[k] = hb.T[k];
+  result_host[12] = 0.0; result_host[13] = 0.0; result_host[14] = 0.0; result_host[15] = 1.0;
+  result_host[16] = (double)(hb.inliers < 0 ? 0 : hb.inliers);
+  result_host[17] = hb.inliers > 0 ? sqrt(hb.err2 / (double)hb.inliers) : 0.0;
+  result_host[18] = (double)hb.it;
+  result_host[19] = (double)tv;
+  return APR_OK;
+}
 
 APR_API size_t apr_ransac_scratch_bytes(int64_t n0, int64_t max_iter) {
   int64_t cap = max_iter < kChunk ? max_iter : kChunk;

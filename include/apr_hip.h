@@ -170,12 +170,36 @@ int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1
                     int64_t max_iter, uint64_t seed,
                     void* scratch, size_t scratch_bytes, double* result_host, void* stream);
 
+/* Same sampler / checkers / Kabsch, but open3d <= 0.11 semantics as used by
+ *   Predator_APR/lib/benchmark_utils.py:213-225 (`o3d.registration`, RANSACConvergenceCriteria(50000, 1000)):
+ *   only the first `max_validation` surviving hypotheses (in iteration order) are validated, and a
+ *   hypothesis is scored GEOMETRICALLY: a transformed source point is an inlier when its nearest
+ *   target point lies within max_dist (uniform-grid NN search); fitness = inliers / n0, then RMSE.
+ *   max_iter <= 2^20.  result_host as apr_ransac_pose.  Synchronises the stream. */
+size_t apr_ransac_geometric_scratch_bytes(int64_t n0, int64_t n1, int64_t max_iter);
+int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1,
+                              const int64_t* corr, double max_dist, double edge_ratio,
+                              int64_t max_iter, int64_t max_validation, uint64_t seed,
+                              void* scratch, size_t scratch_bytes, double* result_host, void* stream);
+
 /* Robust linearised 6-DoF pose (20 IRLS iterations), replaces
  * est_quad_linear_robust (FCGF_APR/util/transform_estimation.py:89-116).
  * pts0/pts1 f32[n,3] paired, weight f32[n] nullable; T_host f32[16]; syncs. */
 int apr_irls_pose(const float* pts0, const float* pts1, const float* weight, int64_t n,
                   float* T_host, void* scratch, size_t scratch_bytes, void* stream);
 size_t apr_irls_scratch_bytes(int64_t n);
+
+/* Hardest-contrastive mining (forward), replaces the mining + masking + loss arithmetic of
+ *   contrastive_hardest_negative_loss (FCGF_APR/lib/trainer.py:400-452, `_hash` util/misc.py:6-18).
+ *   pos_f0/pos_f1 f32[p,c]: features of the sampled positive pairs; nn01/nn10 u64[p]: packed
+ *   apr_feature_nn results of pos_f0 in F1[sel1] / pos_f1 in F0[sel0]; sorted_pos_keys: ascending
+ *   int64 keys i + j*hash_seed of ALL positive pairs.  out6 f64[6] (device) =
+ *   {sum pos_loss, p, sum neg_loss0, count0, sum neg_loss1, count1}. */
+int apr_contrastive_reduce(const float* pos_f0, const float* pos_f1, int32_t p, int32_t c,
+                           const uint64_t* nn01, const uint64_t* nn10, const int64_t* sel0, const int64_t* sel1,
+                           const int64_t* pos_ind0, const int64_t* pos_ind1, const int64_t* sorted_pos_keys,
+                           int32_t n_keys, int64_t hash_seed, float pos_thresh, float neg_thresh,
+                           double* out6, void* stream);
 
 /* ------------------------------------------------------------------------
  * Point-set index builds of the KPConv encoder (Predator_APR)

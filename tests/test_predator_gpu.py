@@ -82,8 +82,12 @@ def test_collate_matches_reference_collate(dev):
     assert [len(p) for p in got["points"]] == [int(v) for v in g["level_sizes"]]
     assert [n.shape[1] for n in got["neighbors"]] == [int(v) for v in g["nbr_widths"]]
     for l in range(4):
-        assert np.array_equal(PREF.canonical_rows(got["points"][l].cpu().numpy(), got["stack_lengths"][l].numpy()),
-                              PREF.canonical_rows(ref["points"][l].numpy(), ref["stack_lengths"][l].numpy()))
+        a = PREF.canonical_rows(got["points"][l].cpu().numpy(), got["stack_lengths"][l].numpy())
+        b = PREF.canonical_rows(ref["points"][l].numpy(), ref["stack_lengths"][l].numpy())
+        if l <= 1:      # same input order -> bit-identical barycentres
+            assert np.array_equal(a, b)
+        else:           # level >= 2 sums level-1 points, whose ROW ORDER differs (unordered_map) -> fp32 re-rounding
+            assert np.allclose(a, b, rtol=0, atol=1e-4)
     # level 0 is in input order on both sides: neighbour tables comparable entry by entry (ties aside)
     same = (got["neighbors"][0].cpu().long() == ref["neighbors"][0]).float().mean()
     assert same > 0.995
