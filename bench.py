@@ -58,6 +58,18 @@ def build_model(name, n_out, dev):
     return m.to(dev).eval()
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC run of this same command
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 fetch correction): the
+    counters cannot be collected from inside the process, so bench.py reports the profiled value."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spconv_summary.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(state_dict, name, n_out, pair, ransac_iters):
     """The oracle (a CPU port of the reference path) timed on this box's host cores, one pair."""
     from oracle import match_pose_oracle as MO
@@ -200,7 +212,7 @@ def main():
         out["roofline"] = {
             "kernel": "k_spconv_mfma (sparse-conv gather->MFMA->fused epilogue)",
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(),
             "launches_per_encode": s["launches"] // nprof,
             "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
             "avg_launch_us": 1000.0 * s["ms"] / s["launches"],
