@@ -303,21 +303,29 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs(
     decode(d);
     return true;
   };
+  // hand strength-reduced addressing: one 64-bit lane base per step, scalar strides, immediate offsets
+  // (letting the compiler expand the full index expression cost ~150 VALU incl. quarter-rate v_mul_lo
+  // per step and made the loop issue-bound)
+  const int lane_w_off = (q * cout + r16) * 4;           // floats, lane-constant
+  const int64_t wstride = (int64_t)16 * cout;            // floats between consecutive j (4 cin groups)
   auto load = [&](const Desc& d, f32x4 (&bw)[CB][NJ], f32x4 (&aw)[NJ]) {
+    const int64_t wsc = ((int64_t)(d.k * cinG + d.chunk * (CK / 4)) * cout + col0) * 4;   // scalar part
+    const float* wb = wp + wsc + lane_w_off;
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int j = 0; j < NJ; ++j) {
+      const float* wj = wb + j * wstride;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int g = d.chunk * (CK / 4) + j * 4 + q;
-        bw[cb][j] = *reinterpret_cast<const f32x4*>(
-            wp + (((int64_t)d.k * cinG + g) * cout + col0 + cb * 16 + r16) * 4);
+      for (int cb = 0; cb < CB; ++cb) {
+        bw[cb][j] = *reinterpret_cast<const f32x4*>(wj + cb * 64);
       }
+    }
     // padded pairs (p >= cnt) gather pair 0's row: their columns of D^T are never written back
     const int p = d.g0 + r16;
     const int idx = s_in[d.k * TM + (p < d.cnt ? p : 0)];
+    const float* ab = in + (int64_t)idx * ldi + (d.chunk * CK + q * 4);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      aw[j] = *reinterpret_cast<const f32x4*>(in + (int64_t)idx * ldi + d.chunk * CK + j * 16 + q * 4);
+      aw[j] = *reinterpret_cast<const f32x4*>(ab + j * 16);
   };
   auto compute = [&](const Desc& d, const f32x4 (&bw)[CB][NJ], const f32x4 (&aw)[NJ]) {
     // D^T = W^T . A^T : lane (r16 = pair, q) ends up with 4 consecutive output channels of one pair
