@@ -270,13 +270,14 @@ class _ConvBase(nn.Module):
             raise AprHipError("transposed convolution needs the encoder's coordinate map of that stride")
         return cm.kernel_map(ts, ts_out, self.kernel_size, self.stride != 1), ts_out
 
-    def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None):
-        """Raw fused launch on feature rows (used by the fused encoder plan)."""
+    def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None, batch=None):
+        """Raw fused launch on feature rows (used by the fused encoder plan); `batch` defers the launch."""
         if shift is None and self.bias is not None:
             shift = self.bias.view(-1)
-        return ops.spconv(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
-                          self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
-                          relu=relu, out=out, n_out=n_out)
+        fn = ops.spconv if batch is None else batch.add
+        return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
+                  self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
+                  relu=relu, out=out, n_out=n_out)
 
     def forward(self, x: SparseTensor):
         _no_grad_guard(self)

@@ -21,6 +21,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libapr_hip.so")
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _f64, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
+class SpconvDesc(C.Structure):
+    """struct apr_spconv_desc (include/apr_hip.h)."""
+    _fields_ = [("inp", C.c_void_p), ("ldi", C.c_int64), ("nbr", C.c_void_p), ("n_out", C.c_int64),
+                ("K", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32),
+                ("w_packed", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
 PROTOTYPES = {
     "apr_last_error": (C.c_char_p, []),
@@ -34,6 +42,7 @@ PROTOTYPES = {
     "apr_spconv_packed_size": (_i64, [_i32, _i32, _i32]),
     "apr_spconv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "apr_spconv_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "apr_spconv_fwd_batch": (C.c_int, [_p, _i32, _p]),
     "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     "apr_bn_stats_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _p]),

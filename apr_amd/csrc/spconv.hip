@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256) void k_spconv_mfma(
 constexpr int kKMax = 27;
 
 
-template <int TM, int CN, int CK>
-__global__ __launch_bounds__(256, 2) void k_spconv_pairs(
+template <int TM, int CN, int CK, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void k_spconv_pairs(
     const float* __restrict__ in, int64_t ldi, const int* __restrict__ nbr, int n_out, int K,
     int cin, int cout, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ residual, int64_t ldr, int relu,
@@ -214,9 +214,10 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs(
   constexpr int CB = CN / 16;   // 16-col blocks per wave item
   constexpr int NJ = CK / 16;   // 16-wide k groups per chunk
   constexpr int LDO = CN + 4;   // accumulator row stride (floats), 16-B aligned rows
-  static_assert(TM * kKMax <= 4 * TM * LDO, "nbr staging must fit in the accumulator region");
+  constexpr int NT = 64 * NW;   // threads per workgroup (NW waves, each with a private accumulator tile)
+  static_assert(TM * kKMax <= NW * TM * LDO, "nbr staging must fit in the accumulator region");
 
-  __shared__ __attribute__((aligned(16))) float s_acc[4 * TM * LDO];
+  __shared__ __attribute__((aligned(16))) float s_acc[NW * TM * LDO];
   __shared__ int s_in[kKMax * TM];
   __shared__ __attribute__((aligned(4))) unsigned char s_row[kKMax * TM];
   __shared__ int s_cnt[32];
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs(
 
   // 1. stage this tile's slice of the neighbour table (coalesced) in the accumulator region
   int* s_stage = reinterpret_cast<int*>(s_acc);
-  for (int t = tid; t < TM * K; t += 256) {
+  for (int t = tid; t < TM * K; t += NT) {
     int r = t / K;
     int row = row0 + r;
     int v = -1;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs(
   }
   __syncthreads();
   // 2. per-offset compaction of (input row, local output row) pairs: ballot + popcount
-  for (int k = wave; k < K; k += 4) {
+  for (int k = wave; k < K; k += NW) {
     int cnt = 0;
 #pragma unroll
     for (int base = 0; base < TM; base += 64) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs(
     if (c > 0) s_act[__popcll(m & ((1ull << lane) - 1ull))] = lane;
     if (lane == 0) s_nact = __popcll(m);
   }
-  for (int t = tid; t < 4 * TM * LDO / 4; t += 256)
+  for (int t = tid; t < NW * TM * LDO / 4; t += NT)
     reinterpret_cast<f32x4*>(s_acc)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs(
       d.g0 += 16;
       return true;
     }
-    if (d.item + 4 >= nitems) return false;
-    d.item += 4;
+    if (d.item + NW >= nitems) return false;
+    d.item += NW;
     d.g0 = 0;
     decode(d);
     return true;
@@ -373,15 +374,14 @@ __global__ __launch_bounds__(256, 2) void k_spconv_pairs(
   __syncthreads();
 
   // 5. epilogue: fixed-order sum of the 4 private tiles, fused affine/residual/ReLU, 16-B row stores
-  for (int e = tid; e < TM * (CN / 4); e += 256) {
+  for (int e = tid; e < TM * (CN / 4); e += NT) {
     const int r = e / (CN / 4), c4 = e - r * (CN / 4);
     const int row = row0 + r;
     if (row >= n_out) continue;
     const int col = col0 + c4 * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(&s_acc[(0 * TM + r) * LDO + c4 * 4]);
-    v += *reinterpret_cast<const f32x4*>(&s_acc[(1 * TM + r) * LDO + c4 * 4]);
-    v += *reinterpret_cast<const f32x4*>(&s_acc[(2 * TM + r) * LDO + c4 * 4]);
-    v += *reinterpret_cast<const f32x4*>(&s_acc[(3 * TM + r) * LDO + c4 * 4]);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(&s_acc[(w * TM + r) * LDO + c4 * 4]);
     if (scale) v *= *reinterpret_cast<const f32x4*>(scale + col);
     if (shift) v += *reinterpret_cast<const f32x4*>(shift + col);
     if (residual) v += *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + col);
@@ -492,13 +492,13 @@ int launch_mfma(const float* in, int64_t ldi, const int* nbr, int64_t n_out, int
   return APR_OK;
 }
 
-template <int TM, int CN, int CK>
+template <int TM, int CN, int CK, int NW>
 int launch_pairs(const float* in, int64_t ldi, const int* nbr, int64_t n_out, int K, int cin,
                  int cout, const float* wp, const float* scale, const float* shift,
                  const float* residual, int64_t ldr, int relu, float* out, int64_t ldo,
                  hipStream_t st) {
   int64_t tiles = cdiv64(n_out, TM) * (cout / CN);
-  hipLaunchKernelGGL((k_spconv_pairs<TM, CN, CK>), dim3((unsigned)tiles), dim3(256), 0, st, in, ldi,
+  hipLaunchKernelGGL((k_spconv_pairs<TM, CN, CK, NW>), dim3((unsigned)tiles), dim3(64 * NW), 0, st, in, ldi,
                      nbr, (int)n_out, K, cin, cout, wp, scale, shift, residual, ldr, relu, out, ldo);
   APR_LAUNCH_CHECK();
   return APR_OK;
@@ -547,9 +547,13 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
                       (((uintptr_t)out) & 15) == 0 &&
                       (!residual || ((ldr % 4) == 0 && (((uintptr_t)residual) & 15) == 0));
   if (s_impl == 2 && use_mfma(K, cin, cout) && K <= kKMax && vec_ok) {
-#define APR_PAIRS(TM_, CN_, CK_)                                                                   \
-  return launch_pairs<TM_, CN_, CK_>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift,    \
-                                     residual, ldr, relu, out, ldo, st)
+#define APR_PAIRS(TM_, CN_, CK_)                                                                      \
+  return launch_pairs<TM_, CN_, CK_, 4>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift,    \
+                                        residual, ldr, relu, out, ldo, st)
+    static const int s_nw = env_int("APR_SPCONV_NW", 4);
+    if (s_nw == 8 && cout % 64 == 0)   // 8-wave tiles: 32-row tile, 32-channel pieces (<= 128 VGPRs, 4 waves/SIMD)
+      return launch_pairs<32, 64, 32, 8>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift, residual, ldr,
+                                         relu, out, ldo, st);
     static const int s_ck = env_int("APR_SPCONV_CK", 0);
     const bool cn64 = (cout % 64 == 0), ck64 = (cin % 64 == 0) && s_ck != 32;
     // 64-row tiles halve the weight re-reads; use them once there are enough tiles to fill 256 CUs
@@ -614,5 +618,15 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
   hipLaunchKernelGGL(k_spconv_generic, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, in, ldi, nbr,
                      n_out, K, cin, cout, w_packed, scale, shift, residual, ldr, relu, out, ldo);
   APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_spconv_fwd_batch(const apr_spconv_desc* d, int32_t n, void* stream) {
+  APR_CHECK_ARG(n >= 0 && (d != nullptr || n == 0), "apr_spconv_fwd_batch: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    int rc = apr_spconv_fwd(d[i].in, d[i].ldi, d[i].nbr, d[i].n_out, d[i].K, d[i].cin, d[i].cout, d[i].w_packed,
+                            d[i].scale, d[i].shift, d[i].residual, d[i].ldr, d[i].relu, d[i].out, d[i].ldo, stream);
+    if (rc != APR_OK) return rc;
+  }
   return APR_OK;
 }

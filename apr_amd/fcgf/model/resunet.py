@@ -129,10 +129,12 @@ class ResUNet2(ME.MinkowskiNetwork):
         cat1, cat2, cat3 = buf(N1, TR[2] + CH[1]), buf(N2, TR[3] + CH[2]), buf(N3, TR[4] + CH[3])
         s1, s2, s4 = cat1[:, TR[2]:], cat2[:, TR[3]:], cat3[:, TR[4]:]
 
+        batch = ops.SpconvBatch()   # the 23 conv launches leave through ONE library call
+
         def stage(conv, norm, feats, nbr, n_out, blk, nbr_blk, out):
             sc, sh = norm.folded()
-            a = conv.run(feats, nbr, n_out, scale=sc, shift=sh)
-            return blk.fused_eval(a, nbr_blk, out)
+            a = conv.run(feats, nbr, n_out, scale=sc, shift=sh, batch=batch)
+            return blk.fused_eval(a, nbr_blk, out, batch=batch)
 
         m11 = cm.kernel_map(1, 1, 3)
         m22 = cm.kernel_map(2, 2, 3)
@@ -148,8 +150,9 @@ class ResUNet2(ME.MinkowskiNetwork):
               cat2[:, :TR[3]])
         stage(self.conv2_tr, self.norm2_tr, cat2, cm.kernel_map(2, 1, 3, True), N1, self.block2_tr, m11,
               cat1[:, :TR[2]])
-        h = self.conv1_tr.run(cat1, None, N1, relu=True)
-        out = self.final.run(h, None, N1)
+        h = self.conv1_tr.run(cat1, None, N1, relu=True, batch=batch)
+        out = self.final.run(h, None, N1, batch=batch)
+        batch.launch()
         if self.normalize_feature:
             out = ops.l2_normalize(out, out=out)
         return ME.SparseTensor(out, coordinate_map_key=CoordinateMapKey(1), coordinate_manager=cm)

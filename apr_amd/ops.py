@@ -194,6 +194,47 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
     return out
 
 
+class SpconvBatch:
+    """Collects sparse-conv launches and enqueues them with ONE library call (apr_spconv_fwd_batch)."""
+
+    def __init__(self):
+        self.descs = []
+        self.keep = []      # tensors referenced by raw pointers stay alive until the launch call returns
+
+    def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None):
+        if PROFILE is not None:     # per-launch timing requested: fall back to immediate launches
+            return spconv(x, nbr, K, cin, cout, wp, scale, shift, residual, relu, out, n_out)
+        x, ldi = _rows(x, "spconv.x")
+        if nbr is not None:
+            n_out = nbr.shape[0]
+        elif n_out is None:
+            n_out = x.shape[0]
+        if out is None:
+            out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        out, ldo = _rows(out, "spconv.out")
+        ldr = 0
+        if residual is not None:
+            residual, ldr = _rows(residual, "spconv.residual")
+        d = _lib.SpconvDesc()
+        d.inp, d.ldi, d.nbr, d.n_out = x.data_ptr(), ldi, (nbr.data_ptr() if nbr is not None else None), n_out
+        d.K, d.cin, d.cout, d.relu = K, cin, cout, int(bool(relu))
+        d.w_packed = wp.data_ptr()
+        d.scale = scale.data_ptr() if scale is not None else None
+        d.shift = shift.data_ptr() if shift is not None else None
+        d.residual = residual.data_ptr() if residual is not None else None
+        d.ldr, d.out, d.ldo = ldr, out.data_ptr(), ldo
+        self.descs.append(d)
+        self.keep += [x, nbr, wp, scale, shift, residual, out]
+        return out
+
+    def launch(self):
+        if not self.descs:
+            return
+        arr = (_lib.SpconvDesc * len(self.descs))(*self.descs)
+        check(_lib_().apr_spconv_fwd_batch(arr, len(self.descs), stream()))
+        self.descs, self.keep = [], []
+
+
 # ----------------------------------------------------------------------------
 # normalisation / elementwise
 # ----------------------------------------------------------------------------

@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--n-out", type=int, default=32)
     ap.add_argument("--ransac-iters", type=int, default=4000000)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs cycled through")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="pairs in flight per GPU: each on its own HIP stream + host thread (a 28 k-voxel pair "
+                         "cannot fill 256 CUs alone, so independent pairs overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -109,12 +112,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal switches (1-GPU box): APR_BENCH_BACKEND=gloo + APR_BENCH_SINGLE_DEVICE=1 run N ranks on cuda:0
+    backend = os.environ.get("APR_BENCH_BACKEND", "nccl")
+    if os.environ.get("APR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from apr_amd import ops, shard, synth
     from apr_amd.fcgf.pipeline import PairRegistration
@@ -152,31 +162,52 @@ def main():
         a, b = pairs[i % len(pairs)]
         return pipe(a, b, seed=i)
 
-    for i in range(args.warmup):
+    # S independent pairs in flight: worker w owns HIP stream w and runs steps w, w+S, w+2S, ...
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    results = {}
+
+    def worker(w, first, last):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[w]):
+            for i in range(first + w, last, nstreams):
+                results[i] = step(i)
+            streams[w].synchronize()
+
+    def run_steps(first, last):
+        if nstreams == 1:
+            worker(0, first, last)
+            return
+        import threading
+        ts = [threading.Thread(target=worker, args=(w, first, last)) for w in range(nstreams)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+
+    for i in range(min(args.warmup, npool)):     # lazily built caches (packed weights, folded BN): one thread
         step(i)
+    torch.cuda.synchronize()
+    run_steps(min(args.warmup, npool), args.warmup)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
-    marks = []
-    for i in range(args.steps):
-        T, info = step(i)          # ends with the RANSAC result copy: each step is synchronous
-        marks.append(time.perf_counter())
+    run_steps(args.warmup, args.warmup + args.steps)     # EXACTLY `steps` pairs, `streams` in flight
+    T, info = results[args.warmup + args.steps - 1]
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dev)   # RCCL all-reduce(MAX) of one double
+    elapsed = shard.max_over_ranks(elapsed, dev if backend == "nccl" else torch.device("cpu"))   # all-reduce(MAX)
 
     def log(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    log(f"timed loop: {args.steps} steps in {elapsed:.3f}s; per-step ms: "
-        + " ".join(f"{1000 * (b - a):.2f}" for a, b in zip([t0] + marks[:-1], marks)))
+    log(f"timed loop: {args.steps} steps in {elapsed:.3f}s with {nstreams} stream(s)")
     out = {
         "metric": "point-cloud pairs/sec (120k-pt KITTI frame, FCGF encode+match+SVD)",
         "value": world * args.steps / elapsed,
@@ -193,7 +224,7 @@ def main():
         "config": {"workload": "FCGF_APR encode+match+SVD, one 120k-point KITTI-shaped pair per step, voxel_size=0.3",
                    "encoder": args.model, "feature_dim": args.n_out, "points_per_frame": int(n_pts),
                    "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
-                   "pairs_per_step": 1, "sharding": f"{world} ranks x independent pairs"},
+                   "pairs_per_step": 1, "streams_per_gpu": nstreams, "sharding": f"{world} ranks x independent pairs"},
     }
 
     if rank == 0 and not args.no_roofline:

@@ -115,6 +115,18 @@ int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_o
                    const float* residual, int64_t ldr, int32_t relu,
                    float* out, int64_t ldo, void* stream);
 
+/* One launch description of apr_spconv_fwd; apr_spconv_fwd_batch enqueues n of them back to back
+ * from a single call (the 23 fused conv launches of one ResUNet encode), so a host binding pays
+ * one FFI transition instead of 23 and can overlap several encodes from different host threads. */
+typedef struct apr_spconv_desc {
+  const float* in; int64_t ldi; const int32_t* nbr; int64_t n_out;
+  int32_t K, cin, cout, relu;
+  const float* w_packed; const float* scale; const float* shift;
+  const float* residual; int64_t ldr;
+  float* out; int64_t ldo;
+} apr_spconv_desc;
+int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* stream);
+
 /* ------------------------------------------------------------------------
  * Normalisation / elementwise on feature rows [n, c]
  * ---------------------------------------------------------------------- */
