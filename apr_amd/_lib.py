@@ -44,6 +44,7 @@ PROTOTYPES = {
     "apr_spconv_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_spconv_fwd_batch": (C.c_int, [_p, _i32, _p]),
     "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "apr_norm_params": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _p, _p, _sz, _p]),
     "apr_bn_stats_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _p]),
     "apr_l2_normalize": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),

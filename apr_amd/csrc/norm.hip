@@ -35,7 +35,8 @@ __global__ void k_bn_partial(const float* __restrict__ x, int64_t ld, int64_t n,
 }
 
 __global__ void k_bn_finish(const double* __restrict__ partial, int nblk, int64_t n, int c,
-                            float* __restrict__ mean, float* __restrict__ var) {
+                            float* __restrict__ mean, float* __restrict__ var, float eps,
+                            float* __restrict__ scale, float* __restrict__ shift) {
   int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= c) return;
   double s = 0.0, s2 = 0.0;
@@ -45,8 +46,14 @@ __global__ void k_bn_finish(const double* __restrict__ partial, int nblk, int64_
   }
   double m = s / (double)n;
   double v = s2 / (double)n - m * m;
-  mean[col] = (float)m;
-  var[col] = (float)(v > 0.0 ? v : 0.0);
+  const float mf = (float)m, vf = (float)(v > 0.0 ? v : 0.0);
+  if (mean) mean[col] = mf;
+  if (var) var[col] = vf;
+  if (scale) {   // no-affine normalisation parameters: y = x * scale + shift
+    const float sc = 1.0f / sqrtf(vf + eps);
+    scale[col] = sc;
+    shift[col] = -mf * sc;
+  }
 }
 
 __global__ void k_affine_act(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
@@ -98,7 +105,20 @@ APR_API int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c, float
   hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, n, c,
                      (double*)scratch);
   hipLaunchKernelGGL(k_bn_finish, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     (const double*)scratch, nblk, n, c, mean, var);
+                     (const double*)scratch, nblk, n, c, mean, var, 0.f, (float*)nullptr, (float*)nullptr);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, float eps, float* scale, float* shift,
+                            void* scratch, size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(n > 0 && c > 0 && ld >= c && eps >= 0.f, "apr_norm_params: bad arguments");
+  APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_norm_params: scratch too small");
+  const int nblk = (int)cdiv64(n, kRowsPerBlock);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, n, c,
+                     (double*)scratch);
+  hipLaunchKernelGGL(k_bn_finish, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const double*)scratch, nblk, n, c, (float*)nullptr, (float*)nullptr, eps, scale, shift);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

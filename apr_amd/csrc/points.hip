@@ -131,42 +131,63 @@ __global__ void k_fill(const int* __restrict__ cell, int64_t n, const int* __res
   sorted[start[id] + atomicAdd(&cursor[id], 1)] = (int)i;
 }
 
-// one thread per cell: order its points by input index, sum sequentially in fp32, scale by
+// one WAVE per cell: rank-sort the cell's point indices in LDS (cells of a raw scan near the sensor hold
+// hundreds of points, a per-thread insertion sort made this kernel 8 ms), then lane 0 sums them
+// sequentially in fp32 in index order -- the reference's `point += p` order -- and scales by
 // (float)(1.0 / count)  (grid_subsampling.cpp:60-89).  Also counts cells per cloud.
-__global__ void k_barycentre(const float* __restrict__ pts, const int4* __restrict__ cell_coords,
-                             const int* __restrict__ n_cells_dev, const int* __restrict__ start,
-                             int* __restrict__ sorted, const float* __restrict__ feats, int fdim,
-                             float* __restrict__ out_pts, float* __restrict__ out_feats,
-                             int* __restrict__ out_len) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kCellCap = 1024;
+__global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pts, const int4* __restrict__ cell_coords,
+                                                    const int* __restrict__ n_cells_dev, const int* __restrict__ start,
+                                                    int* __restrict__ sorted, const float* __restrict__ feats, int fdim,
+                                                    float* __restrict__ out_pts, float* __restrict__ out_feats,
+                                                    int* __restrict__ out_len) {
+  __shared__ int s_raw[4][kCellCap];
+  __shared__ int s_ord[4][kCellCap];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + wave;
   if (c >= *n_cells_dev) return;
   const int lo = start[c], hi = start[c + 1];
-  for (int a = lo + 1; a < hi; ++a) {  // insertion sort by point index (cells hold a handful of points)
-    int v = sorted[a], p = a - 1;
-    while (p >= lo && sorted[p] > v) {
-      sorted[p + 1] = sorted[p];
-      --p;
+  const int m = hi - lo;
+  const int* ord;
+  if (m <= kCellCap) {
+    for (int e = lane; e < m; e += 64) s_raw[wave][e] = sorted[lo + e];
+    for (int e = lane; e < m; e += 64) {
+      const int v = s_raw[wave][e];
+      int rank = 0;
+      for (int o = 0; o < m; ++o) rank += s_raw[wave][o] < v ? 1 : 0;
+      s_ord[wave][rank] = v;
     }
-    sorted[p + 1] = v;
+    ord = s_ord[wave];
+  } else {   // very dense cell: in-place insertion sort by one lane (rare)
+    if (lane == 0)
+      for (int a = lo + 1; a < hi; ++a) {
+        int v = sorted[a], p = a - 1;
+        while (p >= lo && sorted[p] > v) {
+          sorted[p + 1] = sorted[p];
+          --p;
+        }
+        sorted[p + 1] = v;
+      }
+    ord = sorted + lo;
   }
+  if (lane != 0) return;
   float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int a = lo; a < hi; ++a) {
-    int64_t i = sorted[a];
+  for (int a = 0; a < m; ++a) {
+    const int64_t i = ord[a];
     sx = __fadd_rn(sx, pts[3 * i]);
     sy = __fadd_rn(sy, pts[3 * i + 1]);
     sz = __fadd_rn(sz, pts[3 * i + 2]);
   }
-  const int count = hi - lo;
-  const float inv = (float)(1.0 / (double)count);
+  const float inv = (float)(1.0 / (double)m);
   out_pts[3 * (int64_t)c] = __fmul_rn(sx, inv);
   out_pts[3 * (int64_t)c + 1] = __fmul_rn(sy, inv);
   out_pts[3 * (int64_t)c + 2] = __fmul_rn(sz, inv);
   if (feats) {
-    const float fc = (float)count;
+    const float fc = (float)m;
     for (int f = 0; f < fdim; ++f) {
-      float s = 0.f;
-      for (int a = lo; a < hi; ++a) s = __fadd_rn(s, feats[(int64_t)sorted[a] * fdim + f]);
-      out_feats[(int64_t)c * fdim + f] = __fdiv_rn(s, fc);
+      float sacc = 0.f;
+      for (int a = 0; a < m; ++a) sacc = __fadd_rn(sacc, feats[(int64_t)ord[a] * fdim + f]);
+      out_feats[(int64_t)c * fdim + f] = __fdiv_rn(sacc, fc);
     }
   }
   atomicAdd(&out_len[cell_coords[c].x], 1);
@@ -424,7 +445,7 @@ APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengt
   if (rc != APR_OK) return rc;
   int* out_len_dev = w.cursor;  // cursor is dead after k_fill; reuse its first nb ints
   APR_HIP(hipMemsetAsync(out_len_dev, 0, kMaxBatch * 4, st));
-  hipLaunchKernelGGL(k_barycentre, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, st, pts, w.cell_coords,
+  hipLaunchKernelGGL(k_barycentre, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, pts, w.cell_coords,
                      w.n_cells, w.start, w.sorted, feats, fdim, out_pts, out_feats, out_len_dev);
   APR_LAUNCH_CHECK();
   int status = 0;

@@ -441,22 +441,24 @@ __global__ void k_rank_by_iteration(const Hyp* __restrict__ hyps, const int* __r
   selected[h] = rank < max_validation ? 1 : 0;
 }
 
-// One wave per selected survivor: every transformed source point looks for its nearest target point
-// within max_dist in a uniform grid (cell = max_dist): inlier count + sum of squared NN distances
+// One WORKGROUP per selected survivor: every transformed source point looks for its nearest target point
+// within max_dist in a uniform grid whose cell edge is 2*max_dist, so the 2x2x2 block of cells around
+// (p - max_dist) covers the search ball with 8 hash probes: inlier count + sum of squared NN distances
 // (GetRegistrationResultAndCorrespondences of open3d <= 0.11).
 __global__ __launch_bounds__(256) void k_score_geometric(const float* __restrict__ xyz0, int64_t n0,
                                                          const float* __restrict__ xyz1, AprSearchGrid g,
                                                          double max_dist, Hyp* __restrict__ hyps,
                                                          const int* __restrict__ n_valid, int cap,
                                                          const int* __restrict__ selected) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  __shared__ int s_cnt[4];
+  __shared__ double s_e2[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = min(*n_valid, cap);
   const float md2 = (float)(max_dist * max_dist);
-  for (int h = wave; h < nv; h += nwaves) {
+  const float inv_cell = 1.0f / g.cell;
+  for (int h = blockIdx.x; h < nv; h += gridDim.x) {
     if (!selected[h]) {
-      if (lane == 0) hyps[h].inliers = -1;
+      if (threadIdx.x == 0) hyps[h].inliers = -1;
       continue;
     }
     double T[12];
@@ -464,33 +466,32 @@ __global__ __launch_bounds__(256) void k_score_geometric(const float* __restrict
     for (int k = 0; k < 12; ++k) T[k] = hyps[h].T[k];
     int cnt = 0;
     double e2 = 0.0;
-    for (int64_t i = lane; i < n0; i += 64) {
+    for (int64_t i = threadIdx.x; i < n0; i += 256) {
       const double sx = xyz0[3 * i], sy = xyz0[3 * i + 1], sz = xyz0[3 * i + 2];
       const float px = (float)(T[0] * sx + T[1] * sy + T[2] * sz + T[3]);
       const float py = (float)(T[4] * sx + T[5] * sy + T[6] * sz + T[7]);
       const float pz = (float)(T[8] * sx + T[9] * sy + T[10] * sz + T[11]);
-      const int cx = (int)floorf((px - g.mins[0]) / g.cell), cy = (int)floorf((py - g.mins[1]) / g.cell),
-                cz = (int)floorf((pz - g.mins[2]) / g.cell);
+      const int bx = (int)floorf((px - g.mins[0]) * inv_cell - 0.5f), by = (int)floorf((py - g.mins[1]) * inv_cell - 0.5f),
+                bz = (int)floorf((pz - g.mins[2]) * inv_cell - 0.5f);
       float best = md2;
       bool found = false;
-      for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-          for (int dx = -1; dx <= 1; ++dx) {
-            const int x = cx + dx, y = cy + dy, z = cz + dz;
-            if (!apr_key_in_range(0, x, y, z)) continue;
-            const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, x, y, z));
-            if (id < 0) continue;
-            for (int a = g.start[id]; a < g.start[id + 1]; ++a) {
-              const int j = g.sorted[a];
-              const float ex = px - xyz1[3 * (int64_t)j], ey = py - xyz1[3 * (int64_t)j + 1],
-                          ez = pz - xyz1[3 * (int64_t)j + 2];
-              const float d2 = ex * ex + ey * ey + ez * ez;
-              if (d2 < best) {
-                best = d2;
-                found = true;
-              }
-            }
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int x = bx + (o & 1), y = by + ((o >> 1) & 1), z = bz + (o >> 2);
+        if (!apr_key_in_range(0, x, y, z)) continue;
+        const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, x, y, z));
+        if (id < 0) continue;
+        for (int a = g.start[id]; a < g.start[id + 1]; ++a) {
+          const int j = g.sorted[a];
+          const float ex = px - xyz1[3 * (int64_t)j], ey = py - xyz1[3 * (int64_t)j + 1],
+                      ez = pz - xyz1[3 * (int64_t)j + 2];
+          const float d2 = ex * ex + ey * ey + ez * ez;
+          if (d2 < best) {
+            best = d2;
+            found = true;
           }
+        }
+      }
       if (found) {
         ++cnt;
         e2 += (double)best;
@@ -500,9 +501,15 @@ __global__ __launch_bounds__(256) void k_score_geometric(const float* __restrict
       cnt += __shfl_xor(cnt, d);
       e2 += __shfl_xor(e2, d);
     }
+    __syncthreads();
     if (lane == 0) {
-      hyps[h].inliers = cnt;
-      hyps[h].err2 = e2;
+      s_cnt[wave] = cnt;
+      s_e2[wave] = e2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      hyps[h].inliers = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      hyps[h].err2 = (s_e2[0] + s_e2[1]) + (s_e2[2] + s_e2[3]);
     }
   }
 }
@@ -542,7 +549,7 @@ APR_API int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float
   p = (char*)selected + (size_t)cap * 4;
   void* grid_scratch = (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
   AprSearchGrid g;
-  int rc = apr_internal_search_grid(xyz1, n1, (float)max_dist, grid_scratch, &g, st);
+  int rc = apr_internal_search_grid(xyz1, n1, (float)(2.0 * max_dist), grid_scratch, &g, st);
   if (rc != APR_OK) return rc;
   hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, best, total_valid);
   hipLaunchKernelGGL(k_gather_targets, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz1, n1,
@@ -552,7 +559,7 @@ APR_API int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float
                      max_dist, edge_ratio, 0ll, (long long)max_iter, seed, hyps, n_valid, (int)cap);
   hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, hyps, n_valid, (int)cap,
                      (int)(max_validation < (1ll << 30) ? max_validation : (1ll << 30)), selected);
-  hipLaunchKernelGGL(k_score_geometric, dim3(1024), dim3(256), 0, st, xyz0, n0, xyz1, g, max_dist, hyps, n_valid,
+  hipLaunchKernelGGL(k_score_geometric, dim3(2048), dim3(256), 0, st, xyz0, n0, xyz1, g, max_dist, hyps, n_valid,
                      (int)cap, selected);
   hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, hyps, n_valid, (int)cap, best, total_valid);
   APR_LAUNCH_CHECK();

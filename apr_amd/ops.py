@@ -251,6 +251,18 @@ def bn_stats(x):
     return mean, var
 
 
+def norm_params(x, eps):
+    """(scale, shift) of a no-affine per-channel normalisation over all rows (one fused stats pass)."""
+    x, ld = _rows(x, "norm_params.x")
+    n, c = x.shape
+    lib = _lib_()
+    ss = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    check(lib.apr_norm_params(ptr(x), ld, n, c, float(eps), ptr(ss[0]), ptr(ss[1]), ptr(scratch), sb, stream()))
+    return ss[0], ss[1]
+
+
 def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None, leaky=None):
     """y = act(x*scale + shift + residual); relu=True -> ReLU, leaky=slope -> LeakyReLU(slope)."""
     x, ldx = _rows(x, "affine_act.x")

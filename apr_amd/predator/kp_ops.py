@@ -16,15 +16,33 @@ def _i32(t, name):
 
 
 def linear(x, wp_info, shift=None, relu=False, out=None):
-    """x [N,cin] @ W (packed by `pack_linear`) (+ shift) -> [N,cout] on the sparse-conv GEMM path."""
-    wp, cin, cout = wp_info
-    return ops.spconv(x, None, 1, cin, cout, wp, shift=shift, relu=relu, out=out, n_out=x.shape[0])
+    """x [N,cin] @ W (packed by `pack_linear`) (+ shift) -> [N,cout] on the MFMA GEMM path.
+
+    Channel counts that are not multiples of 32 (the decoder's 1282->129, 641->64, 320->34, the 256->1 score
+    head) run zero-padded: W is padded once at pack time, x / shift per call; the result is a column slice.
+    """
+    wp, cin, cout, cin_p, cout_p = wp_info
+    if cin_p != cin or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = torch.nn.functional.pad(x, (0, cin_p - cin))
+    if cout_p == cout:
+        return ops.spconv(x, None, 1, cin_p, cout_p, wp, shift=shift, relu=relu, out=out, n_out=x.shape[0])
+    if shift is not None:
+        shift = torch.nn.functional.pad(shift.view(-1), (0, cout_p - cout))
+    y = ops.spconv(x, None, 1, cin_p, cout_p, wp, shift=shift, relu=relu, n_out=x.shape[0])[:, :cout]
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def pack_linear(w_in_out):
-    """[cin, cout] weight -> (packed, cin, cout)."""
-    w = w_in_out.detach().to(torch.float32).contiguous()
-    return ops.pack_weights(w), w.shape[0], w.shape[1]
+    """[cin, cout] weight -> (packed, cin, cout, cin_padded, cout_padded)."""
+    w = w_in_out.detach().to(torch.float32)
+    cin, cout = w.shape
+    cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+    if (cin_p, cout_p) != (cin, cout):
+        w = torch.nn.functional.pad(w, (0, cout_p - cout, 0, cin_p - cin))
+    return ops.pack_weights(w.contiguous()), cin, cout, cin_p, cout_p
 
 
 def row_sums(x):
@@ -104,7 +122,5 @@ def score_head(x_col):
 
 def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=None):
     """Per-channel normalisation over all rows, no affine (InstanceNorm1d on [1,C,N]) + activation."""
-    mean, var = ops.bn_stats(x)
-    scale = torch.rsqrt(var + eps)
-    shift = -mean * scale
+    scale, shift = ops.norm_params(x, eps)
     return ops.affine_act(x, scale=scale, shift=shift, residual=residual, relu=relu, leaky=leaky, out=out)

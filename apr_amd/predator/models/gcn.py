@@ -52,9 +52,8 @@ class SelfAttention(nn.Module):
         n = feats.shape[0]
         e = kp_ops.edge_features(feats, knn)                   # [n*k, 2c]
         y = conv1x1(e, conv, cache)                            # [n*k, c']
-        mean, var = kp_ops.ops.bn_stats(y)                     # InstanceNorm2d: per channel over n*k
-        scale = torch.rsqrt(var + eps)
-        return kp_ops.group_max(y, n, knn.shape[1], scale, -mean * scale, 0.2)
+        scale, shift = kp_ops.ops.norm_params(y, eps)          # InstanceNorm2d: per channel over n*k
+        return kp_ops.group_max(y, n, knn.shape[1], scale, shift, 0.2)
 
     def forward(self, coords, features):
         """coords [N,3], features [N,C] -> [N,C]."""

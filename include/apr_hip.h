@@ -137,6 +137,12 @@ int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c,
                  float* mean, float* var, void* scratch, size_t scratch_bytes, void* stream);
 size_t apr_bn_stats_scratch_bytes(int64_t n, int32_t c);
 
+/* Per-channel normalisation parameters over all rows, no affine: scale = 1/sqrt(var + eps),
+ * shift = -mean*scale (InstanceNorm1d over the stacked points, Predator_APR/models/blocks.py:451-466;
+ * InstanceNorm2d of the edge convolutions, models/gcn.py:41-48).  Same scratch as apr_bn_stats. */
+int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, float eps, float* scale, float* shift,
+                    void* scratch, size_t scratch_bytes, void* stream);
+
 /* y = act(x * scale[c] + shift[c] (+ residual)); scale/shift/residual nullable.
  * relu: 0 none, 1 ReLU, 2 LeakyReLU(negative_slope) (Predator_APR/models/blocks.py:489,574). */
 int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c,

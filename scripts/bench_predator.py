@@ -1,0 +1,83 @@
+"""BASELINE config 3: Predator_APR KPConv encoder + overlap attention (+ score sampling + RANSAC) on one
+120 k-point KITTI-shaped pair, stage times on the GPU and (optionally) the CPU oracle beside it.
+
+    python scripts/bench_predator.py [--cpu] [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from apr_amd import synth
+from apr_amd.predator import point_ops
+from apr_amd.predator.configs.models import kitti_config
+from apr_amd.predator.datasets.dataloader import collate_fn_descriptor
+from apr_amd.predator.lib import benchmark_utils as BU
+from apr_amd.predator.models.architectures import KPFCNN
+
+LIMITS = [58, 59, 58, 57]     # 80-th percentile caps measured on this generator
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (needs oracle/_ref)")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    np.random.seed(0); torch.manual_seed(0)
+    cfg = kitti_config()
+    model = KPFCNN(cfg).to(dev).eval()
+    a, b, T = synth.make_pair(0)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(); return time.perf_counter()
+
+    rows = []
+    for rep in range(args.reps + 1):
+        t0 = sync()
+        pts, lens = point_ops.grid_subsample(torch.cat([ta, tb]), np.array([len(a), len(b)], np.int32), 0.3)
+        src, tgt = pts[:lens[0]], pts[lens[0]:]
+        t1 = sync()
+        ones = lambda p: torch.ones((len(p), 1), device=dev)
+        batch = collate_fn_descriptor([(src, tgt, ones(src), ones(tgt))], cfg, LIMITS)
+        t2 = sync()
+        feats, ov, sal = model(batch)
+        t3 = sync()
+        n0 = int(lens[0])
+        np.random.seed(rep)
+        s_p, s_f, _ = BU.sample_by_score(src, feats[:n0], ov[:n0] * sal[:n0], 5000)
+        t_p, t_f, _ = BU.sample_by_score(tgt, feats[n0:], ov[n0:] * sal[n0:], 5000)
+        Tm, info = BU.ransac_pose_estimation(s_p, t_p, s_f, t_f, distance_threshold=0.3, ransac_n=4, seed=rep,
+                                             return_info=True)
+        t4 = sync()
+        if rep:   # first repetition = warm-up
+            rows.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3])
+    r = np.array(rows).mean(0) * 1e3
+    out = {"workload": "Predator_APR pair, 2 x ~118 k pts -> 0.3 m grid", "points_per_level": [len(p) for p in batch["points"]],
+           "neighbor_limits": LIMITS, "ms": {"grid_subsample_0.3": r[0], "collate(12 radius + 3 subsample)": r[1],
+                                             "KPFCNN forward": r[2], "sampling + RANSAC(50000,1000)": r[3]},
+           "pairs_per_s": 1e3 / r.sum()}
+    if args.cpu:
+        from oracle import kpfcnn_oracle as KO
+        from oracle import match_pose_oracle as MO
+        from oracle import predator_points_oracle as PREF
+        torch.set_num_threads(MO.host_threads())
+        t0 = time.perf_counter()
+        cp, cl = PREF.subsample_batch(np.concatenate([a, b]), np.array([len(a), len(b)], np.int32), sampleDl=0.3)
+        bo = KO.collate(cp[:cl[0]], cp[cl[0]:], cfg, LIMITS)
+        t1 = time.perf_counter()
+        KO.kpfcnn_forward({k: v.cpu() for k, v in model.state_dict().items()}, cfg, bo)
+        t2 = time.perf_counter()
+        out["cpu_oracle"] = {"threads": MO.host_threads(), "index_build_s (reference C++)": t1 - t0,
+                             "kpfcnn_forward_s": t2 - t1}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is git-ignored: (cross-)compile it on first use so a fresh checkout can run the suite
+    from apr_amd import build as _b
+    if _b.needs_build():
+        _b.build(verbose=False)
 
 
 @pytest.fixture(scope="session")
