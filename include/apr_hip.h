@@ -293,6 +293,26 @@ int apr_softmax_matvec(const float* a, const float* b, const float* w, int32_t n
 /* y[i] = clamp(sigmoid(x[i*ldx]), 0, 1), NaN/Inf -> 0  (architectures.py:131-134,203-207). */
 int apr_score_head(const float* x, int64_t ldx, int64_t n, float* y, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Adjacent components: APG aggregation and Chamfer 1-NN sums
+ * ---------------------------------------------------------------------- */
+
+/* out = pts @ R^T + t in fp32, T16_dev = row-major 4x4 on the device
+ * (apply_transform, FCGF_APR/lib/complement_data_loader.py:65-70). */
+int apr_transform_points(const float* pts, int64_t n, const float* T16_dev, float* out, void* stream);
+
+/* Keep the points with |p|^2 < max_i |key_i|^2, order preserved
+ * (crop of the aggregated complement frames, complement_data_loader.py:620-628).
+ * out f32[<=n,3]; *n_out_dev device counter. */
+size_t apr_crop_scratch_bytes(int64_t n);
+int apr_crop_to_radius(const float* key_pts, int64_t n_key, const float* pts, int64_t n, float* out,
+                       int32_t* n_out_dev, void* scratch, size_t scratch_bytes, void* stream);
+
+/* *out_dev (f64) = sum_i min_j |a_i - b_j|^2 -- one direction of chamferdist.ChamferDistance()(a, b) as used by
+ * chamfer_distance (FCGF_APR/lib/complement_trainer.py:188-196).  scratch >= 4*n bytes. */
+int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m, double* out_dev, void* scratch,
+                    size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""APG aggregation, GT correspondences, NPR MLP + Chamfer vs CPU restatements."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from apr_amd import synth
+from apr_amd.fcgf.lib import apg
+from oracle import me_oracle as OME
+
+pytestmark = pytest.mark.gpu
+
+
+def test_apg_aggregation_matches_numpy(dev):
+    rng = np.random.default_rng(0)
+    key = synth.make_small_frame(0)
+    frames, poses = [], []
+    for k in range(4):
+        f = synth.make_small_frame(10 + k)
+        a = np.deg2rad(rng.uniform(-10, 10))
+        M = np.eye(4); M[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+        M[:3, 3] = [6.0 * (k - 1.5), rng.uniform(-1, 1), 0.0]
+        frames.append(f); poses.append(M)
+    # numpy restatement of complement_data_loader.py:65-70, 576-579, 620-628, 671-674
+    moved = [f @ M.astype(np.float32)[:3, :3].T + M.astype(np.float32)[:3, 3] for f, M in zip(frames, poses)]
+    cat = np.concatenate(moved, 0)
+    lim = np.max((key ** 2).sum(-1))
+    ref = cat[np.where((cat ** 2).sum(-1) < lim)[0]]
+    _, sel_ref = OME.sparse_quantize(ref / np.float32(0.3), return_index=True)
+    nghb, sel = apg.aggregate_frames(key, frames, poses, 0.3)
+    got = nghb.cpu().numpy()
+    assert abs(len(got) - len(ref)) <= 3                      # fp32 rounding at the crop boundary
+    if len(got) == len(ref):
+        assert np.allclose(got, ref, atol=1e-4)
+        assert (np.isin(sel.cpu().numpy(), sel_ref).mean() > 0.999)
+
+
+def test_get_matching_indices_matches_bruteforce(dev):
+    a, b, T = synth.make_pair(2, n_beams=8, n_azimuth=400)
+    a, b = a[::2], b[::2]
+    pairs = apg.get_matching_indices(a, b, T, 0.45).cpu().numpy()
+    src = (a @ T[:3, :3].T.astype(np.float32) + T[:3, 3].astype(np.float32)).astype(np.float32)
+    d2 = ((src[:, None, :] - b[None]) ** 2).sum(-1)
+    ref = np.argwhere(d2 < 0.45 ** 2)
+    assert abs(len(pairs) - len(ref)) <= 4
+    assert len(set(map(tuple, pairs)) ^ set(map(tuple, ref))) <= 8
+    p1 = apg.get_matching_indices(a, b, T, 0.45, K=1).cpu().numpy()
+    assert len(np.unique(p1[:, 0])) == len(p1)                 # at most one (the nearest) match per source point
+
+
+def test_chamfer_matches_bruteforce(dev):
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-5, 5, (3000, 3)).astype(np.float32)
+    b = rng.uniform(-5, 5, (4500, 3)).astype(np.float32)
+    d2 = ((a[:, None].astype(np.float64) - b[None]) ** 2).sum(-1)
+    ref = d2.min(1).sum() / len(a) + d2.min(0).sum() / len(b)
+    got = float(apg.chamfer_distance(a, b))
+    assert abs(got - ref) < 1e-5 * ref
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_generative_mlp_matches_torch(dev, train):
+    torch.manual_seed(0)
+    m = apg.GenerativeMLP_98(in_channel=32, out_points=4)
+    ref = GenerativeMLPRef(32, 4)
+    ref.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+    m.load_state_dict(ref.state_dict())
+    m.train(train); ref.train(train)
+    x = torch.randn(2000, 32)
+    with torch.no_grad():
+        y_ref = ref(x)
+    y = m.to(dev)(x.to(dev))
+    assert torch.allclose(y.cpu(), y_ref, rtol=1e-4, atol=1e-5)
+    if train:
+        assert torch.allclose(m.mlp[2].running_mean.cpu(), ref.mlp[2].running_mean, atol=1e-5)
+
+
+class GenerativeMLPRef(torch.nn.Module):
+    """torch-CPU twin with the reference layout (FCGF_APR/model/mlp.py:6-37, GenerativeMLP_98)."""
+
+    def __init__(self, cin, out_points):
+        super().__init__()
+        nn = torch.nn
+        self.mlp = nn.Sequential(nn.Linear(cin, 512), nn.ReLU(), nn.BatchNorm1d(512, momentum=0.1),
+                                 nn.Linear(512, 256), nn.ReLU(), nn.BatchNorm1d(256, momentum=0.1),
+                                 nn.Linear(256, out_points * 3), nn.ReLU())
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+def test_npr_loss_matches_restatement(dev):
+    torch.manual_seed(1)
+    gen = apg.GenerativeMLP_98(in_channel=32, out_points=4).eval()
+    feats = torch.randn(1500, 32)
+    coords = torch.randint(-50, 50, (1500, 3))
+    nghb = torch.randn(6000, 3) * 8
+    with torch.no_grad():
+        g = gen.mlp(feats) * 0.3
+        reg = (g.reshape(-1, 3) ** 2).sum(-1).mean()
+        mod = (g + 0.3 * coords.float().repeat(1, 4)).reshape(-1, 3)
+        d2 = torch.cdist(mod.double(), nghb.double()) ** 2
+        ref = d2.min(1)[0].sum() / len(mod) + d2.min(0)[0].sum() / len(nghb) + reg * 0.01
+    got = apg.npr_reconstruction_loss(gen.to(dev), feats.to(dev), coords.to(dev), nghb.to(dev), 0.3, 4)
+    assert abs(float(got) - float(ref)) < 1e-4 * float(ref)
