@@ -46,6 +46,7 @@ class CoordinateManager:
     def __init__(self, coordinates: torch.Tensor):
         self.maps = {1: ops.build_map(coordinates)}
         self._kmaps = {}
+        self._plists = {}
         self.device = coordinates.device
 
     # -- coordinate maps -----------------------------------------------------
@@ -91,6 +92,23 @@ class CoordinateManager:
             nbr = ops.kernel_map(out_map, in_map, kernel_size, scale)
             self._kmaps[key] = nbr
         return nbr
+
+    def pair_list(self, ts_in, ts_out, kernel_size, transpose=False):
+        """Per-offset pair lists of kernel_map(...) for the weight-stationary conv path (cached per map)."""
+        key = (ts_in, ts_out, kernel_size, transpose)
+        pl = self._plists.get(key)
+        if pl is None:
+            nbr = self.kernel_map(ts_in, ts_out, kernel_size, transpose)
+            n_fine = self.size(min(ts_in, ts_out))
+            if ts_in != ts_out and kernel_size == 3 and max(ts_in, ts_out) == 2 * min(ts_in, ts_out):
+                # stride-2 maps: a fine voxel meets at most 2 coarse voxels per axis -> <= 8 pairs per fine row
+                # (LiDAR scans measure ~2.2)
+                p_max, p_est = 8 * n_fine, 9 * n_fine // 4
+            else:
+                p_max, p_est = None, 15 * nbr.shape[0] // 2      # same-level 3x3x3 maps measure ~7.5 per row
+            pl = ops.build_pairlist(nbr, p_max, p_est, lazy=True)
+            self._plists[key] = pl
+        return pl
 
 
 class SparseTensor:
@@ -270,14 +288,15 @@ class _ConvBase(nn.Module):
             raise AprHipError("transposed convolution needs the encoder's coordinate map of that stride")
         return cm.kernel_map(ts, ts_out, self.kernel_size, self.stride != 1), ts_out
 
-    def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None, batch=None):
+    def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None, batch=None,
+            plist=None):
         """Raw fused launch on feature rows (used by the fused encoder plan); `batch` defers the launch."""
         if shift is None and self.bias is not None:
             shift = self.bias.view(-1)
         fn = ops.spconv if batch is None else batch.add
         return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
                   self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
-                  relu=relu, out=out, n_out=n_out)
+                  relu=relu, out=out, n_out=n_out, plist=plist)
 
     def forward(self, x: SparseTensor):
         _no_grad_guard(self)

@@ -3,9 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/apr_hip.h"
+
+// tuning / A-B switches read once from the environment
+static inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 #define APR_API extern "C" __attribute__((visibility("default")))
 

@@ -6,12 +6,20 @@
 // distance checker = voxel_size, TransformationEstimationPointToPoint(False),
 // up to 4 000 000 iterations).  Here one thread owns one hypothesis: a
 // counter-based RNG picks its 4 correspondences (so the CPU oracle can replay the
-// exact stream), the cheap edge-length test runs first, survivors get a closed
-// form Kabsch (Horn quaternion, Jacobi eigen-solve of the 4x4 in fp64 registers),
-// the distance checker, and an append to the survivor list.  A persistent grid
-// of waves then scores each survivor against all correspondences (coalesced
-// 12-B point loads, fp64 transform, wave shuffle reduction), and a single
-// workgroup keeps the lexicographic best (inliers desc, rmse asc, iteration asc).
+// exact stream) and the cheap edge-length test runs first (k_sample_check; the
+// ~99.9 % rejected there never reach a square root: squared lengths are compared
+// with a 1e-12 guard band and only the band replays the oracle's sqrt form).
+// Survivors are COMPACTED (wave-aggregated append) so that the expensive part
+// runs on dense waves (k_fit_check): closed-form Kabsch (Horn quaternion, Jacobi
+// eigen-solve of the 4x4 in fp64 registers), the distance checker, and an append
+// to the hypothesis list.  A persistent grid of waves then scores each hypothesis
+// against all correspondences (32-B packed {source, target} records, fp64
+// transform, wave shuffle reduction), and a single workgroup keeps the
+// lexicographic best (inliers desc, rmse asc, iteration asc).
+//
+// sqrt(d2) < m is evaluated as d2 < T2 with T2 = the smallest double whose
+// correctly-rounded sqrt is >= m (found on the host): sqrt is monotone, so the two
+// predicates are identical for every d2, and no fp64 sqrt runs per point.
 #include "common.h"
 
 namespace {
@@ -133,85 +141,125 @@ __device__ inline void kabsch4(const double s[4][3], const double t[4][3], doubl
   }
 }
 
-// tgt[i] = xyz1[corr[i]] as a dense [n0,3] array so scoring streams coalesced
-__global__ void k_gather_targets(const float* __restrict__ xyz1, int64_t n1, const long long* __restrict__ corr,
-                                 int64_t n0, float* __restrict__ tgt) {
+// rec[2i] = (source_i, 0), rec[2i+1] = (target_i = xyz1[corr[i]], 0): one 32-B record per correspondence, so a
+// random sample costs two 16-B loads from one cache line instead of six scattered dwords
+__global__ void k_pack_pairs(const float* __restrict__ xyz0, const float* __restrict__ xyz1, int64_t n1,
+                             const long long* __restrict__ corr, int64_t n0, float4* __restrict__ rec) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n0) return;
   long long j = corr[i];
   if (j < 0 || j >= n1) j = 0;
-  tgt[3 * i + 0] = xyz1[3 * j + 0];
-  tgt[3 * i + 1] = xyz1[3 * j + 1];
-  tgt[3 * i + 2] = xyz1[3 * j + 2];
+  rec[2 * i] = make_float4(xyz0[3 * i], xyz0[3 * i + 1], xyz0[3 * i + 2], 0.f);
+  rec[2 * i + 1] = make_float4(xyz1[3 * j], xyz1[3 * j + 1], xyz1[3 * j + 2], 0.f);
 }
 
-__global__ void k_hypotheses(const float* __restrict__ xyz0, const float* __restrict__ tgt, uint32_t n0,
-                             double max_dist, double edge_ratio, long long it0, long long it1, uint64_t seed,
-                             Hyp* __restrict__ hyps, int* __restrict__ n_valid, int cap) {
-  long long it = it0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= it1) return;
-  double s[4][3], t[4][3];
+__device__ inline void load_samples(const float4* __restrict__ rec, uint64_t seed, long long it, uint32_t n0,
+                                    double s[4][3], double t[4][3]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    uint32_t i = sample_index(seed, (uint64_t)it, j, n0);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      s[j][d] = (double)xyz0[3 * (int64_t)i + d];
-      t[j][d] = (double)tgt[3 * (int64_t)i + d];
-    }
-  }
-  // CorrespondenceCheckerBasedOnEdgeLength
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = a + 1; b < 4; ++b) {
-      double ds = sqrt((s[a][0] - s[b][0]) * (s[a][0] - s[b][0]) + (s[a][1] - s[b][1]) * (s[a][1] - s[b][1]) +
-                       (s[a][2] - s[b][2]) * (s[a][2] - s[b][2]));
-      double dt = sqrt((t[a][0] - t[b][0]) * (t[a][0] - t[b][0]) + (t[a][1] - t[b][1]) * (t[a][1] - t[b][1]) +
-                       (t[a][2] - t[b][2]) * (t[a][2] - t[b][2]));
-      if (ds < dt * edge_ratio || dt < ds * edge_ratio) return;
-    }
-  double T[12];
-  kabsch4(s, t, T);
-  // CorrespondenceCheckerBasedOnDistance
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    double dx = T[0] * s[j][0] + T[1] * s[j][1] + T[2] * s[j][2] + T[3] - t[j][0];
-    double dy = T[4] * s[j][0] + T[5] * s[j][1] + T[6] * s[j][2] + T[7] - t[j][1];
-    double dz = T[8] * s[j][0] + T[9] * s[j][1] + T[10] * s[j][2] + T[11] - t[j][2];
-    if (sqrt(dx * dx + dy * dy + dz * dz) > max_dist) return;
-  }
-  int slot = atomicAdd(n_valid, 1);
-  if (slot < cap) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) hyps[slot].T[k] = T[k];
-    hyps[slot].it = it;
-    hyps[slot].inliers = 0;
-    hyps[slot].err2 = 0.0;
+    const uint32_t i = sample_index(seed, (uint64_t)it, j, n0);
+    const float4 a = rec[2 * (int64_t)i], b = rec[2 * (int64_t)i + 1];
+    s[j][0] = (double)a.x; s[j][1] = (double)a.y; s[j][2] = (double)a.z;
+    t[j][0] = (double)b.x; t[j][1] = (double)b.y; t[j][2] = (double)b.z;
   }
 }
 
-// Persistent waves: wave w scores hypotheses w, w + W, ... (exit is reached by every wave).
-__global__ __launch_bounds__(256) void k_score(const float* __restrict__ xyz0, const float* __restrict__ tgt,
-                                               int64_t n0, double max_dist, Hyp* __restrict__ hyps,
-                                               const int* __restrict__ n_valid, int cap) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+// CorrespondenceCheckerBasedOnEdgeLength: reject if |s_a s_b| < r |t_a t_b| or |t_a t_b| < r |s_a s_b| (lengths via
+// fp64 sqrt in the oracle).  Squared form first; inside the 1e-12 guard band the oracle's exact expression decides.
+__device__ inline bool edge_reject(double a2, double b2, double r, double r2) {
+  const double rb = b2 * r2;
+  if (a2 < rb * (1.0 - 1e-12)) return true;
+  if (a2 > rb * (1.0 + 1e-12)) return false;
+  return sqrt(a2) < sqrt(b2) * r;
+}
+
+__global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__ rec, uint32_t n0, double edge_ratio,
+                                                      long long it0, long long it1, uint64_t seed,
+                                                      long long* __restrict__ cand, int* __restrict__ n_cand) {
+  const long long it = it0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = it < it1;
+  if (ok) {
+    double s[4][3], t[4][3];
+    load_samples(rec, seed, it, n0, s, t);
+    const double r2 = edge_ratio * edge_ratio;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = a + 1; b < 4; ++b) {
+        const double ds2 = (s[a][0] - s[b][0]) * (s[a][0] - s[b][0]) + (s[a][1] - s[b][1]) * (s[a][1] - s[b][1]) +
+                           (s[a][2] - s[b][2]) * (s[a][2] - s[b][2]);
+        const double dt2 = (t[a][0] - t[b][0]) * (t[a][0] - t[b][0]) + (t[a][1] - t[b][1]) * (t[a][1] - t[b][1]) +
+                           (t[a][2] - t[b][2]) * (t[a][2] - t[b][2]);
+        if (edge_reject(ds2, dt2, edge_ratio, r2) || edge_reject(dt2, ds2, edge_ratio, r2)) ok = false;
+      }
+  }
+  // wave-aggregated append of the survivors' iteration numbers
+  const unsigned long long m = __ballot(ok);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_cand, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (ok) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
+  }
+}
+
+// dense over the compacted candidates (grid-stride: the count only exists on the device)
+__global__ __launch_bounds__(256) void k_fit_check(const float4* __restrict__ rec, uint32_t n0, double thr_gt,
+                                                   uint64_t seed, const long long* __restrict__ cand,
+                                                   const int* __restrict__ n_cand, Hyp* __restrict__ hyps,
+                                                   int* __restrict__ n_valid, int cap) {
+  const int nc = *n_cand;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    const long long it = cand[c];
+    double s[4][3], t[4][3];
+    load_samples(rec, seed, it, n0, s, t);
+    double T[12];
+    kabsch4(s, t, T);
+    // CorrespondenceCheckerBasedOnDistance: sqrt(d2) > max_dist  <=>  d2 > thr_gt
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double dx = T[0] * s[j][0] + T[1] * s[j][1] + T[2] * s[j][2] + T[3] - t[j][0];
+      double dy = T[4] * s[j][0] + T[5] * s[j][1] + T[6] * s[j][2] + T[7] - t[j][1];
+      double dz = T[8] * s[j][0] + T[9] * s[j][1] + T[10] * s[j][2] + T[11] - t[j][2];
+      if (dx * dx + dy * dy + dz * dz > thr_gt) ok = false;
+    }
+    if (!ok) continue;
+    const int slot = atomicAdd(n_valid, 1);
+    if (slot < cap) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) hyps[slot].T[k] = T[k];
+      hyps[slot].it = it;
+      hyps[slot].inliers = 0;
+      hyps[slot].err2 = 0.0;
+    }
+  }
+}
+
+// A workgroup per hypothesis (grid-stride; every workgroup reaches the exit): only a few hundred hypotheses survive
+// the checkers, so one WAVE per hypothesis would leave the chip idle behind ~220 serial iterations per wave.
+// The per-thread partial sums are combined in a fixed order (lane tree, then waves 0..3): bitwise reproducible.
+__global__ __launch_bounds__(256) void k_score(const float4* __restrict__ rec, int64_t n0, double thr_lt,
+                                               Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap) {
+  __shared__ int s_cnt[4];
+  __shared__ double s_e2[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = min(*n_valid, cap);
-  for (int h = wave; h < nv; h += nwaves) {
+  for (int h = blockIdx.x; h < nv; h += gridDim.x) {
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = hyps[h].T[k];
     int cnt = 0;
     double e2 = 0.0;
-    for (int64_t i = lane; i < n0; i += 64) {
-      double sx = xyz0[3 * i], sy = xyz0[3 * i + 1], sz = xyz0[3 * i + 2];
-      double dx = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - (double)tgt[3 * i];
-      double dy = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - (double)tgt[3 * i + 1];
-      double dz = T[8] * sx + T[9] * sy + T[10] * sz + T[11] - (double)tgt[3 * i + 2];
+    for (int64_t i = threadIdx.x; i < n0; i += 256) {
+      const float4 a = rec[2 * i], b = rec[2 * i + 1];
+      const double sx = a.x, sy = a.y, sz = a.z;
+      double dx = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - (double)b.x;
+      double dy = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - (double)b.y;
+      double dz = T[8] * sx + T[9] * sy + T[10] * sz + T[11] - (double)b.z;
       double d2 = dx * dx + dy * dy + dz * dz;
-      if (sqrt(d2) < max_dist) {
+      if (d2 < thr_lt) {   // <=> sqrt(d2) < max_dist
         ++cnt;
         e2 += d2;
       }
@@ -221,9 +269,15 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ xyz0, c
       e2 += __shfl_xor(e2, d);
     }
     if (lane == 0) {
-      hyps[h].inliers = cnt;
-      hyps[h].err2 = e2;
+      s_cnt[wave] = cnt;
+      s_e2[wave] = e2;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      hyps[h].inliers = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      hyps[h].err2 = ((s_e2[0] + s_e2[1]) + s_e2[2]) + s_e2[3];
+    }
+    __syncthreads();
   }
 }
 
@@ -516,10 +570,89 @@ __global__ __launch_bounds__(256) void k_score_geometric(const float* __restrict
 
 constexpr int64_t kChunk = 1 << 20;
 
+// smallest double t with sqrt(t) >= m: sqrt(x) < m <=> x < t for every x >= 0 (sqrt is monotone, correctly rounded)
+static double sqrt_lt_threshold(double m) {
+  double t = m * m;
+  while (t > 0.0 && sqrt(t) >= m) t = nextafter(t, 0.0);
+  while (sqrt(t) < m) t = nextafter(t, INFINITY);
+  return t;
+}
+// largest double u with sqrt(u) <= m: sqrt(x) > m <=> x > u
+static double sqrt_gt_threshold(double m) {
+  double u = m * m;
+  while (sqrt(u) <= m) u = nextafter(u, INFINITY);
+  while (u > 0.0 && sqrt(u) > m) u = nextafter(u, 0.0);
+  return u;
+}
+
+struct RansacScratch {
+  Hyp* best;
+  long long* total_valid;
+  int* n_valid;
+  int* n_cand;
+  Hyp* hyps;
+  float4* rec;
+  long long* cand;
+  char* end;
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t ransac_core_bytes(int64_t n0, int64_t max_iter) {
+  const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
+  return align256(sizeof(Hyp) + 64) + align256((size_t)(cap < 1 ? 1 : cap) * sizeof(Hyp)) + align256((size_t)n0 * 32) +
+         align256((size_t)(max_iter < 1 ? 1 : max_iter) * 8) + 256;
+}
+
+static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
+  const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
+  RansacScratch r;
+  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  r.best = (Hyp*)p;
+  r.total_valid = (long long*)(p + sizeof(Hyp));
+  r.n_valid = (int*)(p + sizeof(Hyp) + 8);
+  r.n_cand = r.n_valid + 1;   // adjacent: one 8-byte memset clears both
+  p += align256(sizeof(Hyp) + 64);
+  r.hyps = (Hyp*)p;
+  p += align256((size_t)cap * sizeof(Hyp));
+  r.rec = (float4*)p;
+  p += align256((size_t)n0 * 32);
+  r.cand = (long long*)p;
+  p += align256((size_t)max_iter * 8);
+  r.end = p;
+  return r;
+}
+
+// sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
+static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dist, double edge_ratio, int64_t it0,
+                              int64_t it1, uint64_t seed, int cap, hipStream_t st) {
+  (void)hipMemsetAsync(r.n_valid, 0, 8, st);   // n_valid and n_cand are adjacent
+  hipLaunchKernelGGL(k_sample_check, dim3((unsigned)cdiv64(it1 - it0, 256)), dim3(256), 0, st, r.rec, (uint32_t)n0,
+                     edge_ratio, (long long)it0, (long long)it1, seed, r.cand, r.n_cand);
+  hipLaunchKernelGGL(k_fit_check, dim3(512), dim3(256), 0, st, r.rec, (uint32_t)n0, sqrt_gt_threshold(max_dist), seed,
+                     r.cand, r.n_cand, r.hyps, r.n_valid, cap);
+}
+
+static int fetch_result(const RansacScratch& r, double* result_host, long long* tv_out, hipStream_t st) {
+  Hyp hb;
+  long long tv = 0;
+  APR_HIP(hipMemcpyAsync(&hb, r.best, sizeof(Hyp), hipMemcpyDeviceToHost, st));
+  APR_HIP(hipMemcpyAsync(&tv, r.total_valid, 8, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipStreamSynchronize(st));
+  for (int k = 0; k < 12; ++k) result_host[k] = hb.T[k];
+  result_host[12] = 0.0; result_host[13] = 0.0; result_host[14] = 0.0; result_host[15] = 1.0;
+  result_host[16] = (double)(hb.inliers < 0 ? 0 : hb.inliers);
+  result_host[17] = hb.inliers > 0 ? sqrt(hb.err2 / (double)hb.inliers) : 0.0;
+  result_host[18] = (double)hb.it;
+  result_host[19] = (double)tv;
+  *tv_out = tv;
+  return APR_OK;
+}
+
 }  // namespace
 
 APR_API size_t apr_ransac_geometric_scratch_bytes(int64_t n0, int64_t n1, int64_t max_iter) {
-  return apr_ransac_scratch_bytes(n0, max_iter) + (size_t)(max_iter < kChunk ? max_iter : kChunk) * 4 + 256 +
+  return ransac_core_bytes(n0, max_iter) + align256((size_t)(max_iter < kChunk ? max_iter : kChunk) * 4) + 256 +
          apr_internal_grid_bytes(n1) + 256;
 }
 
@@ -534,97 +667,59 @@ APR_API int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float
   APR_CHECK_ARG(scratch_bytes >= apr_ransac_geometric_scratch_bytes(n0, n1, max_iter),
                 "apr_ransac_pose_geometric: scratch too small");
   const int64_t cap = max_iter;
-  char* p = (char*)scratch;
-  Hyp* best = (Hyp*)p;
-  p += sizeof(Hyp);
-  long long* total_valid = (long long*)p;
-  p += 8;
-  int* n_valid = (int*)p;
-  p += 56;
-  Hyp* hyps = (Hyp*)p;
-  p += (size_t)cap * sizeof(Hyp);
-  float* tgt = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-  p = (char*)tgt + (size_t)n0 * 12;
-  int* selected = (int*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-  p = (char*)selected + (size_t)cap * 4;
-  void* grid_scratch = (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  const RansacScratch r = carve_ransac(scratch, n0, max_iter);
+  int* selected = (int*)r.end;
+  void* grid_scratch = (void*)(r.end + align256((size_t)cap * 4));
   AprSearchGrid g;
   int rc = apr_internal_search_grid(xyz1, n1, (float)(2.0 * max_dist), grid_scratch, &g, st);
   if (rc != APR_OK) return rc;
-  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, best, total_valid);
-  hipLaunchKernelGGL(k_gather_targets, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz1, n1,
-                     (const long long*)corr, n0, tgt);
-  APR_HIP(hipMemsetAsync(n_valid, 0, 4, st));
-  hipLaunchKernelGGL(k_hypotheses, dim3((unsigned)cdiv64(max_iter, 256)), dim3(256), 0, st, xyz0, tgt, (uint32_t)n0,
-                     max_dist, edge_ratio, 0ll, (long long)max_iter, seed, hyps, n_valid, (int)cap);
-  hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, hyps, n_valid, (int)cap,
-                     (int)(max_validation < (1ll << 30) ? max_validation : (1ll << 30)), selected);
-  hipLaunchKernelGGL(k_score_geometric, dim3(2048), dim3(256), 0, st, xyz0, n0, xyz1, g, max_dist, hyps, n_valid,
+  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
+  hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz0, xyz1, n1,
+                     (const long long*)corr, n0, r.rec);
+  launch_hypotheses(r, n0, max_dist, edge_ratio, 0, max_iter, seed, (int)cap, st);
+  hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, r.hyps, r.n_valid,
+                     (int)cap, (int)(max_validation < (1ll << 30) ? max_validation : (1ll << 30)), selected);
+  hipLaunchKernelGGL(k_score_geometric, dim3(2048), dim3(256), 0, st, xyz0, n0, xyz1, g, max_dist, r.hyps, r.n_valid,
                      (int)cap, selected);
-  hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, hyps, n_valid, (int)cap, best, total_valid);
+  hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
   APR_LAUNCH_CHECK();
-  Hyp hb;
-  long long tv = 0;
-  APR_HIP(hipMemcpyAsync(&hb, best, sizeof(Hyp), hipMemcpyDeviceToHost, st));
-  APR_HIP(hipMemcpyAsync(&tv, total_valid, 8, hipMemcpyDeviceToHost, st));
-  APR_HIP(hipStreamSynchronize(st));
-  for (int k = 0; k < 12; ++k) result_host[k] = hb.T[k];
-  result_host[12] = 0.0; result_host[13] = 0.0; result_host[14] = 0.0; result_host[15] = 1.0;
-  result_host[16] = (double)(hb.inliers < 0 ? 0 : hb.inliers);
-  result_host[17] = hb.inliers > 0 ? sqrt(hb.err2 / (double)hb.inliers) : 0.0;
-  result_host[18] = (double)hb.it;
-  result_host[19] = (double)tv;
-  return APR_OK;
+  long long tv;
+  return fetch_result(r, result_host, &tv, st);
 }
 
-APR_API size_t apr_ransac_scratch_bytes(int64_t n0, int64_t max_iter) {
-  int64_t cap = max_iter < kChunk ? max_iter : kChunk;
-  if (cap < 1) cap = 1;
-  return (size_t)cap * sizeof(Hyp) + sizeof(Hyp) + 64 + (size_t)n0 * 12 + 256;
-}
+APR_API size_t apr_ransac_scratch_bytes(int64_t n0, int64_t max_iter) { return ransac_core_bytes(n0, max_iter); }
 
 APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1, const int64_t* corr,
                             double max_dist, double edge_ratio, int64_t max_iter, uint64_t seed, void* scratch,
                             size_t scratch_bytes, double* result_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(n0 > 0 && n0 < (1ll << 31) && n1 > 0, "apr_ransac_pose: empty point set");
-  APR_CHECK_ARG(max_iter > 0 && max_dist > 0, "apr_ransac_pose: bad max_iter / max_dist");
+  APR_CHECK_ARG(max_iter > 0 && max_iter < (1ll << 31) && max_dist > 0, "apr_ransac_pose: bad max_iter / max_dist");
   APR_CHECK_ARG(scratch_bytes >= apr_ransac_scratch_bytes(n0, max_iter), "apr_ransac_pose: scratch too small");
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
-  char* p = (char*)scratch;
-  Hyp* best = (Hyp*)p;
-  p += sizeof(Hyp);
-  long long* total_valid = (long long*)p;
-  p += 8;
-  int* n_valid = (int*)p;
-  p += 56;
-  Hyp* hyps = (Hyp*)p;
-  p += (size_t)cap * sizeof(Hyp);
-  float* tgt = (float*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, best, total_valid);
-  hipLaunchKernelGGL(k_gather_targets, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz1, n1,
-                     (const long long*)corr, n0, tgt);
-  for (int64_t it0 = 0; it0 < max_iter; it0 += cap) {
-    const int64_t it1 = (it0 + cap < max_iter) ? it0 + cap : max_iter;
-    APR_HIP(hipMemsetAsync(n_valid, 0, 4, st));
-    hipLaunchKernelGGL(k_hypotheses, dim3((unsigned)cdiv64(it1 - it0, 256)), dim3(256), 0, st, xyz0, tgt,
-                       (uint32_t)n0, max_dist, edge_ratio, (long long)it0, (long long)it1, seed, hyps, n_valid,
-                       (int)cap);
-    hipLaunchKernelGGL(k_score, dim3(2048), dim3(256), 0, st, xyz0, tgt, n0, max_dist, hyps, n_valid, (int)cap);
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, hyps, n_valid, (int)cap, best, total_valid);
+  const RansacScratch r = carve_ransac(scratch, n0, max_iter);
+  const double thr_lt = sqrt_lt_threshold(max_dist);
+  hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz0, xyz1, n1,
+                     (const long long*)corr, n0, r.rec);
+  // Fast path: ALL iterations in one round.  The hypothesis list holds kChunk entries; only if more than that
+  // survive both checkers (near-perfect correspondences) the rounds are replayed kChunk iterations at a time,
+  // where the list cannot overflow.  total_valid tells which case it was.
+  const int s_force_rounds = env_int("APR_RANSAC_FORCE_ROUNDS", 0);   // test hook (read per call): skip the fast path
+  for (int pass = s_force_rounds ? 1 : 0; pass < 2; ++pass) {
+    const int64_t step = pass == 0 ? max_iter : cap;
+    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
+    for (int64_t it0 = 0; it0 < max_iter; it0 += step) {
+      const int64_t it1 = (it0 + step < max_iter) ? it0 + step : max_iter;
+      launch_hypotheses(r, n0, max_dist, edge_ratio, it0, it1, seed, (int)cap, st);
+      hipLaunchKernelGGL(k_score, dim3(2048), dim3(256), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, (int)cap);
+      hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
+    }
+    APR_LAUNCH_CHECK();
+    long long tv;
+    int rc = fetch_result(r, result_host, &tv, st);
+    if (rc != APR_OK) return rc;
+    if (tv <= cap || step == cap) break;   // nothing was dropped
   }
-  APR_LAUNCH_CHECK();
-  Hyp hb;
-  long long tv = 0;
-  APR_HIP(hipMemcpyAsync(&hb, best, sizeof(Hyp), hipMemcpyDeviceToHost, st));
-  APR_HIP(hipMemcpyAsync(&tv, total_valid, 8, hipMemcpyDeviceToHost, st));
-  APR_HIP(hipStreamSynchronize(st));
-  for (int k = 0; k < 12; ++k) result_host[k] = hb.T[k];
-  result_host[12] = 0.0; result_host[13] = 0.0; result_host[14] = 0.0; result_host[15] = 1.0;
-  result_host[16] = (double)(hb.inliers < 0 ? 0 : hb.inliers);
-  result_host[17] = hb.inliers > 0 ? sqrt(hb.err2 / (double)hb.inliers) : 0.0;
-  result_host[18] = (double)hb.it;
-  result_host[19] = (double)tv;
   return APR_OK;
 }
 

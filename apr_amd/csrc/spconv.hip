@@ -504,11 +504,6 @@ int launch_pairs(const float* in, int64_t ldi, const int* nbr, int64_t n_out, in
   return APR_OK;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 }  // namespace
 
 APR_API int64_t apr_spconv_packed_size(int32_t K, int32_t cin, int32_t cout) {
@@ -555,14 +550,26 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
       return launch_pairs<32, 64, 32, 8>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift, residual, ldr,
                                          relu, out, ldo, st);
     static const int s_ck = env_int("APR_SPCONV_CK", 0);
-    const bool cn64 = (cout % 64 == 0), ck64 = (cin % 64 == 0) && s_ck != 32;
-    // 64-row tiles halve the weight re-reads; use them once there are enough tiles to fill 256 CUs
-    const int tm = s_tm ? s_tm : ((n_out * (cout / (cn64 ? 64 : 32)) >= 64 * 400) ? 64 : 32);
+    static const int s_cn = env_int("APR_SPCONV_CN", 0);
+    const bool cn64 = (cout % 64 == 0) && s_cn != 32;
+    const bool ck64 = (cin % 64 == 0) && s_ck != 32;
+    // 64-row tiles halve the weight re-reads but need >= ~400 workgroups to fill 256 CUs; below that 32-row
+    // tiles win.  16-row tiles / 32-channel slices (APR_SPCONV_TM=16, APR_SPCONV_CN=32) measured slower on
+    // every layer of the encoder: the deep layers are bound by the weight stream, not by parallelism — they
+    // go through the weight-stationary path (spconv_ws.hip) instead.
+    int tm = s_tm;
+    if (!tm) tm = cdiv64(n_out, 64) * (cout / (cn64 ? 64 : 32)) >= 400 ? 64 : 32;
     if (tm == 64) {
       if (cn64 && ck64) APR_PAIRS(64, 64, 64);
       if (cn64) APR_PAIRS(64, 64, 32);
       if (ck64) APR_PAIRS(64, 32, 64);
       APR_PAIRS(64, 32, 32);
+    }
+    if (tm == 16) {
+      if (cn64 && ck64) APR_PAIRS(16, 64, 64);
+      if (cn64) APR_PAIRS(16, 64, 32);
+      if (ck64) APR_PAIRS(16, 32, 64);
+      APR_PAIRS(16, 32, 32);
     }
     if (cn64 && ck64) APR_PAIRS(32, 64, 64);
     if (cn64) APR_PAIRS(32, 64, 32);
@@ -624,6 +631,17 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
 APR_API int apr_spconv_fwd_batch(const apr_spconv_desc* d, int32_t n, void* stream) {
   APR_CHECK_ARG(n >= 0 && (d != nullptr || n == 0), "apr_spconv_fwd_batch: bad arguments");
   for (int i = 0; i < n; ++i) {
+    if (d[i].plist) {
+      if (d[i].plist_bytes > 0) {
+        int rcb = apr_pairlist_build(d[i].nbr, d[i].n_out, d[i].K, d[i].plist, (size_t)d[i].plist_bytes, stream);
+        if (rcb != APR_OK) return rcb;
+      }
+      int rcw = apr_spconv_ws_fwd(d[i].in, d[i].ldi, d[i].plist, d[i].n_out, d[i].K, d[i].cin, d[i].cout,
+                                  d[i].w_packed, d[i].scale, d[i].shift, d[i].residual, d[i].ldr, d[i].relu, d[i].out,
+                                  d[i].ldo, d[i].prod_scratch, d[i].p_max, d[i].p_est, stream);
+      if (rcw != APR_OK) return rcw;
+      continue;
+    }
     int rc = apr_spconv_fwd(d[i].in, d[i].ldi, d[i].nbr, d[i].n_out, d[i].K, d[i].cin, d[i].cout, d[i].w_packed,
                             d[i].scale, d[i].shift, d[i].residual, d[i].ldr, d[i].relu, d[i].out, d[i].ldo, stream);
     if (rc != APR_OK) return rc;

@@ -1,0 +1,328 @@
+// Weight-stationary sparse convolution for maps with FEW pairs per output tile:
+// strided / transposed convolutions and the deep, small levels of the UNet.
+//
+// The tile kernel (spconv.hip) re-reads W[k] for every (32-row tile, offset): with Cin*Cout >= 128*64 and
+// only 2-8 pairs per (tile, offset) the weight stream from L2 (100-550 MB per launch) dominates.  Here the
+// kernel map is first turned into per-offset pair lists (one-off per map, cached by the caller):
+//     pairs of offset k, ascending output row:  pair_in[p], pair_out[p];  pair_id[row, k] = p or -1
+// built with wave64 ballot + popcount + a per-offset exclusive scan over row blocks, then
+//   1. k_ws_gemm: a workgroup owns (offset k, 64 consecutive pairs, 64 output channels); the weight piece
+//      W[k][chunk] is staged ONCE per workgroup in LDS (double buffered, one barrier per 64-channel chunk),
+//      each wave gathers its 16 pairs' input rows straight into MFMA operand registers, accumulates over all
+//      Cin chunks in registers (v_mfma_f32_16x16x4_f32, D^T form) and stores prod[p, :] with 16-B stores;
+//   2. k_ws_reduce: out[j,:] = act((sum_k prod[pair_id[j,k],:]) * scale + shift + residual) in fixed k order.
+// No atomics, bitwise reproducible.  Extra HBM traffic: the [P, Cout] product buffer, written and read once.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRows = 256;   // rows per block in the pair-list build
+
+struct PairHeader {   // lives at the start of the pair-list blob (device memory)
+  int off[33];        // pair range of offset k: [off[k], off[k+1])
+  int unit_off[33];   // 64-pair work units of offset k: [unit_off[k], unit_off[k+1])
+};
+
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct PairViews {
+  PairHeader* hdr;
+  int* pair_in;
+  int* pair_out;
+  int* pair_id;   // [n_out, K]
+  int* cnt;       // [K, nblk] scratch: per-block counts then exclusive bases
+};
+
+__host__ __device__ inline PairViews carve_pairs(void* blob, int64_t n_out, int K) {
+  PairViews v;
+  char* p = (char*)blob;
+  v.hdr = (PairHeader*)p;
+  p += align256(sizeof(PairHeader));
+  const size_t cap = (size_t)n_out * K;
+  v.pair_in = (int*)p;
+  p += align256(cap * 4);
+  v.pair_out = (int*)p;
+  p += align256(cap * 4);
+  v.pair_id = (int*)p;
+  p += align256(cap * 4);
+  v.cnt = (int*)p;
+  return v;
+}
+
+// pass 1 / 3: per (row block, offset) counts, then fill.  FILL = false: counts only.
+// The block's [256, K] slab of the table goes through LDS once (coalesced); wave w then owns offsets
+// w, w+4, ... and walks the 256 rows 64 at a time with ballot + popcount (row stride K ints: conflict-free for
+// odd K, 2-way at worst) — no barrier inside the offset loop.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_pairs_scan(const int* __restrict__ nbr, int n_out, int K, int nblk,
+                                                    PairViews v) {
+  __shared__ int s_nbr[kRows * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x;
+  const int row0 = blk * kRows;
+  const int rows = min(kRows, n_out - row0);
+  const int total = rows * K;
+  const int* src = nbr + (int64_t)row0 * K;
+  for (int e = threadIdx.x; e < total; e += 256) s_nbr[e] = src[e];
+  __syncthreads();
+  for (int k = wave; k < K; k += 4) {
+    int run = 0;
+    if (FILL) run = v.hdr->off[k] + v.cnt[k * nblk + blk];
+#pragma unroll
+    for (int c = 0; c < kRows / 64; ++c) {
+      const int r = c * 64 + lane;
+      const int idx = (r < rows) ? s_nbr[r * K + k] : -1;
+      const unsigned long long m = __ballot(idx >= 0);
+      if (FILL && r < rows) {
+        int pos = -1;
+        if (idx >= 0) {
+          pos = run + __popcll(m & ((1ull << lane) - 1ull));
+          v.pair_in[pos] = idx;
+          v.pair_out[pos] = row0 + r;
+        }
+        s_nbr[r * K + k] = pos;
+      }
+      run += __popcll(m);
+    }
+    if (!FILL && lane == 0) v.cnt[k * nblk + blk] = run;
+  }
+  if (FILL) {
+    __syncthreads();
+    int* dst = v.pair_id + (int64_t)row0 * K;
+    for (int e = threadIdx.x; e < total; e += 256) dst[e] = s_nbr[e];   // coalesced write of the id slab
+  }
+}
+
+// pass 2: per offset, exclusive scan of the block counts (one wave per offset), then the offset prefix
+__global__ __launch_bounds__(1024) void k_pairs_offsets(int K, int nblk, PairViews v) {
+  __shared__ int s_total[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < K; k += 16) {
+    int carry = 0;
+    for (int base = 0; base < nblk; base += 64) {
+      const int i = base + lane;
+      const int c = i < nblk ? v.cnt[k * nblk + i] : 0;
+      int incl = c;
+      for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (i < nblk) v.cnt[k * nblk + i] = carry + incl - c;
+      carry += __shfl(incl, 63);
+    }
+    if (lane == 0) s_total[k] = carry;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int o = 0, u = 0;
+    for (int k = 0; k < K; ++k) {
+      v.hdr->off[k] = o;
+      v.hdr->unit_off[k] = u;
+      o += s_total[k];
+      u += (s_total[k] + 63) >> 6;
+    }
+    v.hdr->off[K] = o;
+    v.hdr->unit_off[K] = u;
+  }
+}
+
+// Work unit = (offset k, block of 64*G consecutive pairs of k, 64 output channels); G is chosen ON THE DEVICE
+// from the real pair count so that ~768 units exist, and a fixed-size grid strides over them (no host sync, no
+// surplus workgroups).  The whole weight slice W[k][:, col0:col0+64] (cin*256 B, <= 128 KB) is staged in LDS
+// once per unit (8 independent 16-B loads in flight per thread), then each wave walks 16-pair groups: gather
+// rows -> registers (prefetched one 64-channel chunk ahead, across group boundaries), B fragments from LDS
+// (conflict-free ds_read_b128), cin/64 * 64 MFMAs into 16 accumulator registers.
+__global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in, int64_t ldi, PairViews v, int K,
+                                                    int cin, int cout, const float* __restrict__ wp,
+                                                    float* __restrict__ prod, int p_cap) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];   // [g = cin/4][col 64][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int col0 = blockIdx.y * 64;
+  const int cinG = cin >> 2;
+  const int nchunk = cin >> 6;   // cin % 64 == 0 on this path
+  // unit table in registers: every wave redoes the 32-entry scan (no LDS, no barrier)
+  const int o0 = (lane <= K) ? v.hdr->off[lane] : 0;
+  const int o1 = __shfl_down(o0, 1);
+  const int P = __shfl(o0, K);
+  int G = (int)(((int64_t)(P >> 6) * gridDim.y) / 768);
+  G = G < 1 ? 1 : (G > 16 ? 16 : G);
+  const int span = 64 * G;
+  const int units = (lane < K) ? (o1 - o0 + span - 1) / span : 0;
+  int incl = units;
+  for (int d = 1; d < 32; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  const int total_units = __shfl(incl, 31);
+
+  for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+    const int k = __popcll(__ballot(lane < K && incl <= unit));
+    const int excl = __shfl(incl - units, k);
+    const int p_begin = __shfl(o0, k) + (unit - excl) * span;
+    const int p_end = min(p_begin + span, __shfl(o1, k));
+    const int ngroups = (p_end - p_begin + 15) >> 4;
+
+    // first group's rows (index load overlaps the weight staging)
+    int g = wave;
+    int my_p = p_begin + g * 16 + r16;
+    int idx = (g < ngroups) ? v.pair_in[my_p < p_end ? my_p : p_begin] : 0;
+    {
+      const float* src = wp + ((int64_t)k * cinG * cout + col0) * 4 + lane * 4;
+      for (int g0 = wave; g0 < cinG; g0 += 32) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (g0 + 4 * u < cinG) t[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(g0 + 4 * u) * cout * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (g0 + 4 * u < cinG) *reinterpret_cast<f32x4*>(&s_w[((g0 + 4 * u) * 64 + lane) * 4]) = t[u];
+      }
+    }
+    f32x4 an[4];
+    const float* abase = in + (int64_t)idx * ldi + q * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) an[j] = *reinterpret_cast<const f32x4*>(abase + j * 16);
+    __syncthreads();
+
+    while (g < ngroups) {
+      const int gn = g + 4;
+      const int np = p_begin + gn * 16 + r16;
+      const int idx_n = (gn < ngroups) ? v.pair_in[np < p_end ? np : p_begin] : idx;
+      f32x4 acc[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int chunk = 0; chunk < nchunk; ++chunk) {
+        f32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = an[j];
+        // prefetch: next chunk of this group, or chunk 0 of the wave's next group (a harmless re-read at the end)
+        const bool last = chunk + 1 == nchunk;
+        const float* nb = last ? in + (int64_t)idx_n * ldi + q * 4 : abase + (chunk + 1) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) an[j] = *reinterpret_cast<const f32x4*>(nb + j * 16);
+        const float* wb = s_w + (chunk * 16 * 64) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 b[4];
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+            b[cb] = *reinterpret_cast<const f32x4*>(wb + ((j * 4 + q) * 64 + cb * 16 + r16) * 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cb][t], a[j][t], acc[cb], 0, 0, 0);
+        }
+      }
+      // D^T: lane (r16 = pair, q) holds channels cb*16 + 4q .. +3 of its pair
+      if (my_p < p_end && my_p < p_cap) {
+        float* dst = prod + (int64_t)my_p * cout + col0 + q * 4;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(dst + cb * 16) = acc[cb];
+      }
+      g = gn;
+      my_p = np;
+      idx = idx_n;
+      abase = in + (int64_t)idx * ldi + q * 4;
+    }
+    __syncthreads();   // the slice is re-staged by the next unit
+  }
+}
+
+// All pair ids of the row first, then all product loads in flight at once (exec-masked), summed in offset order:
+// the naive "load id -> branch -> load -> add" loop is a chain of K dependent L2 round trips (~25 us floor).
+template <int KT>
+__global__ __launch_bounds__(256) void k_ws_reduce(const float* __restrict__ prod, PairViews v, int64_t n_out, int K,
+                                                   int cout, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, const float* __restrict__ residual,
+                                                   int64_t ldr, int relu, float* __restrict__ out, int64_t ldo) {
+  const int c4n = cout >> 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * c4n) return;
+  const int64_t row = t / c4n;
+  const int col = (int)(t - row * c4n) * 4;
+  const int* ids = v.pair_id + row * K;
+  int pid[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) pid[k] = (k < K) ? ids[k] : -1;
+  f32x4 p[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    p[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pid[k] >= 0) p[k] = *reinterpret_cast<const f32x4*>(prod + (int64_t)pid[k] * cout + col);
+  }
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < KT; ++k) s += p[k];
+  if (scale) s *= *reinterpret_cast<const f32x4*>(scale + col);
+  if (shift) s += *reinterpret_cast<const f32x4*>(shift + col);
+  if (residual) s += *reinterpret_cast<const f32x4*>(residual + row * ldr + col);
+  if (relu) {
+    s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f);
+  }
+  *reinterpret_cast<f32x4*>(out + row * ldo + col) = s;
+}
+
+}  // namespace
+
+APR_API size_t apr_pairlist_bytes(int64_t n_out, int32_t K) {
+  const int64_t nblk = cdiv64(n_out > 0 ? n_out : 1, kRows);
+  return align256(sizeof(PairHeader)) + 3 * align256((size_t)n_out * K * 4) + align256((size_t)K * nblk * 4) + 256;
+}
+
+APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, void* plist, size_t plist_bytes,
+                               void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 32, "apr_pairlist_build: bad n_out / K");
+  APR_CHECK_ARG(plist_bytes >= apr_pairlist_bytes(n_out, K), "apr_pairlist_build: blob too small");
+  const int nblk = (int)cdiv64(n_out, kRows);
+  PairViews v = carve_pairs(plist, n_out, K);
+  hipLaunchKernelGGL(k_pairs_scan<false>, dim3(nblk), dim3(256), 0, st, nbr, (int)n_out, K, nblk, v);
+  hipLaunchKernelGGL(k_pairs_offsets, dim3(1), dim3(1024), 0, st, K, nblk, v);
+  hipLaunchKernelGGL(k_pairs_scan<true>, dim3(nblk), dim3(256), 0, st, nbr, (int)n_out, K, nblk, v);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, int64_t n_out, int32_t K, int32_t cin,
+                              int32_t cout, const float* w_packed, const float* scale, const float* shift,
+                              const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
+                              float* prod_scratch, int64_t p_max, int64_t p_est, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n_out > 0 && K >= 1 && K <= 32, "apr_spconv_ws_fwd: bad n_out / K");
+  APR_CHECK_ARG(cin % 64 == 0 && cin <= 512 && cout % 64 == 0,
+                "apr_spconv_ws_fwd: needs cin %% 64 == 0, cin <= 512 and cout %% 64 == 0");
+  APR_CHECK_ARG(ldi % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out) | ((uintptr_t)prod_scratch)) & 15) == 0,
+                "apr_spconv_ws_fwd: 16-byte aligned rows required");
+  APR_CHECK_ARG(!residual || (ldr % 4 == 0 && (((uintptr_t)residual) & 15) == 0), "apr_spconv_ws_fwd: residual alignment");
+  PairViews v = carve_pairs(const_cast<void*>(plist), n_out, K);
+  (void)p_est;
+  const int64_t p_bound = (p_max > 0 && p_max < n_out * (int64_t)K) ? p_max : n_out * (int64_t)K;
+  // fixed grid striding over the device-side unit list: <= ~1024 workgroups, never more than the pair bound needs
+  int64_t gx = cdiv64(1024, cout / 64);
+  const int64_t need = cdiv64(p_bound, 64) + K;
+  if (gx > need) gx = need;
+  const unsigned units = (unsigned)gx;
+  const size_t lds = (size_t)cin * 64 * 4;
+  static bool s_attr = false;
+  if (!s_attr) {
+    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    s_attr = true;
+  }
+  hipLaunchKernelGGL(k_ws_gemm, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,
+                     prod_scratch, (int)p_bound);
+  const dim3 rgrid((unsigned)cdiv64(n_out * (cout / 4), 256));
+  if (K <= 8)
+    hipLaunchKernelGGL(k_ws_reduce<8>, rgrid, dim3(256), 0, st, prod_scratch, v, n_out, K, cout, scale, shift, residual,
+                       ldr, relu, out, ldo);
+  else if (K <= 27)
+    hipLaunchKernelGGL(k_ws_reduce<27>, rgrid, dim3(256), 0, st, prod_scratch, v, n_out, K, cout, scale, shift,
+                       residual, ldr, relu, out, ldo);
+  else
+    hipLaunchKernelGGL(k_ws_reduce<32>, rgrid, dim3(256), 0, st, prod_scratch, v, n_out, K, cout, scale, shift,
+                       residual, ldr, relu, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}

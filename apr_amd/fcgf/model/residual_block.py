@@ -33,7 +33,7 @@ class BasicBlockBase(nn.Module):
         out += residual
         return MEF.relu(out)
 
-    def fused_eval(self, feats, nbr, out, batch=None):
+    def fused_eval(self, feats, nbr, out, batch=None, plist=None):
         """Eval-mode BN block as two fused sparse-conv launches.
 
         feats [N,C] rows in, `out` (maybe a column slice of a concat buffer)
@@ -42,8 +42,9 @@ class BasicBlockBase(nn.Module):
         n = feats.shape[0]
         s1, b1 = self.norm1.folded()
         s2, b2 = self.norm2.folded()
-        h = self.conv1.run(feats, nbr, n, scale=s1, shift=b1, relu=True, batch=batch)
-        return self.conv2.run(h, nbr, n, scale=s2, shift=b2, residual=feats, relu=True, out=out, batch=batch)
+        h = self.conv1.run(feats, nbr, n, scale=s1, shift=b1, relu=True, batch=batch, plist=plist)
+        return self.conv2.run(h, nbr, n, scale=s2, shift=b2, residual=feats, relu=True, out=out, batch=batch,
+                              plist=plist)
 
 
 class BasicBlockBN(BasicBlockBase):

@@ -15,6 +15,8 @@ Two execution paths produce the same numbers:
     straight into column slices of the concat buffers, and the coordinate
     pyramid (strides 2/4/8) built with a single host sync.
 """
+import os
+
 import torch
 
 from ... import MinkowskiEngine as ME
@@ -23,6 +25,18 @@ from ...MinkowskiEngine import MinkowskiFunctional as MEF
 from ...MinkowskiEngine.core import CoordinateMapKey
 from .common import get_norm
 from .residual_block import get_block
+
+
+# stages of the fused plan that take the weight-stationary conv path (few pairs per tile, large Cin*Cout);
+# measured per layer on MI355X (scripts/layer_bench.py), override with APR_WS_STAGES="conv3,block4,..." / "none"
+WS_STAGES = ("conv3", "conv4", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", "conv2_tr")
+
+
+def _ws_stages():
+    env = os.environ.get("APR_WS_STAGES")
+    if env is None:
+        return set(WS_STAGES)
+    return set() if env in ("", "none") else set(env.split(","))
 
 
 class ResUNet2(ME.MinkowskiNetwork):
@@ -131,25 +145,24 @@ class ResUNet2(ME.MinkowskiNetwork):
 
         batch = ops.SpconvBatch()   # the 23 conv launches leave through ONE library call
 
-        def stage(conv, norm, feats, nbr, n_out, blk, nbr_blk, out):
-            sc, sh = norm.folded()
-            a = conv.run(feats, nbr, n_out, scale=sc, shift=sh, batch=batch)
-            return blk.fused_eval(a, nbr_blk, out, batch=batch)
+        ws = _ws_stages()
 
-        m11 = cm.kernel_map(1, 1, 3)
-        m22 = cm.kernel_map(2, 2, 3)
-        m44 = cm.kernel_map(4, 4, 3)
-        m88 = cm.kernel_map(8, 8, 3)
-        stage(self.conv1, self.norm1, x.F, cm.kernel_map(1, 1, k1) if k1 != 3 else m11, N1, self.block1, m11, s1)
-        stage(self.conv2, self.norm2, s1, cm.kernel_map(1, 2, 3), N2, self.block2, m22, s2)
-        stage(self.conv3, self.norm3, s2, cm.kernel_map(2, 4, 3), N3, self.block3, m44, s4)
-        s8 = stage(self.conv4, self.norm4, s4, cm.kernel_map(4, 8, 3), N4, self.block4, m88, buf(N4, CH[4]))
-        stage(self.conv4_tr, self.norm4_tr, s8, cm.kernel_map(8, 4, 3, True), N3, self.block4_tr, m44,
-              cat3[:, :TR[4]])
-        stage(self.conv3_tr, self.norm3_tr, cat3, cm.kernel_map(4, 2, 3, True), N2, self.block3_tr, m22,
-              cat2[:, :TR[3]])
-        stage(self.conv2_tr, self.norm2_tr, cat2, cm.kernel_map(2, 1, 3, True), N1, self.block2_tr, m11,
-              cat1[:, :TR[2]])
+        def stage(name, feats, cmap, n_out, bmap, out):
+            """conv -> folded BN -> residual block; cmap / bmap = (ts_in, ts_out, kernel, transpose)."""
+            conv, norm, blk = getattr(self, "conv" + name), getattr(self, "norm" + name), getattr(self, "block" + name)
+            sc, sh = norm.folded()
+            a = conv.run(feats, cm.kernel_map(*cmap), n_out, scale=sc, shift=sh, batch=batch,
+                         plist=cm.pair_list(*cmap) if "conv" + name in ws else None)
+            return blk.fused_eval(a, cm.kernel_map(*bmap), out, batch=batch,
+                                  plist=cm.pair_list(*bmap) if "block" + name in ws else None)
+
+        stage("1", x.F, (1, 1, k1, False), N1, (1, 1, 3, False), s1)
+        stage("2", s1, (1, 2, 3, False), N2, (2, 2, 3, False), s2)
+        stage("3", s2, (2, 4, 3, False), N3, (4, 4, 3, False), s4)
+        s8 = stage("4", s4, (4, 8, 3, False), N4, (8, 8, 3, False), buf(N4, CH[4]))
+        stage("4_tr", s8, (8, 4, 3, True), N3, (4, 4, 3, False), cat3[:, :TR[4]])
+        stage("3_tr", cat3, (4, 2, 3, True), N2, (2, 2, 3, False), cat2[:, :TR[3]])
+        stage("2_tr", cat2, (2, 1, 3, True), N1, (1, 1, 3, False), cat1[:, :TR[2]])
         h = self.conv1_tr.run(cat1, None, N1, relu=True, batch=batch)
         out = self.final.run(h, None, N1, batch=batch)
         batch.launch()

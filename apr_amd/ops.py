@@ -157,10 +157,50 @@ class SpconvProfile:
 PROFILE = None  # set to a SpconvProfile to time launches
 
 
-def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None):
+class PairList:
+    """Per-offset pair lists of one kernel map (apr_pairlist_build): device blob + pair-count bounds.
+
+    `built` False: the blob is only allocated; the first launch of a SpconvBatch that uses it builds it inside
+    the same library call (no extra host round trip)."""
+
+    def __init__(self, blob, nbr, p_max, p_est, built):
+        self.blob, self.nbr, self.built = blob, nbr, built
+        self.n_out, self.K = nbr.shape
+        self.p_max = min(int(p_max), self.n_out * self.K) if p_max else self.n_out * self.K
+        self.p_est = min(int(p_est), self.p_max) if p_est else 0
+
+    def prod_scratch(self, cout):
+        return torch.empty(self.p_max * cout, dtype=torch.float32, device=self.blob.device)
+
+    def build(self):
+        if not self.built:
+            check(_lib_().apr_pairlist_build(ptr(self.nbr), self.n_out, self.K, ptr(self.blob), self.blob.numel(),
+                                             stream()))
+            self.built = True
+        return self
+
+
+def build_pairlist(nbr, p_max=None, p_est=None, lazy=False):
+    """nbr int32 [n_out, K] -> PairList.  p_max bounds the number of valid entries (default n_out*K), p_est is
+    the expected number (work-unit sizing hint)."""
+    if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2:
+        raise _lib.AprHipError("build_pairlist: nbr must be a contiguous int32 [n_out, K] tensor")
+    n_out, K = nbr.shape
+    nb = int(_lib_().apr_pairlist_bytes(n_out, K))
+    pl = PairList(torch.empty(nb, dtype=torch.uint8, device=nbr.device), nbr, p_max, p_est, False)
+    return pl if lazy else pl.build()
+
+
+def ws_supported(K, cin, cout):
+    return K <= 32 and cin % 64 == 0 and cin <= 512 and cout % 64 == 0
+
+
+def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
+           plist=None):
     """out[j] = act((sum_o x[nbr[j,o]] @ W[o]) * scale + shift + residual[j]).
 
-    x / residual / out may be column slices of wider row-major buffers.
+    x / residual / out may be column slices of wider row-major buffers.  With `plist` (the PairList of `nbr`)
+    the launch takes the weight-stationary path (apr_spconv_ws_fwd).
     """
     x, ldi = _rows(x, "spconv.x")
     if x.shape[1] != cin:
@@ -186,8 +226,16 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         P = prof.pairs(nbr, n_out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib_().apr_spconv_fwd(ptr(x), ldi, ptr(nbr), n_out, K, cin, cout, ptr(wp), ptr(scale), ptr(shift),
-                                 ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
+    if plist is not None and nbr is not None and ws_supported(K, cin, cout):
+        if plist.n_out != n_out or plist.K != K:
+            raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
+        prod = plist.build().prod_scratch(cout)
+        check(_lib_().apr_spconv_ws_fwd(ptr(x), ldi, ptr(plist.blob), n_out, K, cin, cout, ptr(wp), ptr(scale),
+                                        ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, ptr(prod),
+                                        plist.p_max, plist.p_est, stream()))
+    else:
+        check(_lib_().apr_spconv_fwd(ptr(x), ldi, ptr(nbr), n_out, K, cin, cout, ptr(wp), ptr(scale), ptr(shift),
+                                     ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
     if prof is not None:
         e1.record()
         prof.records.append((P, cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0, e0, e1))
@@ -200,10 +248,12 @@ class SpconvBatch:
     def __init__(self):
         self.descs = []
         self.keep = []      # tensors referenced by raw pointers stay alive until the launch call returns
+        self.prod = {}      # weight-stationary product buffers by size
 
-    def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None):
+    def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
+            plist=None):
         if PROFILE is not None:     # per-launch timing requested: fall back to immediate launches
-            return spconv(x, nbr, K, cin, cout, wp, scale, shift, residual, relu, out, n_out)
+            return spconv(x, nbr, K, cin, cout, wp, scale, shift, residual, relu, out, n_out, plist)
         x, ldi = _rows(x, "spconv.x")
         if nbr is not None:
             n_out = nbr.shape[0]
@@ -223,8 +273,19 @@ class SpconvBatch:
         d.shift = shift.data_ptr() if shift is not None else None
         d.residual = residual.data_ptr() if residual is not None else None
         d.ldr, d.out, d.ldo = ldr, out.data_ptr(), ldo
+        prod = None
+        if plist is not None and nbr is not None and ws_supported(K, cin, cout):
+            if plist.n_out != n_out or plist.K != K:
+                raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
+            prod = self.prod.get(plist.p_max * cout)        # launches run in order on one stream: share scratch
+            if prod is None:
+                prod = self.prod[plist.p_max * cout] = plist.prod_scratch(cout)
+            d.plist, d.prod_scratch = plist.blob.data_ptr(), prod.data_ptr()
+            d.p_max, d.p_est = plist.p_max, plist.p_est
+            if not plist.built:
+                d.plist_bytes, plist.built = plist.blob.numel(), True
         self.descs.append(d)
-        self.keep += [x, nbr, wp, scale, shift, residual, out]
+        self.keep += [x, nbr, wp, scale, shift, residual, out, plist, prod]
         return out
 
     def launch(self):
@@ -232,7 +293,7 @@ class SpconvBatch:
             return
         arr = (_lib.SpconvDesc * len(self.descs))(*self.descs)
         check(_lib_().apr_spconv_fwd_batch(arr, len(self.descs), stream()))
-        self.descs, self.keep = [], []
+        self.descs, self.keep, self.prod = [], [], {}
 
 
 # ----------------------------------------------------------------------------

@@ -13,20 +13,45 @@ ops.finalize_maps(maps)
 cm = CoordinateManager(torch.cat([m.coords for m in maps]))
 cm.build_pyramid([2, 4, 8])
 layers = [("b1 32>32 N1", 1, 1, 32, 32, False), ("b2tr 64>64 N1", 1, 1, 64, 64, False), ("c2tr 128>64 2>1", 2, 1, 128, 64, True),
-          ("c2 32>64 1>2", 1, 2, 32, 64, False), ("b2 64>64 N2", 2, 2, 64, 64, False), ("b3 128>128 N3", 4, 4, 128, 128, False),
-          ("b4 256>256 N4", 8, 8, 256, 256, False), ("c4tr 256>128 8>4", 8, 4, 256, 128, True)]
+          ("c2 32>64 1>2", 1, 2, 32, 64, False), ("b2 64>64 N2", 2, 2, 64, 64, False), ("c3 64>128 2>4", 2, 4, 64, 128, False),
+          ("b3 128>128 N3", 4, 4, 128, 128, False), ("c4 128>256 4>8", 4, 8, 128, 256, False),
+          ("b4 256>256 N4", 8, 8, 256, 256, False), ("c4tr 256>128 8>4", 8, 4, 256, 128, True),
+          ("c3tr 256>64 4>2", 4, 2, 256, 64, True)]
+
+
+def timeit(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000 / 20
+
+
 for name, ti, to, cin, cout, tr in layers:
     nbr = cm.kernel_map(ti, to, 3, tr)
     P = int((nbr >= 0).sum())
     x = torch.randn(cm.size(ti), cin, device=dev)
     wp = ops.pack_weights(torch.randn(27, cin, cout, device=dev) * 0.05)
     out = torch.empty(cm.size(to), cout, device=dev)
-    for _ in range(3): ops.spconv(x, nbr, 27, cin, cout, wp, out=out)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20): ops.spconv(x, nbr, 27, cin, cout, wp, out=out)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1000 / 20
-    by = 4.0 * P * (cin + cout) + 8.0 * P
-    print(f"{name:18s} rows={cm.size(to):6d} P={P:7d} {us:7.1f} us  {by/us/1e3:7.1f} GB/s  {2.0*P*cin*cout/us/1e6:6.1f} TF", flush=True)
+    def batched(plist=None, o=out):      # 20 launches through ONE library call: GPU time, not host time
+        b = ops.SpconvBatch()
+        for _ in range(20):
+            b.add(x, nbr, 27, cin, cout, wp, out=o, plist=plist)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); b.launch(); e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1000 / 20
+    ops.spconv(x, nbr, 27, cin, cout, wp, out=out); batched()
+    us = batched()
+    line = f"{name:18s} rows={cm.size(to):6d} P={P:7d} tile {us:7.1f} us {2.0*P*cin*cout/us/1e6:6.1f} TF"
+    if ops.ws_supported(27, cin, cout):
+        t_build = timeit(lambda: ops.build_pairlist(nbr))
+        pl = cm.pair_list(ti, to, 3, tr).build()
+        out2 = torch.empty_like(out)
+        ops.spconv(x, nbr, 27, cin, cout, wp, out=out2, plist=pl); batched(pl, out2)
+        us2 = batched(pl, out2)
+        err = float((out2 - out).norm() / out.norm())
+        line += f" | ws {us2:7.1f} us {2.0*P*cin*cout/us2/1e6:6.1f} TF  (pairlist build {t_build:5.1f} us, rel diff {err:.1e})"
+    print(line, flush=True)

@@ -101,6 +101,36 @@ def test_ransac_full_reference_criteria(dev):
     assert rte < 0.2 and rre < 0.5 and info["inliers"] > 0.15 * 15000
 
 
+def test_ransac_single_round_and_chunked_rounds_agree(dev, monkeypatch):
+    """The fast path (all iterations in one round) and the 2^20-iteration rounds are the same search."""
+    xyz0, xyz1, F0, F1, _ = _synthetic_pair(3, n=4000, inlier=0.3)
+    args = dict(ransac_n=4, edge_length=0.9, max_iteration=2500000, seed=9, return_info=True)
+    T_a, info_a = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, **args)
+    monkeypatch.setenv("APR_RANSAC_FORCE_ROUNDS", "1")
+    T_b, info_b = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, **args)
+    assert info_a == info_b and np.array_equal(T_a, T_b)
+
+
+def test_ransac_hypothesis_list_overflow_replays_in_rounds(dev):
+    """Perfect correspondences: every one of 1.2 M hypotheses survives both checkers, more than the 2^20-entry
+    list holds, so the call must fall back to rounds; all of them are counted and scored."""
+    rng = np.random.default_rng(5)
+    n = 300
+    xyz0 = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+    R = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    xyz1 = (xyz0.astype(np.float64) @ R.T + np.array([1.0, -2.0, 0.5])).astype(np.float32)
+    corr = torch.arange(n, device=dev)
+    T, info = ops.ransac_pose(torch.from_numpy(xyz0).to(dev), torch.from_numpy(xyz1).to(dev), corr, 0.3, 0.9,
+                              max_iter=1200000, seed=2)
+    assert info["n_valid"] == 1200000 and info["inliers"] == n
+    assert np.allclose(T[:3, :3], R, atol=1e-5) and np.allclose(T[:3, 3], [1.0, -2.0, 0.5], atol=1e-4)
+    # the winner is the lowest-rmse hypothesis of ALL rounds: same answer as the oracle on its own iteration
+    T_o, info_o = MO.ransac_feature_matching(xyz0, xyz1, np.arange(n), 0.3, 0.9, max_iter=info["best_iteration"] + 1,
+                                             seed=2) if info["best_iteration"] < 20000 else (None, None)
+    if info_o is not None:
+        assert info_o["best_iteration"] == info["best_iteration"]
+
+
 @pytest.mark.parametrize("seed,weighted", [(0, False), (1, True)])
 def test_irls_matches_oracle_and_recovers_pose(dev, seed, weighted):
     rng = np.random.default_rng(seed)

@@ -55,6 +55,46 @@ def test_spconv_matches_oracle(dev, cin, cout, K, n_in, n_out):
     assert rel_l2(out.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("cin,cout,K,n_in,n_out,density", [
+    (64, 64, 27, 5000, 5000, 0.27), (256, 128, 27, 300, 900, 0.1), (128, 128, 27, 900, 900, 0.3),
+    (384, 128, 27, 500, 1300, 0.08), (192, 64, 8, 700, 257, 0.5),
+    (64, 64, 27, 31, 31, 0.3), (256, 256, 27, 1246, 1246, 0.29), (64, 64, 27, 40000, 40000, 0.27),
+    (64, 64, 27, 500, 500, 0.0), (128, 64, 32, 100, 1000, 1.0), (512, 64, 27, 400, 700, 0.3),
+])
+def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, density):
+    """apr_pairlist_build + apr_spconv_ws_fwd (strided / transposed / deep layers) against the same oracle,
+    with the fused epilogue and strided in / out / residual rows; also bit-stable run to run."""
+    rng = np.random.default_rng(cin * 977 + cout + K + n_out)
+    xw = torch.from_numpy(rng.standard_normal((n_in, cin + 32)).astype(np.float32))
+    x = xw[:, 32:]
+    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32))
+    nbr = _random_map(rng, n_in, n_out, K, density)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    resw = torch.from_numpy(rng.standard_normal((n_out, cout + 64)).astype(np.float32))
+    res = resw[:, :cout]
+    wp = ops.pack_weights(W.to(dev))
+    nbr_d = torch.from_numpy(nbr).to(dev)
+    pl = ops.build_pairlist(nbr_d)
+    outw = torch.zeros(n_out, cout + 32, device=dev)
+    xd, resd = xw.to(dev)[:, 32:], resw.to(dev)[:, :cout]
+    out = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd, relu=True,
+                     out=outw[:, 32:], plist=pl)
+    ref = _oracle_conv(x, nbr, W, scale, shift, res, relu=True)
+    assert rel_l2(out.cpu(), ref) < 2e-6
+    assert float(outw[:, :32].abs().max()) == 0.0          # neighbouring columns untouched
+    # pair lists: ascending output row per offset, ids consistent with the map
+    hdr = pl.blob[:33 * 4].view(torch.int32).cpu().numpy()
+    assert hdr[K] == int((nbr >= 0).sum())
+    assert np.array_equal(np.diff(hdr[:K + 1]), (nbr >= 0).sum(axis=0))
+    again = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd,
+                       relu=True, plist=ops.build_pairlist(nbr_d))
+    assert torch.equal(again, out)
+    # and agrees with the tile kernel to fp32 summation-order noise
+    tile = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd, relu=True)
+    assert rel_l2(tile.cpu(), out.cpu()) < 2e-6
+
+
 def test_spconv_fused_epilogue_and_slices(dev):
     rng = np.random.default_rng(7)
     n, cin, cout, K = 2111, 64, 64, 27
