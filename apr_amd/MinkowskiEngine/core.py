@@ -99,14 +99,7 @@ class CoordinateManager:
         pl = self._plists.get(key)
         if pl is None:
             nbr = self.kernel_map(ts_in, ts_out, kernel_size, transpose)
-            n_fine = self.size(min(ts_in, ts_out))
-            if ts_in != ts_out and kernel_size == 3 and max(ts_in, ts_out) == 2 * min(ts_in, ts_out):
-                # stride-2 maps: a fine voxel meets at most 2 coarse voxels per axis -> <= 8 pairs per fine row
-                # (LiDAR scans measure ~2.2)
-                p_max, p_est = 8 * n_fine, 9 * n_fine // 4
-            else:
-                p_max, p_est = None, 15 * nbr.shape[0] // 2      # same-level 3x3x3 maps measure ~7.5 per row
-            pl = ops.build_pairlist(nbr, p_max, p_est, lazy=True)
+            pl = ops.build_pairlist(nbr, lazy=True)
             self._plists[key] = pl
         return pl
 

@@ -154,6 +154,20 @@ __device__ inline int table_lookup(const unsigned long long* __restrict__ keys,
   return -1;
 }
 
+// keys <- ~0 (empty), vals <- INT-ish max (atomicMin target), status/n_out <- 0: one launch instead of four memsets
+__global__ void k_table_init(unsigned long long* __restrict__ keys, int* __restrict__ vals, int64_t cap,
+                             int* __restrict__ status, int* __restrict__ n_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) {
+    keys[i] = ~0ull;
+    vals[i] = 0x7F7F7F7F;
+  }
+  if (i == 0) {
+    *status = 0;
+    if (n_out) *n_out = 0;
+  }
+}
+
 // One thread per (out row, offset) probe; consecutive lanes -> consecutive offsets of
 // one row, so the nbr store is fully coalesced and the 16-B coordinate load is a
 // broadcast within the wave.
@@ -215,11 +229,10 @@ APR_API int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_
                 (long long)cap);
   APR_CHECK_ARG(scratch_bytes >= apr_map_scratch_bytes(n), "apr_map_build: scratch too small");
   APR_CHECK_ARG(floor_to >= 0, "apr_map_build: floor_to < 0");
-  APR_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, st));
-  APR_HIP(hipMemsetAsync(vals, 0x7F, (size_t)cap * 4, st));
-  APR_HIP(hipMemsetAsync(status, 0, 4, st));
+  hipLaunchKernelGGL(k_table_init, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, (unsigned long long*)keys, vals,
+                     cap, status, n == 0 ? n_out : (int*)nullptr);
   if (n == 0) {
-    APR_HIP(hipMemsetAsync(n_out, 0, 4, st));
+    APR_LAUNCH_CHECK();
     return APR_OK;
   }
   const int nblk = (int)cdiv64(n, kBlock);

@@ -638,7 +638,7 @@ APR_API int apr_spconv_fwd_batch(const apr_spconv_desc* d, int32_t n, void* stre
       }
       int rcw = apr_spconv_ws_fwd(d[i].in, d[i].ldi, d[i].plist, d[i].n_out, d[i].K, d[i].cin, d[i].cout,
                                   d[i].w_packed, d[i].scale, d[i].shift, d[i].residual, d[i].ldr, d[i].relu, d[i].out,
-                                  d[i].ldo, d[i].prod_scratch, d[i].p_max, d[i].p_est, stream);
+                                  d[i].ldo, d[i].prod_scratch, stream);
       if (rcw != APR_OK) return rcw;
       continue;
     }

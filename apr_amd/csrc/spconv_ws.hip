@@ -1,37 +1,37 @@
 // Weight-stationary sparse convolution for maps with FEW pairs per output tile:
 // strided / transposed convolutions and the deep, small levels of the UNet.
 //
-// The tile kernel (spconv.hip) re-reads W[k] for every (32-row tile, offset): with Cin*Cout >= 128*64 and
+// The tile kernel (spconv.hip) re-reads W[k] for every (32-row tile, offset): with Cin*Cout >= 64*64 and
 // only 2-8 pairs per (tile, offset) the weight stream from L2 (100-550 MB per launch) dominates.  Here the
 // kernel map is first turned into per-offset pair lists (one-off per map, cached by the caller):
-//     pairs of offset k, ascending output row:  pair_in[p], pair_out[p];  pair_id[row, k] = p or -1
-// built with wave64 ballot + popcount + a per-offset exclusive scan over row blocks, then
-//   1. k_ws_gemm: a workgroup owns (offset k, 64 consecutive pairs, 64 output channels); the weight piece
-//      W[k][chunk] is staged ONCE per workgroup in LDS (double buffered, one barrier per 64-channel chunk),
-//      each wave gathers its 16 pairs' input rows straight into MFMA operand registers, accumulates over all
-//      Cin chunks in registers (v_mfma_f32_16x16x4_f32, D^T form) and stores prod[p, :] with 16-B stores;
+//     offset k owns the fixed region [k*n_out, k*n_out + cnt[k]) of pair_in[];  pair_id[row, k] = position or -1
+// built by ONE kernel: a block's [256, K] slab of the table goes through LDS, wave64 ballot + popcount ranks the
+// valid entries, one atomicAdd per (block, offset) reserves their range.  Pair positions therefore vary from
+// run to run, the RESULT does not: each product row is computed independently of its position and summed per
+// output row in fixed offset order.  Then
+//   1. k_ws_gemm: a workgroup owns (offset k, 64*G consecutive pairs, 64 output channels); the weight slice
+//      W[k][:, 64 cols] is staged ONCE per workgroup in LDS, each wave gathers its 16 pairs' input rows straight
+//      into MFMA operand registers, accumulates over all Cin chunks in registers (v_mfma_f32_16x16x4_f32,
+//      D^T form) and stores prod[p, :] with 16-B stores;
 //   2. k_ws_reduce: out[j,:] = act((sum_k prod[pair_id[j,k],:]) * scale + shift + residual) in fixed k order.
-// No atomics, bitwise reproducible.  Extra HBM traffic: the [P, Cout] product buffer, written and read once.
+// No float atomics, bitwise reproducible.  Extra HBM traffic: the product rows, written and read once.
 #include "common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kRows = 256;   // rows per block in the pair-list build
+constexpr int kRows = 128;   // rows per block in the pair-list build
 
 struct PairHeader {   // lives at the start of the pair-list blob (device memory)
-  int off[33];        // pair range of offset k: [off[k], off[k+1])
-  int unit_off[33];   // 64-pair work units of offset k: [unit_off[k], unit_off[k+1])
+  int cnt[32];        // pairs of offset k; they sit at pair_in[k * n_out .. k * n_out + cnt[k])
 };
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct PairViews {
   PairHeader* hdr;
-  int* pair_in;
-  int* pair_out;
-  int* pair_id;   // [n_out, K]
-  int* cnt;       // [K, nblk] scratch: per-block counts then exclusive bases
+  int* pair_in;   // [K, n_out] input row of each pair
+  int* pair_id;   // [n_out, K] position of the pair (row, k) or -1
 };
 
 __host__ __device__ inline PairViews carve_pairs(void* blob, int64_t n_out, int K) {
@@ -42,89 +42,64 @@ __host__ __device__ inline PairViews carve_pairs(void* blob, int64_t n_out, int 
   const size_t cap = (size_t)n_out * K;
   v.pair_in = (int*)p;
   p += align256(cap * 4);
-  v.pair_out = (int*)p;
-  p += align256(cap * 4);
   v.pair_id = (int*)p;
-  p += align256(cap * 4);
-  v.cnt = (int*)p;
   return v;
 }
 
-// pass 1 / 3: per (row block, offset) counts, then fill.  FILL = false: counts only.
 // The block's [256, K] slab of the table goes through LDS once (coalesced); wave w then owns offsets
-// w, w+4, ... and walks the 256 rows 64 at a time with ballot + popcount (row stride K ints: conflict-free for
-// odd K, 2-way at worst) — no barrier inside the offset loop.
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_pairs_scan(const int* __restrict__ nbr, int n_out, int K, int nblk,
-                                                    PairViews v) {
+// w, w+4, ... : ballot + popcount over the 256 rows (row stride K ints: conflict-free for odd K), one atomicAdd
+// reserves the block's range in the offset's region, ranks fill it; the id slab is written back coalesced.
+__global__ __launch_bounds__(256) void k_pairs_build(const int* __restrict__ nbr, int n_out, int K, PairViews v) {
   __shared__ int s_nbr[kRows * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int blk = blockIdx.x;
-  const int row0 = blk * kRows;
+  const int row0 = blockIdx.x * kRows;
   const int rows = min(kRows, n_out - row0);
   const int total = rows * K;
   const int* src = nbr + (int64_t)row0 * K;
   for (int e = threadIdx.x; e < total; e += 256) s_nbr[e] = src[e];
   __syncthreads();
-  for (int k = wave; k < K; k += 4) {
-    int run = 0;
-    if (FILL) run = v.hdr->off[k] + v.cnt[k * nblk + blk];
+  // phase 1: counts of this wave's offsets, all range reservations in flight together (one L2 round trip)
+  int base[8];
 #pragma unroll
-    for (int c = 0; c < kRows / 64; ++c) {
-      const int r = c * 64 + lane;
-      const int idx = (r < rows) ? s_nbr[r * K + k] : -1;
-      const unsigned long long m = __ballot(idx >= 0);
-      if (FILL && r < rows) {
-        int pos = -1;
-        if (idx >= 0) {
-          pos = run + __popcll(m & ((1ull << lane) - 1ull));
-          v.pair_in[pos] = idx;
-          v.pair_out[pos] = row0 + r;
+  for (int s = 0; s < 8; ++s) {
+    const int k = wave + 4 * s;
+    base[s] = 0;
+    if (k < K) {
+      int cnt = 0;
+#pragma unroll
+      for (int c = 0; c < kRows / 64; ++c) {
+        const int r = c * 64 + lane;
+        cnt += __popcll(__ballot(r < rows && s_nbr[r * K + k] >= 0));
+      }
+      if (lane == 0 && cnt) base[s] = atomicAdd(&v.hdr->cnt[k], cnt);
+    }
+  }
+  // phase 2: ranks -> positions
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = wave + 4 * s;
+    if (k < K) {
+      int run = __shfl(base[s], 0) + k * n_out;
+#pragma unroll
+      for (int c = 0; c < kRows / 64; ++c) {
+        const int r = c * 64 + lane;
+        const int idx = (r < rows) ? s_nbr[r * K + k] : -1;
+        const unsigned long long m = __ballot(idx >= 0);
+        if (r < rows) {
+          int pos = -1;
+          if (idx >= 0) {
+            pos = run + __popcll(m & ((1ull << lane) - 1ull));
+            v.pair_in[pos] = idx;
+          }
+          s_nbr[r * K + k] = pos;
         }
-        s_nbr[r * K + k] = pos;
+        run += __popcll(m);
       }
-      run += __popcll(m);
     }
-    if (!FILL && lane == 0) v.cnt[k * nblk + blk] = run;
-  }
-  if (FILL) {
-    __syncthreads();
-    int* dst = v.pair_id + (int64_t)row0 * K;
-    for (int e = threadIdx.x; e < total; e += 256) dst[e] = s_nbr[e];   // coalesced write of the id slab
-  }
-}
-
-// pass 2: per offset, exclusive scan of the block counts (one wave per offset), then the offset prefix
-__global__ __launch_bounds__(1024) void k_pairs_offsets(int K, int nblk, PairViews v) {
-  __shared__ int s_total[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = wave; k < K; k += 16) {
-    int carry = 0;
-    for (int base = 0; base < nblk; base += 64) {
-      const int i = base + lane;
-      const int c = i < nblk ? v.cnt[k * nblk + i] : 0;
-      int incl = c;
-      for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-      }
-      if (i < nblk) v.cnt[k * nblk + i] = carry + incl - c;
-      carry += __shfl(incl, 63);
-    }
-    if (lane == 0) s_total[k] = carry;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int o = 0, u = 0;
-    for (int k = 0; k < K; ++k) {
-      v.hdr->off[k] = o;
-      v.hdr->unit_off[k] = u;
-      o += s_total[k];
-      u += (s_total[k] + 63) >> 6;
-    }
-    v.hdr->off[K] = o;
-    v.hdr->unit_off[K] = u;
-  }
+  int* dst = v.pair_id + (int64_t)row0 * K;
+  for (int e = threadIdx.x; e < total; e += 256) dst[e] = s_nbr[e];
 }
 
 // Work unit = (offset k, block of 64*G consecutive pairs of k, 64 output channels); G is chosen ON THE DEVICE
@@ -135,7 +110,7 @@ __global__ __launch_bounds__(1024) void k_pairs_offsets(int K, int nblk, PairVie
 // (conflict-free ds_read_b128), cin/64 * 64 MFMAs into 16 accumulator registers.
 __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in, int64_t ldi, PairViews v, int K,
                                                     int cin, int cout, const float* __restrict__ wp,
-                                                    float* __restrict__ prod, int p_cap) {
+                                                    float* __restrict__ prod, int n_out) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];   // [g = cin/4][col 64][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
@@ -143,13 +118,14 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
   const int cinG = cin >> 2;
   const int nchunk = cin >> 6;   // cin % 64 == 0 on this path
   // unit table in registers: every wave redoes the 32-entry scan (no LDS, no barrier)
-  const int o0 = (lane <= K) ? v.hdr->off[lane] : 0;
-  const int o1 = __shfl_down(o0, 1);
-  const int P = __shfl(o0, K);
+  const int cnt_l = (lane < K) ? v.hdr->cnt[lane] : 0;
+  int P = cnt_l;
+  for (int d = 16; d >= 1; d >>= 1) P += __shfl_xor(P, d);
+  P = __shfl(P, 0);   // lanes >= 32 hold no offsets
   int G = (int)(((int64_t)(P >> 6) * gridDim.y) / 768);
   G = G < 1 ? 1 : (G > 16 ? 16 : G);
   const int span = 64 * G;
-  const int units = (lane < K) ? (o1 - o0 + span - 1) / span : 0;
+  const int units = (cnt_l + span - 1) / span;
   int incl = units;
   for (int d = 1; d < 32; d <<= 1) {
     const int t = __shfl_up(incl, d);
@@ -160,8 +136,9 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
   for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
     const int k = __popcll(__ballot(lane < K && incl <= unit));
     const int excl = __shfl(incl - units, k);
-    const int p_begin = __shfl(o0, k) + (unit - excl) * span;
-    const int p_end = min(p_begin + span, __shfl(o1, k));
+    const int region = k * n_out;
+    const int p_begin = region + (unit - excl) * span;
+    const int p_end = min(p_begin + span, region + __shfl(cnt_l, k));
     const int ngroups = (p_end - p_begin + 15) >> 4;
 
     // first group's rows (index load overlaps the weight staging)
@@ -217,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
         }
       }
       // D^T: lane (r16 = pair, q) holds channels cb*16 + 4q .. +3 of its pair
-      if (my_p < p_end && my_p < p_cap) {
+      if (my_p < p_end) {
         float* dst = prod + (int64_t)my_p * cout + col0 + q * 4;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(dst + cb * 16) = acc[cb];
@@ -268,8 +245,7 @@ __global__ __launch_bounds__(256) void k_ws_reduce(const float* __restrict__ pro
 }  // namespace
 
 APR_API size_t apr_pairlist_bytes(int64_t n_out, int32_t K) {
-  const int64_t nblk = cdiv64(n_out > 0 ? n_out : 1, kRows);
-  return align256(sizeof(PairHeader)) + 3 * align256((size_t)n_out * K * 4) + align256((size_t)K * nblk * 4) + 256;
+  return align256(sizeof(PairHeader)) + 2 * align256((size_t)(n_out > 0 ? n_out : 1) * K * 4) + 256;
 }
 
 APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, void* plist, size_t plist_bytes,
@@ -277,11 +253,9 @@ APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, voi
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 32, "apr_pairlist_build: bad n_out / K");
   APR_CHECK_ARG(plist_bytes >= apr_pairlist_bytes(n_out, K), "apr_pairlist_build: blob too small");
-  const int nblk = (int)cdiv64(n_out, kRows);
   PairViews v = carve_pairs(plist, n_out, K);
-  hipLaunchKernelGGL(k_pairs_scan<false>, dim3(nblk), dim3(256), 0, st, nbr, (int)n_out, K, nblk, v);
-  hipLaunchKernelGGL(k_pairs_offsets, dim3(1), dim3(1024), 0, st, K, nblk, v);
-  hipLaunchKernelGGL(k_pairs_scan<true>, dim3(nblk), dim3(256), 0, st, nbr, (int)n_out, K, nblk, v);
+  APR_HIP(hipMemsetAsync(v.hdr, 0, sizeof(PairHeader), st));
+  hipLaunchKernelGGL(k_pairs_build, dim3((unsigned)cdiv64(n_out, kRows)), dim3(256), 0, st, nbr, (int)n_out, K, v);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -289,20 +263,18 @@ APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, voi
 APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, int64_t n_out, int32_t K, int32_t cin,
                               int32_t cout, const float* w_packed, const float* scale, const float* shift,
                               const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
-                              float* prod_scratch, int64_t p_max, int64_t p_est, void* stream) {
+                              float* prod_scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  APR_CHECK_ARG(n_out > 0 && K >= 1 && K <= 32, "apr_spconv_ws_fwd: bad n_out / K");
+  APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 32, "apr_spconv_ws_fwd: bad n_out / K");
   APR_CHECK_ARG(cin % 64 == 0 && cin <= 512 && cout % 64 == 0,
                 "apr_spconv_ws_fwd: needs cin %% 64 == 0, cin <= 512 and cout %% 64 == 0");
   APR_CHECK_ARG(ldi % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out) | ((uintptr_t)prod_scratch)) & 15) == 0,
                 "apr_spconv_ws_fwd: 16-byte aligned rows required");
   APR_CHECK_ARG(!residual || (ldr % 4 == 0 && (((uintptr_t)residual) & 15) == 0), "apr_spconv_ws_fwd: residual alignment");
   PairViews v = carve_pairs(const_cast<void*>(plist), n_out, K);
-  (void)p_est;
-  const int64_t p_bound = (p_max > 0 && p_max < n_out * (int64_t)K) ? p_max : n_out * (int64_t)K;
-  // fixed grid striding over the device-side unit list: <= ~1024 workgroups, never more than the pair bound needs
+  // fixed grid striding over the device-side unit list: <= ~1024 workgroups, never more than the map can need
   int64_t gx = cdiv64(1024, cout / 64);
-  const int64_t need = cdiv64(p_bound, 64) + K;
+  const int64_t need = cdiv64(n_out * (int64_t)K, 64) + K;
   if (gx > need) gx = need;
   const unsigned units = (unsigned)gx;
   const size_t lds = (size_t)cin * 64 * 4;
@@ -312,7 +284,7 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, i
     s_attr = true;
   }
   hipLaunchKernelGGL(k_ws_gemm, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,
-                     prod_scratch, (int)p_bound);
+                     prod_scratch, (int)n_out);
   const dim3 rgrid((unsigned)cdiv64(n_out * (cout / 4), 256));
   if (K <= 8)
     hipLaunchKernelGGL(k_ws_reduce<8>, rgrid, dim3(256), 0, st, prod_scratch, v, n_out, K, cout, scale, shift, residual,

@@ -158,19 +158,18 @@ PROFILE = None  # set to a SpconvProfile to time launches
 
 
 class PairList:
-    """Per-offset pair lists of one kernel map (apr_pairlist_build): device blob + pair-count bounds.
+    """Per-offset pair lists of one kernel map (apr_pairlist_build): a device blob.
 
     `built` False: the blob is only allocated; the first launch of a SpconvBatch that uses it builds it inside
     the same library call (no extra host round trip)."""
 
-    def __init__(self, blob, nbr, p_max, p_est, built):
+    def __init__(self, blob, nbr, built):
         self.blob, self.nbr, self.built = blob, nbr, built
         self.n_out, self.K = nbr.shape
-        self.p_max = min(int(p_max), self.n_out * self.K) if p_max else self.n_out * self.K
-        self.p_est = min(int(p_est), self.p_max) if p_est else 0
 
     def prod_scratch(self, cout):
-        return torch.empty(self.p_max * cout, dtype=torch.float32, device=self.blob.device)
+        """Product rows [K * n_out, cout]; offset k uses the head of its own n_out-row region."""
+        return torch.empty(self.n_out * self.K * cout, dtype=torch.float32, device=self.blob.device)
 
     def build(self):
         if not self.built:
@@ -179,15 +178,18 @@ class PairList:
             self.built = True
         return self
 
+    def counts(self):
+        """Pairs per offset (host sync; tests / diagnostics)."""
+        return self.build().blob[:self.K * 4].view(torch.int32).cpu().numpy()
 
-def build_pairlist(nbr, p_max=None, p_est=None, lazy=False):
-    """nbr int32 [n_out, K] -> PairList.  p_max bounds the number of valid entries (default n_out*K), p_est is
-    the expected number (work-unit sizing hint)."""
+
+def build_pairlist(nbr, lazy=False):
+    """nbr int32 [n_out, K] -> PairList."""
     if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2:
         raise _lib.AprHipError("build_pairlist: nbr must be a contiguous int32 [n_out, K] tensor")
     n_out, K = nbr.shape
     nb = int(_lib_().apr_pairlist_bytes(n_out, K))
-    pl = PairList(torch.empty(nb, dtype=torch.uint8, device=nbr.device), nbr, p_max, p_est, False)
+    pl = PairList(torch.empty(nb, dtype=torch.uint8, device=nbr.device), nbr, False)
     return pl if lazy else pl.build()
 
 
@@ -232,7 +234,7 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         prod = plist.build().prod_scratch(cout)
         check(_lib_().apr_spconv_ws_fwd(ptr(x), ldi, ptr(plist.blob), n_out, K, cin, cout, ptr(wp), ptr(scale),
                                         ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, ptr(prod),
-                                        plist.p_max, plist.p_est, stream()))
+                                        stream()))
     else:
         check(_lib_().apr_spconv_fwd(ptr(x), ldi, ptr(nbr), n_out, K, cin, cout, ptr(wp), ptr(scale), ptr(shift),
                                      ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
@@ -277,11 +279,11 @@ class SpconvBatch:
         if plist is not None and nbr is not None and ws_supported(K, cin, cout):
             if plist.n_out != n_out or plist.K != K:
                 raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
-            prod = self.prod.get(plist.p_max * cout)        # launches run in order on one stream: share scratch
+            need = plist.n_out * plist.K * cout      # launches run in order on one stream: share the scratch
+            prod = self.prod.get(need)
             if prod is None:
-                prod = self.prod[plist.p_max * cout] = plist.prod_scratch(cout)
+                prod = self.prod[need] = plist.prod_scratch(cout)
             d.plist, d.prod_scratch = plist.blob.data_ptr(), prod.data_ptr()
-            d.p_max, d.p_est = plist.p_max, plist.p_est
             if not plist.built:
                 d.plist_bytes, plist.built = plist.blob.numel(), True
         self.descs.append(d)

@@ -34,8 +34,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="ResUNetBN2C")
     ap.add_argument("--n-out", type=int, default=32)
     ap.add_argument("--ransac-iters", type=int, default=4000000)

@@ -118,16 +118,15 @@ int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_o
 /* Weight-stationary variant for maps with few pairs per output tile (strided / transposed convs, deep levels):
  * the kernel map is first turned into per-offset pair lists (apr_pairlist_build, once per map), then every
  * (offset, 64 pairs, 64 channels) work unit stages its weight piece once, writes per-pair products to
- * prod_scratch f32[P <= n_out*K, cout], and a second kernel sums them per output row in fixed offset order
+ * prod_scratch, and a second kernel sums them per output row in fixed offset order
  * with the same fused epilogue as apr_spconv_fwd.  Needs cin % 64 == 0, cin <= 512, cout % 64 == 0, K <= 32.
- * p_max: rows of prod_scratch = a bound on the number of pairs (0: n_out*K); p_est: expected number of pairs,
- * only used to size the work units (0: n_out*K/4). */
+ * prod_scratch holds n_out*K rows of cout floats (offset k owns rows [k*n_out, (k+1)*n_out), sparsely used). */
 size_t apr_pairlist_bytes(int64_t n_out, int32_t K);
 int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, void* plist, size_t plist_bytes, void* stream);
 int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, int64_t n_out, int32_t K, int32_t cin,
                       int32_t cout, const float* w_packed, const float* scale, const float* shift,
                       const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
-                      float* prod_scratch, int64_t p_max, int64_t p_est, void* stream);
+                      float* prod_scratch, void* stream);
 
 /* One launch description of apr_spconv_fwd; apr_spconv_fwd_batch enqueues n of them back to back
  * from a single call (the 23 fused conv launches of one ResUNet encode), so a host binding pays
@@ -139,8 +138,7 @@ typedef struct apr_spconv_desc {
   const float* residual; int64_t ldr;
   float* out; int64_t ldo;
   void* plist;            /* non-NULL: run this launch through apr_spconv_ws_fwd with ... */
-  float* prod_scratch;    /* ... this product buffer, */
-  int64_t p_max, p_est;   /* ... these pair bounds; */
+  float* prod_scratch;    /* ... this product buffer (n_out*K rows); */
   int64_t plist_bytes;    /* > 0: apr_pairlist_build(nbr -> plist) first (first use of the map in the batch) */
 } apr_spconv_desc;
 int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* stream);
