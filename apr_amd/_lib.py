@@ -47,12 +47,15 @@ PROTOTYPES = {
     "apr_pairlist_build": (C.c_int, [_p, _i64, _i32, _p, _sz, _p]),
     "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "apr_spconv_fwd_batch": (C.c_int, [_p, _i32, _p]),
+    "apr_spconv_fwd_batch_timed": (C.c_int, [_p, _i32, _p, _p]),
     "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     "apr_norm_params": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _p, _p, _sz, _p]),
     "apr_bn_stats_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _p]),
     "apr_l2_normalize": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
     "apr_feature_nn": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p]),
+    "apr_feature_nn_fast_scratch_bytes": (_sz, [_i64, _i64, _i32]),
+    "apr_feature_nn_fast": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p, _sz, _p]),
     "apr_nn_unpack": (C.c_int, [_p, _i64, _p, _p, _p]),
     "apr_ransac_scratch_bytes": (_sz, [_i64, _i64]),
     "apr_ransac_pose": (C.c_int, [_p, _i64, _p, _i64, _p, _f64, _f64, _i64, _u64, _p, _sz, _p, _p]),

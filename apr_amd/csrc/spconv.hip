@@ -628,23 +628,55 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
   return APR_OK;
 }
 
+static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e0, hipEvent_t e1) {
+  hipStream_t st = (hipStream_t)stream;
+  if (d.plist) {
+    if (d.plist_bytes > 0) {   // the pair-list build is per map, not part of the timed conv layer
+      int rcb = apr_pairlist_build(d.nbr, d.n_out, d.K, d.plist, (size_t)d.plist_bytes, stream);
+      if (rcb != APR_OK) return rcb;
+    }
+    if (e0) APR_HIP(hipEventRecord(e0, st));
+    int rcw = apr_spconv_ws_fwd(d.in, d.ldi, d.plist, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.scale, d.shift,
+                                d.residual, d.ldr, d.relu, d.out, d.ldo, d.prod_scratch, stream);
+    if (rcw != APR_OK) return rcw;
+  } else {
+    if (e0) APR_HIP(hipEventRecord(e0, st));
+    int rc = apr_spconv_fwd(d.in, d.ldi, d.nbr, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.scale, d.shift, d.residual,
+                            d.ldr, d.relu, d.out, d.ldo, stream);
+    if (rc != APR_OK) return rc;
+  }
+  if (e1) APR_HIP(hipEventRecord(e1, st));
+  return APR_OK;
+}
+
 APR_API int apr_spconv_fwd_batch(const apr_spconv_desc* d, int32_t n, void* stream) {
   APR_CHECK_ARG(n >= 0 && (d != nullptr || n == 0), "apr_spconv_fwd_batch: bad arguments");
   for (int i = 0; i < n; ++i) {
-    if (d[i].plist) {
-      if (d[i].plist_bytes > 0) {
-        int rcb = apr_pairlist_build(d[i].nbr, d[i].n_out, d[i].K, d[i].plist, (size_t)d[i].plist_bytes, stream);
-        if (rcb != APR_OK) return rcb;
-      }
-      int rcw = apr_spconv_ws_fwd(d[i].in, d[i].ldi, d[i].plist, d[i].n_out, d[i].K, d[i].cin, d[i].cout,
-                                  d[i].w_packed, d[i].scale, d[i].shift, d[i].residual, d[i].ldr, d[i].relu, d[i].out,
-                                  d[i].ldo, d[i].prod_scratch, stream);
-      if (rcw != APR_OK) return rcw;
-      continue;
-    }
-    int rc = apr_spconv_fwd(d[i].in, d[i].ldi, d[i].nbr, d[i].n_out, d[i].K, d[i].cin, d[i].cout, d[i].w_packed,
-                            d[i].scale, d[i].shift, d[i].residual, d[i].ldr, d[i].relu, d[i].out, d[i].ldo, stream);
+    int rc = spconv_batch_one(d[i], stream, nullptr, nullptr);
     if (rc != APR_OK) return rc;
   }
   return APR_OK;
+}
+
+APR_API int apr_spconv_fwd_batch_timed(const apr_spconv_desc* d, int32_t n, float* layer_ms, void* stream) {
+  APR_CHECK_ARG(n >= 0 && n <= 4096 && (d != nullptr || n == 0) && (layer_ms != nullptr || n == 0),
+                "apr_spconv_fwd_batch_timed: bad arguments");
+  hipEvent_t* ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (size_t)(n > 0 ? n : 1));
+  int made = 0, rc = APR_OK;
+  for (; made < 2 * n; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) {
+      apr_set_error("apr_spconv_fwd_batch_timed: hipEventCreate failed");
+      rc = APR_EHIP;
+      break;
+    }
+  for (int i = 0; rc == APR_OK && i < n; ++i) rc = spconv_batch_one(d[i], stream, ev[2 * i], ev[2 * i + 1]);
+  if (rc == APR_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    apr_set_error("apr_spconv_fwd_batch_timed: stream synchronize failed");
+    rc = APR_EHIP;
+  }
+  for (int i = 0; rc == APR_OK && i < n; ++i)
+    if (hipEventElapsedTime(&layer_ms[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) layer_ms[i] = -1.f;
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  free(ev);
+  return rc;
 }

@@ -20,7 +20,9 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kRows = 128;   // rows per block in the pair-list build
+constexpr int kRows = 512;   // rows per block in the pair-list build (fewer, larger blocks: the K range counters are
+                             // contended by every block, ~55 atomics per address on a 28 k-row map)
+constexpr int kBuildWaves = 8;
 
 struct PairHeader {   // lives at the start of the pair-list blob (device memory)
   int cnt[32];        // pairs of offset k; they sit at pair_in[k * n_out .. k * n_out + cnt[k])
@@ -49,20 +51,34 @@ __host__ __device__ inline PairViews carve_pairs(void* blob, int64_t n_out, int 
 // The block's [256, K] slab of the table goes through LDS once (coalesced); wave w then owns offsets
 // w, w+4, ... : ballot + popcount over the 256 rows (row stride K ints: conflict-free for odd K), one atomicAdd
 // reserves the block's range in the offset's region, ranks fill it; the id slab is written back coalesced.
-__global__ __launch_bounds__(256) void k_pairs_build(const int* __restrict__ nbr, int n_out, int K, PairViews v) {
-  __shared__ int s_nbr[kRows * 32];
+__global__ __launch_bounds__(64 * kBuildWaves) void k_pairs_build(const int* __restrict__ nbr, int n_out, int K, PairViews v) {
+  __shared__ int s_nbr[kRows * 27 + 64];   // K <= 27 on this path (larger K: see apr_pairlist_build)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * kRows;
   const int rows = min(kRows, n_out - row0);
   const int total = rows * K;
   const int* src = nbr + (int64_t)row0 * K;
-  for (int e = threadIdx.x; e < total; e += 256) s_nbr[e] = src[e];
+  // 9 independent loads in flight per thread before the first LDS store (a plain copy loop serialises one L2
+  // round trip per iteration)
+  for (int e0 = threadIdx.x; e0 < total; e0 += 9 * 64 * kBuildWaves) {
+    int t[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int e = e0 + u * 64 * kBuildWaves;
+      t[u] = (e < total) ? src[e] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int e = e0 + u * 64 * kBuildWaves;
+      if (e < total) s_nbr[e] = t[u];
+    }
+  }
   __syncthreads();
   // phase 1: counts of this wave's offsets, all range reservations in flight together (one L2 round trip)
-  int base[8];
+  int base[4];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int k = wave + 4 * s;
+  for (int s = 0; s < 4; ++s) {
+    const int k = wave + kBuildWaves * s;
     base[s] = 0;
     if (k < K) {
       int cnt = 0;
@@ -76,8 +92,8 @@ __global__ __launch_bounds__(256) void k_pairs_build(const int* __restrict__ nbr
   }
   // phase 2: ranks -> positions
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int k = wave + 4 * s;
+  for (int s = 0; s < 4; ++s) {
+    const int k = wave + kBuildWaves * s;
     if (k < K) {
       int run = __shfl(base[s], 0) + k * n_out;
 #pragma unroll
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(256) void k_pairs_build(const int* __restrict__ nbr
   }
   __syncthreads();
   int* dst = v.pair_id + (int64_t)row0 * K;
-  for (int e = threadIdx.x; e < total; e += 256) dst[e] = s_nbr[e];
+  for (int e = threadIdx.x; e < total; e += 64 * kBuildWaves) dst[e] = s_nbr[e];
 }
 
 // Work unit = (offset k, block of 64*G consecutive pairs of k, 64 output channels); G is chosen ON THE DEVICE
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(256) void k_pairs_build(const int* __restrict__ nbr
 // (conflict-free ds_read_b128), cin/64 * 64 MFMAs into 16 accumulator registers.
 __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in, int64_t ldi, PairViews v, int K,
                                                     int cin, int cout, const float* __restrict__ wp,
-                                                    float* __restrict__ prod, int n_out) {
+                                                    float* __restrict__ prod, int n_out, int target_units) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];   // [g = cin/4][col 64][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
@@ -122,7 +138,8 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
   int P = cnt_l;
   for (int d = 16; d >= 1; d >>= 1) P += __shfl_xor(P, d);
   P = __shfl(P, 0);   // lanes >= 32 hold no offsets
-  int G = (int)(((int64_t)(P >> 6) * gridDim.y) / 768);
+  // pairs per unit: as few as possible (parallelism) while all units fit the chip in ONE round of workgroups
+  int G = (int)((((int64_t)(P + 63) >> 6) * gridDim.y + target_units - 1) / target_units);
   G = G < 1 ? 1 : (G > 16 ? 16 : G);
   const int span = 64 * G;
   const int units = (cnt_l + span - 1) / span;
@@ -251,11 +268,13 @@ APR_API size_t apr_pairlist_bytes(int64_t n_out, int32_t K) {
 APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, void* plist, size_t plist_bytes,
                                void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 32, "apr_pairlist_build: bad n_out / K");
+  APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 27,
+                "apr_pairlist_build: needs 0 < n_out < 2^26 and 1 <= K <= 27");
   APR_CHECK_ARG(plist_bytes >= apr_pairlist_bytes(n_out, K), "apr_pairlist_build: blob too small");
   PairViews v = carve_pairs(plist, n_out, K);
   APR_HIP(hipMemsetAsync(v.hdr, 0, sizeof(PairHeader), st));
-  hipLaunchKernelGGL(k_pairs_build, dim3((unsigned)cdiv64(n_out, kRows)), dim3(256), 0, st, nbr, (int)n_out, K, v);
+  hipLaunchKernelGGL(k_pairs_build, dim3((unsigned)cdiv64(n_out, kRows)), dim3(64 * kBuildWaves), 0, st, nbr,
+                     (int)n_out, K, v);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -265,26 +284,33 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, i
                               const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
                               float* prod_scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 32, "apr_spconv_ws_fwd: bad n_out / K");
+  APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 27, "apr_spconv_ws_fwd: bad n_out / K");
   APR_CHECK_ARG(cin % 64 == 0 && cin <= 512 && cout % 64 == 0,
                 "apr_spconv_ws_fwd: needs cin %% 64 == 0, cin <= 512 and cout %% 64 == 0");
   APR_CHECK_ARG(ldi % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out) | ((uintptr_t)prod_scratch)) & 15) == 0,
                 "apr_spconv_ws_fwd: 16-byte aligned rows required");
   APR_CHECK_ARG(!residual || (ldr % 4 == 0 && (((uintptr_t)residual) & 15) == 0), "apr_spconv_ws_fwd: residual alignment");
   PairViews v = carve_pairs(const_cast<void*>(plist), n_out, K);
-  // fixed grid striding over the device-side unit list: <= ~1024 workgroups, never more than the map can need
-  int64_t gx = cdiv64(1024, cout / 64);
+  // The weight slice in LDS limits residency to floor(160 KB / slice) workgroups per CU; more units than resident
+  // slots means a second round of workgroups behind the first (measured: 29 us vs 15 us on the 256-channel level).
+  // target = the slots (<= 768); the kernel sizes its units from the real pair count to fit, and a grid of that
+  // many workgroups strides over them.
+  const size_t lds = (size_t)cin * 64 * 4;
+  int64_t per_cu = (160 * 1024) / (int64_t)lds;
+  if (per_cu > 8) per_cu = 8;
+  int64_t target = 256 * per_cu;
+  if (target > 768) target = 768;
+  int64_t gx = cdiv64(target, cout / 64);
   const int64_t need = cdiv64(n_out * (int64_t)K, 64) + K;
   if (gx > need) gx = need;
   const unsigned units = (unsigned)gx;
-  const size_t lds = (size_t)cin * 64 * 4;
   static bool s_attr = false;
   if (!s_attr) {
     APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     s_attr = true;
   }
   hipLaunchKernelGGL(k_ws_gemm, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,
-                     prod_scratch, (int)n_out);
+                     prod_scratch, (int)n_out, (int)target);
   const dim3 rgrid((unsigned)cdiv64(n_out * (cout / 4), 256));
   if (K <= 8)
     hipLaunchKernelGGL(k_ws_reduce<8>, rgrid, dim3(256), 0, st, prod_scratch, v, n_out, K, cout, scale, shift, residual,

@@ -29,7 +29,7 @@ from .residual_block import get_block
 
 # stages of the fused plan that take the weight-stationary conv path (few pairs per tile, large Cin*Cout);
 # measured per layer on MI355X (scripts/layer_bench.py), override with APR_WS_STAGES="conv3,block4,..." / "none"
-WS_STAGES = ("block2", "block3", "conv4_tr", "block4_tr", "conv3_tr", "block3_tr", "conv2_tr", "block2_tr")
+WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", "block3_tr", "conv2_tr", "block2_tr")
 
 
 def _ws_stages():

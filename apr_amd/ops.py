@@ -7,6 +7,7 @@ library is missing).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -140,18 +141,22 @@ class SpconvProfile:
         return int((nbr >= 0).sum().item())  # not cached: map storage is recycled between pairs
 
     def summary(self):
-        """-> dict with algorithmic bytes / flops and summed kernel time of the MFMA launches."""
+        """-> algorithmic bytes / flops and summed time of the MFMA conv layers, in total and per kernel path
+        ("tile" = k_spconv_pairs, "ws" = k_ws_gemm + k_ws_reduce)."""
         torch.cuda.synchronize()
-        tot_b = tot_f = tot_ms = 0.0
-        n = 0
-        for (P, cin, cout, mfma, e0, e1) in self.records:
+        tot = dict(launches=0, bytes=0.0, flops=0.0, ms=0.0)
+        by = {}
+        for (P, cin, cout, mfma, e0, e1, path) in self.records:
             if not mfma:
                 continue
-            tot_b += 4.0 * P * (cin + cout) + 8.0 * P
-            tot_f += 2.0 * P * cin * cout
-            tot_ms += e0.elapsed_time(e1)
-            n += 1
-        return dict(launches=n, bytes=tot_b, flops=tot_f, ms=tot_ms)
+            ms = e0 if e1 is None else e0.elapsed_time(e1)     # batch launches carry milliseconds directly
+            for d in (tot, by.setdefault(path, dict(launches=0, bytes=0.0, flops=0.0, ms=0.0))):
+                d["launches"] += 1
+                d["bytes"] += 4.0 * P * (cin + cout) + 8.0 * P
+                d["flops"] += 2.0 * P * cin * cout
+                d["ms"] += ms
+        tot["by_path"] = by
+        return tot
 
 
 PROFILE = None  # set to a SpconvProfile to time launches
@@ -194,7 +199,7 @@ def build_pairlist(nbr, lazy=False):
 
 
 def ws_supported(K, cin, cout):
-    return K <= 32 and cin % 64 == 0 and cin <= 512 and cout % 64 == 0
+    return K <= 27 and cin % 64 == 0 and cin <= 512 and cout % 64 == 0
 
 
 def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
@@ -223,15 +228,17 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         residual, ldr = _rows(residual, "spconv.residual")
         if residual.shape[0] != n_out or residual.shape[1] != cout:
             raise _lib.AprHipError("spconv: residual shape mismatch")
+    use_ws = plist is not None and nbr is not None and ws_supported(K, cin, cout)
+    if use_ws:
+        if plist.n_out != n_out or plist.K != K:
+            raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
+        prod = plist.build().prod_scratch(cout)
     prof = PROFILE
     if prof is not None:
         P = prof.pairs(nbr, n_out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if plist is not None and nbr is not None and ws_supported(K, cin, cout):
-        if plist.n_out != n_out or plist.K != K:
-            raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
-        prod = plist.build().prod_scratch(cout)
+    if use_ws:
         check(_lib_().apr_spconv_ws_fwd(ptr(x), ldi, ptr(plist.blob), n_out, K, cin, cout, ptr(wp), ptr(scale),
                                         ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, ptr(prod),
                                         stream()))
@@ -240,7 +247,8 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
                                      ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
     if prof is not None:
         e1.record()
-        prof.records.append((P, cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0, e0, e1))
+        prof.records.append((P, cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0, e0, e1,
+                             "ws" if use_ws else "tile"))
     return out
 
 
@@ -251,11 +259,10 @@ class SpconvBatch:
         self.descs = []
         self.keep = []      # tensors referenced by raw pointers stay alive until the launch call returns
         self.prod = {}      # weight-stationary product buffers by size
+        self.meta = []      # (P, cin, cout, mfma?, path) per launch while a SpconvProfile is active
 
     def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
             plist=None):
-        if PROFILE is not None:     # per-launch timing requested: fall back to immediate launches
-            return spconv(x, nbr, K, cin, cout, wp, scale, shift, residual, relu, out, n_out, plist)
         x, ldi = _rows(x, "spconv.x")
         if nbr is not None:
             n_out = nbr.shape[0]
@@ -287,6 +294,9 @@ class SpconvBatch:
             if not plist.built:
                 d.plist_bytes, plist.built = plist.blob.numel(), True
         self.descs.append(d)
+        if PROFILE is not None:
+            self.meta.append((PROFILE.pairs(nbr, n_out), cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0,
+                              "ws" if prod is not None else "tile"))
         self.keep += [x, nbr, wp, scale, shift, residual, out, plist, prod]
         return out
 
@@ -294,8 +304,13 @@ class SpconvBatch:
         if not self.descs:
             return
         arr = (_lib.SpconvDesc * len(self.descs))(*self.descs)
-        check(_lib_().apr_spconv_fwd_batch(arr, len(self.descs), stream()))
-        self.descs, self.keep, self.prod = [], [], {}
+        if PROFILE is not None and len(self.meta) == len(self.descs):
+            ms = (C.c_float * len(self.descs))()
+            check(_lib_().apr_spconv_fwd_batch_timed(arr, len(self.descs), ms, stream()))
+            PROFILE.records += [m[:4] + (float(t), None, m[4]) for m, t in zip(self.meta, ms)]
+        else:
+            check(_lib_().apr_spconv_fwd_batch(arr, len(self.descs), stream()))
+        self.descs, self.keep, self.prod, self.meta = [], [], {}, []
 
 
 # ----------------------------------------------------------------------------
@@ -356,8 +371,14 @@ def l2_normalize(x, out=None):
 # matching / pose
 # ----------------------------------------------------------------------------
 
-def feature_nn(f0, f1, return_distance=False):
-    """Squared-L2 nearest neighbour of every row of f0 in f1 -> int64 [n0] (and d2 f32 [n0])."""
+def feature_nn(f0, f1, return_distance=False, impl=None):
+    """Squared-L2 nearest neighbour of every row of f0 in f1 -> int64 [n0] (and d2 f32 [n0]).
+
+    impl "brute" (default): every distance in exact fp32, cost independent of the data (294 us for a 14 k x 14 k x 32
+    KITTI pair).  impl "fast" (or APR_NN_IMPL=fast; C in 32/64/128): split-bf16 MFMA bound + exact refine, the
+    same bits out; 1.9x faster on discriminative features, SLOWER when most targets lie within ~2e-4 of the
+    minimum (e.g. the collapsed features of a random-init encoder), so it is opt-in.
+    """
     f0 = _f32(f0, "feature_nn.f0").contiguous()
     f1 = _f32(f1, "feature_nn.f1").contiguous()
     if f0.shape[1] != f1.shape[1]:
@@ -366,7 +387,16 @@ def feature_nn(f0, f1, return_distance=False):
     n1 = f1.shape[0]
     lib = _lib_()
     best = torch.empty(n0, dtype=torch.int64, device=f0.device)
-    check(lib.apr_feature_nn(ptr(f0), n0, ptr(f1), n1, c, ptr(best), stream()))
+    if impl is None:
+        impl = os.environ.get("APR_NN_IMPL", "brute")
+    if impl not in ("brute", "fast"):
+        raise _lib.AprHipError(f"feature_nn: unknown impl {impl!r}")
+    if impl == "fast" and c in (32, 64, 128):
+        sb = int(lib.apr_feature_nn_fast_scratch_bytes(n0, n1, c))     # bf16 MFMA filter + exact refine
+        scratch = torch.empty(sb, dtype=torch.uint8, device=f0.device)
+        check(lib.apr_feature_nn_fast(ptr(f0), n0, ptr(f1), n1, c, ptr(best), ptr(scratch), sb, stream()))
+    else:
+        check(lib.apr_feature_nn(ptr(f0), n0, ptr(f1), n1, c, ptr(best), stream()))
     idx = torch.empty(n0, dtype=torch.int64, device=f0.device)
     d2 = torch.empty(n0, dtype=torch.float32, device=f0.device) if return_distance else None
     check(lib.apr_nn_unpack(ptr(best), n0, ptr(idx), ptr(d2), stream()))

@@ -119,7 +119,7 @@ int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_o
  * the kernel map is first turned into per-offset pair lists (apr_pairlist_build, once per map), then every
  * (offset, 64 pairs, 64 channels) work unit stages its weight piece once, writes per-pair products to
  * prod_scratch, and a second kernel sums them per output row in fixed offset order
- * with the same fused epilogue as apr_spconv_fwd.  Needs cin % 64 == 0, cin <= 512, cout % 64 == 0, K <= 32.
+ * with the same fused epilogue as apr_spconv_fwd.  Needs cin % 64 == 0, cin <= 512, cout % 64 == 0, K <= 27.
  * prod_scratch holds n_out*K rows of cout floats (offset k owns rows [k*n_out, (k+1)*n_out), sparsely used). */
 size_t apr_pairlist_bytes(int64_t n_out, int32_t K);
 int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, void* plist, size_t plist_bytes, void* stream);
@@ -142,6 +142,10 @@ typedef struct apr_spconv_desc {
   int64_t plist_bytes;    /* > 0: apr_pairlist_build(nbr -> plist) first (first use of the map in the batch) */
 } apr_spconv_desc;
 int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* stream);
+/* Same, with one HIP event pair per launch recorded on `stream` (around the conv kernels only, not a pair-list
+ * build); synchronises and returns each layer's elapsed milliseconds in layer_ms[n].  Measurement aid
+ * (bench.py's roofline leg): back-to-back launches from C, no host gaps inside a layer. */
+int apr_spconv_fwd_batch_timed(const apr_spconv_desc* descs, int32_t n, float* layer_ms, void* stream);
 
 /* ------------------------------------------------------------------------
  * Normalisation / elementwise on feature rows [n, c]
@@ -183,6 +187,12 @@ int apr_l2_normalize(const float* x, int64_t ldx, int64_t n, int32_t c,
 int apr_feature_nn(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c,
                    uint64_t* best, void* stream);
 /* Unpack: idx i64[n], d2 f32[n] (either nullable). */
+/* Same result, bit for bit, by filter + exact refine: a split-bf16 (hi + lo) MFMA pass bounds every distance
+ * rigorously (|approx - d| <= 1e-4 |a||b| + 5e-5 (|a|^2 + |b|^2)), a second pass evaluates the exact fp32 direct form only
+ * for the pairs that can still be the arg-min.  c in {32, 64, 128}; scratch from apr_feature_nn_fast_scratch_bytes. */
+size_t apr_feature_nn_fast_scratch_bytes(int64_t n0, int64_t n1, int32_t c);
+int apr_feature_nn_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,
+                        void* scratch, size_t scratch_bytes, void* stream);
 int apr_nn_unpack(const uint64_t* best, int64_t n, int64_t* idx, float* d2, void* stream);
 
 /* ------------------------------------------------------------------------

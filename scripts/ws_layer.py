@@ -1,0 +1,27 @@
+"""Run one weight-stationary conv layer on the real kernel maps of a synthetic pair (PMC / trace target)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from apr_amd import ops, synth
+from apr_amd.MinkowskiEngine.core import CoordinateManager
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "b2tr"
+cfg = {"b2tr": (1, 1, 64, 64, False), "b4": (8, 8, 256, 256, False), "c4tr": (8, 4, 256, 128, True),
+       "b3": (4, 4, 128, 128, False), "c3tr": (4, 2, 256, 64, True), "b2": (2, 2, 64, 64, False)}[which]
+xyz0, xyz1, _ = synth.make_pair(0)
+maps = []
+for b, xyz in enumerate((xyz0, xyz1)):
+    c = ops.voxelize(torch.from_numpy(xyz).to(dev), 0.3, b); maps.append(ops.build_map(c))
+ops.finalize_maps(maps)
+cm = CoordinateManager(torch.cat([m.coords for m in maps]))
+cm.build_pyramid([2, 4, 8])
+ti, to, cin, cout, tr = cfg
+nbr = cm.kernel_map(ti, to, 3, tr)
+x = torch.randn(cm.size(ti), cin, device=dev)
+wp = ops.pack_weights(torch.randn(27, cin, cout, device=dev) * 0.05)
+out = torch.empty(cm.size(to), cout, device=dev)
+pl = cm.pair_list(ti, to, 3, tr).build()
+for _ in range(10):
+    ops.spconv(x, nbr, 27, cin, cout, wp, out=out, plist=pl)
+torch.cuda.synchronize()
+print("done", which, int((nbr >= 0).sum()))

@@ -23,7 +23,45 @@ def test_feature_nn_bit_exact(dev, n0, n1, c):
     F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
     F1[n1 // 2] = F1[0]  # exact tie -> smallest index must win
     oi, od = MO.feature_nn(F0, F1)
-    idx, d2 = ops.feature_nn(torch.from_numpy(F0).to(dev), torch.from_numpy(F1).to(dev), return_distance=True)
+    for impl in ("brute", "fast"):      # "fast" falls back to the brute-force kernel for C outside 32/64/128
+        idx, d2 = ops.feature_nn(torch.from_numpy(F0).to(dev), torch.from_numpy(F1).to(dev), return_distance=True,
+                                 impl=impl)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.array_equal(d2.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["clustered", "unnormalised", "duplicates", "tiny", "one_target", "scaled_small"])
+def test_feature_nn_filter_refine_equals_brute_force(dev, case):
+    """The bf16-MFMA filter + exact refine path must return the SAME bits as the brute-force kernel (and the oracle)
+    on inputs built to stress the bound: near-ties, large and tiny magnitudes, exact duplicates, ragged sizes."""
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    c = 32
+    if case == "clustered":         # thousands of near-ties: targets are small perturbations of a few centres
+        cent = rng.standard_normal((7, c)).astype(np.float32)
+        F1 = (cent[rng.integers(0, 7, 4000)] + 1e-3 * rng.standard_normal((4000, c))).astype(np.float32)
+        F0 = (cent[rng.integers(0, 7, 1777)] + 1e-3 * rng.standard_normal((1777, c))).astype(np.float32)
+    elif case == "unnormalised":    # magnitudes from 1e-2 to 1e3 in one problem
+        F0 = (rng.standard_normal((1500, c)) * 10.0 ** rng.uniform(-2, 3, (1500, 1))).astype(np.float32)
+        F1 = (rng.standard_normal((2100, c)) * 10.0 ** rng.uniform(-2, 3, (2100, 1))).astype(np.float32)
+    elif case == "duplicates":      # every target appears 3 times: smallest index must win, d2 = 0 for copies
+        base = rng.standard_normal((500, c)).astype(np.float32)
+        F1 = np.concatenate([base, base, base])[rng.permutation(1500)]
+        F0 = np.concatenate([base[:300], rng.standard_normal((211, c)).astype(np.float32)])
+    elif case == "tiny":
+        F0 = rng.standard_normal((5, c)).astype(np.float32)
+        F1 = rng.standard_normal((3, c)).astype(np.float32)
+    elif case == "one_target":
+        F0 = rng.standard_normal((1000, c)).astype(np.float32)
+        F1 = rng.standard_normal((1, c)).astype(np.float32)
+    else:                           # scaled_small: |a| ~ 1e-3, squared distances ~1e-6
+        F0 = (1e-3 * rng.standard_normal((900, c))).astype(np.float32)
+        F1 = (1e-3 * rng.standard_normal((1100, c))).astype(np.float32)
+    a, b = torch.from_numpy(F0).to(dev), torch.from_numpy(F1).to(dev)
+    idx, d2 = ops.feature_nn(a, b, return_distance=True, impl="fast")
+    idx_b, d2_b = ops.feature_nn(a, b, return_distance=True, impl="brute")
+    assert torch.equal(idx, idx_b)
+    assert torch.equal(d2.view(torch.int32), d2_b.view(torch.int32))
+    oi, od = MO.feature_nn(F0, F1)
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(d2.cpu().numpy().view(np.uint32), od.view(np.uint32))
 
