@@ -47,6 +47,7 @@ class CoordinateManager:
         self.maps = {1: ops.build_map(coordinates)}
         self._kmaps = {}
         self._plists = {}
+        self._plist_counters = None
         self.device = coordinates.device
 
     # -- coordinate maps -----------------------------------------------------
@@ -99,7 +100,11 @@ class CoordinateManager:
         pl = self._plists.get(key)
         if pl is None:
             nbr = self.kernel_map(ts_in, ts_out, kernel_size, transpose)
-            pl = ops.build_pairlist(nbr, lazy=True)
+            if self._plist_counters is None:      # one fill clears the counters of every map of this manager
+                self._plist_counters = torch.zeros((16, 32), dtype=torch.int32, device=nbr.device)
+            slot = len(self._plists)
+            pl = ops.build_pairlist(nbr, lazy=True,
+                                    counters=self._plist_counters[slot] if slot < 16 else None)
             self._plists[key] = pl
         return pl
 

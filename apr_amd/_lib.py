@@ -27,7 +27,8 @@ class SpconvDesc(C.Structure):
                 ("K", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32),
                 ("w_packed", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
-                ("plist", C.c_void_p), ("prod_scratch", C.c_void_p), ("plist_bytes", C.c_int64)]
+                ("counters", C.c_void_p), ("plist", C.c_void_p), ("prod_scratch", C.c_void_p),
+                ("plist_bytes", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
@@ -44,8 +45,8 @@ PROTOTYPES = {
     "apr_spconv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "apr_spconv_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_pairlist_bytes": (_sz, [_i64, _i32]),
-    "apr_pairlist_build": (C.c_int, [_p, _i64, _i32, _p, _sz, _p]),
-    "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
+    "apr_pairlist_build": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
+    "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "apr_spconv_fwd_batch": (C.c_int, [_p, _i32, _p]),
     "apr_spconv_fwd_batch_timed": (C.c_int, [_p, _i32, _p, _p]),
     "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),

@@ -632,11 +632,11 @@ static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e
   hipStream_t st = (hipStream_t)stream;
   if (d.plist) {
     if (d.plist_bytes > 0) {   // the pair-list build is per map, not part of the timed conv layer
-      int rcb = apr_pairlist_build(d.nbr, d.n_out, d.K, d.plist, (size_t)d.plist_bytes, stream);
+      int rcb = apr_pairlist_build(d.nbr, d.n_out, d.K, d.counters, d.plist, (size_t)d.plist_bytes, stream);
       if (rcb != APR_OK) return rcb;
     }
     if (e0) APR_HIP(hipEventRecord(e0, st));
-    int rcw = apr_spconv_ws_fwd(d.in, d.ldi, d.plist, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.scale, d.shift,
+    int rcw = apr_spconv_ws_fwd(d.in, d.ldi, d.counters, d.plist, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.scale, d.shift,
                                 d.residual, d.ldr, d.relu, d.out, d.ldo, d.prod_scratch, stream);
     if (rcw != APR_OK) return rcw;
   } else {

@@ -24,7 +24,7 @@ constexpr int kRows = 512;   // rows per block in the pair-list build (fewer, la
                              // contended by every block, ~55 atomics per address on a 28 k-row map)
 constexpr int kBuildWaves = 8;
 
-struct PairHeader {   // lives at the start of the pair-list blob (device memory)
+struct PairHeader {   // the caller's 32 counters (zero before apr_pairlist_build)
   int cnt[32];        // pairs of offset k; they sit at pair_in[k * n_out .. k * n_out + cnt[k])
 };
 
@@ -36,11 +36,10 @@ struct PairViews {
   int* pair_id;   // [n_out, K] position of the pair (row, k) or -1
 };
 
-__host__ __device__ inline PairViews carve_pairs(void* blob, int64_t n_out, int K) {
+__host__ __device__ inline PairViews carve_pairs(int32_t* counters, void* blob, int64_t n_out, int K) {
   PairViews v;
   char* p = (char*)blob;
-  v.hdr = (PairHeader*)p;
-  p += align256(sizeof(PairHeader));
+  v.hdr = (PairHeader*)counters;
   const size_t cap = (size_t)n_out * K;
   v.pair_in = (int*)p;
   p += align256(cap * 4);
@@ -105,7 +104,8 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_pairs_build(const int* __r
           int pos = -1;
           if (idx >= 0) {
             pos = run + __popcll(m & ((1ull << lane) - 1ull));
-            v.pair_in[pos] = idx;
+            // counters not cleared by the caller would push positions past the offset's region: never write there
+            if (pos < (k + 1) * n_out) v.pair_in[pos] = idx; else pos = -1;
           }
           s_nbr[r * K + k] = pos;
         }
@@ -262,24 +262,25 @@ __global__ __launch_bounds__(256) void k_ws_reduce(const float* __restrict__ pro
 }  // namespace
 
 APR_API size_t apr_pairlist_bytes(int64_t n_out, int32_t K) {
-  return align256(sizeof(PairHeader)) + 2 * align256((size_t)(n_out > 0 ? n_out : 1) * K * 4) + 256;
+  return 2 * align256((size_t)(n_out > 0 ? n_out : 1) * K * 4) + 256;
 }
 
-APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, void* plist, size_t plist_bytes,
-                               void* stream) {
+APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* counters, void* plist,
+                               size_t plist_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 27,
                 "apr_pairlist_build: needs 0 < n_out < 2^26 and 1 <= K <= 27");
   APR_CHECK_ARG(plist_bytes >= apr_pairlist_bytes(n_out, K), "apr_pairlist_build: blob too small");
-  PairViews v = carve_pairs(plist, n_out, K);
-  APR_HIP(hipMemsetAsync(v.hdr, 0, sizeof(PairHeader), st));
+  APR_CHECK_ARG(counters != nullptr && plist != nullptr, "apr_pairlist_build: null counters / plist");
+  PairViews v = carve_pairs(counters, plist, n_out, K);
   hipLaunchKernelGGL(k_pairs_build, dim3((unsigned)cdiv64(n_out, kRows)), dim3(64 * kBuildWaves), 0, st, nbr,
                      (int)n_out, K, v);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
 
-APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, int64_t n_out, int32_t K, int32_t cin,
+APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
+                              int32_t K, int32_t cin,
                               int32_t cout, const float* w_packed, const float* scale, const float* shift,
                               const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
                               float* prod_scratch, void* stream) {
@@ -290,7 +291,7 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, i
   APR_CHECK_ARG(ldi % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out) | ((uintptr_t)prod_scratch)) & 15) == 0,
                 "apr_spconv_ws_fwd: 16-byte aligned rows required");
   APR_CHECK_ARG(!residual || (ldr % 4 == 0 && (((uintptr_t)residual) & 15) == 0), "apr_spconv_ws_fwd: residual alignment");
-  PairViews v = carve_pairs(const_cast<void*>(plist), n_out, K);
+  PairViews v = carve_pairs(const_cast<int32_t*>(counters), const_cast<void*>(plist), n_out, K);
   // The weight slice in LDS limits residency to floor(160 KB / slice) workgroups per CU; more units than resident
   // slots means a second round of workgroups behind the first (measured: 29 us vs 15 us on the 256-channel level).
   // target = the slots (<= 768); the kernel sizes its units from the real pair count to fit, and a grid of that

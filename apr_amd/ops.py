@@ -163,13 +163,13 @@ PROFILE = None  # set to a SpconvProfile to time launches
 
 
 class PairList:
-    """Per-offset pair lists of one kernel map (apr_pairlist_build): a device blob.
+    """Per-offset pair lists of one kernel map (apr_pairlist_build): 32 zeroed counters + a device blob.
 
-    `built` False: the blob is only allocated; the first launch of a SpconvBatch that uses it builds it inside
-    the same library call (no extra host round trip)."""
+    `built` False: only allocated; the first launch of a SpconvBatch that uses it builds it inside the same
+    library call (no extra host round trip)."""
 
-    def __init__(self, blob, nbr, built):
-        self.blob, self.nbr, self.built = blob, nbr, built
+    def __init__(self, counters, blob, nbr, built):
+        self.counters, self.blob, self.nbr, self.built = counters, blob, nbr, built
         self.n_out, self.K = nbr.shape
 
     def prod_scratch(self, cout):
@@ -178,23 +178,26 @@ class PairList:
 
     def build(self):
         if not self.built:
-            check(_lib_().apr_pairlist_build(ptr(self.nbr), self.n_out, self.K, ptr(self.blob), self.blob.numel(),
-                                             stream()))
+            check(_lib_().apr_pairlist_build(ptr(self.nbr), self.n_out, self.K, ptr(self.counters), ptr(self.blob),
+                                             self.blob.numel(), stream()))
             self.built = True
         return self
 
     def counts(self):
         """Pairs per offset (host sync; tests / diagnostics)."""
-        return self.build().blob[:self.K * 4].view(torch.int32).cpu().numpy()
+        return self.build().counters[:self.K].cpu().numpy()
 
 
-def build_pairlist(nbr, lazy=False):
-    """nbr int32 [n_out, K] -> PairList."""
+def build_pairlist(nbr, lazy=False, counters=None):
+    """nbr int32 [n_out, K] -> PairList.  `counters`: an all-zero int32[32] slice to use (a coordinate manager
+    clears the counters of all its maps with one fill); default: a fresh torch.zeros(32)."""
     if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2:
         raise _lib.AprHipError("build_pairlist: nbr must be a contiguous int32 [n_out, K] tensor")
     n_out, K = nbr.shape
     nb = int(_lib_().apr_pairlist_bytes(n_out, K))
-    pl = PairList(torch.empty(nb, dtype=torch.uint8, device=nbr.device), nbr, False)
+    if counters is None:
+        counters = torch.zeros(32, dtype=torch.int32, device=nbr.device)
+    pl = PairList(counters, torch.empty(nb, dtype=torch.uint8, device=nbr.device), nbr, False)
     return pl if lazy else pl.build()
 
 
@@ -239,7 +242,7 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if use_ws:
-        check(_lib_().apr_spconv_ws_fwd(ptr(x), ldi, ptr(plist.blob), n_out, K, cin, cout, ptr(wp), ptr(scale),
+        check(_lib_().apr_spconv_ws_fwd(ptr(x), ldi, ptr(plist.counters), ptr(plist.blob), n_out, K, cin, cout, ptr(wp), ptr(scale),
                                         ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, ptr(prod),
                                         stream()))
     else:
@@ -290,7 +293,7 @@ class SpconvBatch:
             prod = self.prod.get(need)
             if prod is None:
                 prod = self.prod[need] = plist.prod_scratch(cout)
-            d.plist, d.prod_scratch = plist.blob.data_ptr(), prod.data_ptr()
+            d.counters, d.plist, d.prod_scratch = plist.counters.data_ptr(), plist.blob.data_ptr(), prod.data_ptr()
             if not plist.built:
                 d.plist_bytes, plist.built = plist.blob.numel(), True
         self.descs.append(d)

@@ -163,6 +163,8 @@ def main():
         return pipe(a, b, seed=i)
 
     # S independent pairs in flight: worker w owns HIP stream w and runs steps w, w+S, w+2S, ...
+    if os.environ.get("APR_BENCH_SWITCH"):
+        sys.setswitchinterval(float(os.environ["APR_BENCH_SWITCH"]))
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     results = {}

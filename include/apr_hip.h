@@ -120,10 +120,14 @@ int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_o
  * (offset, 64 pairs, 64 channels) work unit stages its weight piece once, writes per-pair products to
  * prod_scratch, and a second kernel sums them per output row in fixed offset order
  * with the same fused epilogue as apr_spconv_fwd.  Needs cin % 64 == 0, cin <= 512, cout % 64 == 0, K <= 27.
+ * counters: int32[32] per-offset pair counts, ZERO before apr_pairlist_build (the caller clears them: one fill
+ * can clear the counters of all maps of a forward pass); plist: apr_pairlist_bytes(n_out, K) bytes.
  * prod_scratch holds n_out*K rows of cout floats (offset k owns rows [k*n_out, (k+1)*n_out), sparsely used). */
 size_t apr_pairlist_bytes(int64_t n_out, int32_t K);
-int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, void* plist, size_t plist_bytes, void* stream);
-int apr_spconv_ws_fwd(const float* in, int64_t ldi, const void* plist, int64_t n_out, int32_t K, int32_t cin,
+int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* counters, void* plist,
+                       size_t plist_bytes, void* stream);
+int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
+                      int32_t K, int32_t cin,
                       int32_t cout, const float* w_packed, const float* scale, const float* shift,
                       const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
                       float* prod_scratch, void* stream);
@@ -137,7 +141,8 @@ typedef struct apr_spconv_desc {
   const float* w_packed; const float* scale; const float* shift;
   const float* residual; int64_t ldr;
   float* out; int64_t ldo;
-  void* plist;            /* non-NULL: run this launch through apr_spconv_ws_fwd with ... */
+  int32_t* counters;      /* pair-list counters and ... */
+  void* plist;            /* ... body; non-NULL: run this launch through apr_spconv_ws_fwd with ... */
   float* prod_scratch;    /* ... this product buffer (n_out*K rows); */
   int64_t plist_bytes;    /* > 0: apr_pairlist_build(nbr -> plist) first (first use of the map in the batch) */
 } apr_spconv_desc;

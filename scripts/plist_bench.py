@@ -19,11 +19,12 @@ for name, ti, to, tr in [("1>1", 1, 1, False), ("2>1T", 2, 1, True), ("2>2", 2, 
     n_out, K = nbr.shape
     nb = int(lib.apr_pairlist_bytes(n_out, K))
     blob = torch.empty(nb, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(32, dtype=torch.int32, device=dev)
     st = stream()
-    for _ in range(3): check(lib.apr_pairlist_build(ptr(nbr), n_out, K, ptr(blob), nb, st))
+    for _ in range(3): cnt.zero_(); check(lib.apr_pairlist_build(ptr(nbr), n_out, K, ptr(cnt), ptr(blob), nb, st))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(50): check(lib.apr_pairlist_build(ptr(nbr), n_out, K, ptr(blob), nb, st))
+    for _ in range(50): cnt.zero_(); check(lib.apr_pairlist_build(ptr(nbr), n_out, K, ptr(cnt), ptr(blob), nb, st))
     e1.record(); torch.cuda.synchronize()
-    print(f"map {name}: rows={n_out} build {e0.elapsed_time(e1)*20:.1f} us (memset + kernel, back to back)", flush=True)
+    print(f"map {name}: rows={n_out} build {e0.elapsed_time(e1)*20:.1f} us (counter fill + kernel)", flush=True)
