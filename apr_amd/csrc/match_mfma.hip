@@ -7,7 +7,7 @@
 //   bound   bf16 MFMA (v_mfma_f32_16x16x32_bf16, K = 32: one instruction per 16x16 block of dot products and
 //           term) accumulates a.b ~ lo.hi + hi.lo + hi.hi in fp32, so approx(i,j) = |a|^2 + |b|^2 - 2 a.b obeys the
 //           RIGOROUS bound
-//               |approx - d| <= eps(i,j) = 1e-4 |a||b| + 5e-5 (|a|^2 + |b|^2)
+//               |approx - d| <= eps(i,j) = 1e-4 |a||b| + 5e-5 (|a|^2 + |b|^2)   (used with |b| <= max_j |b_j|)
 //           (|a - hi - lo| <= 2^-18 |a| and the dropped lo.lo term <= 2^-18 |a||b|: by Cauchy-Schwarz the dot
 //           product is off by <= 3 * 2^-18 |a||b|, doubled by the factor 2 = 2.3e-5, plus <= 1.2e-5 for three
 //           K=32 fp32 accumulations: 3.5e-5, bounded by 1e-4 with ~3x head-room; fp32 norm sums and the direct
@@ -17,7 +17,9 @@
 //   refine  the same MFMA pass again; only pairs with approx - eps <= U_i can be the arg-min (or tie with it): for
 //           those — a handful per query — d is evaluated EXACTLY, in the oracle's order, and meets the others in the
 //           same 64-bit atomicMin on (bits(d) << 32 | j) as the brute-force kernel.
-// No candidate list, no overflow path: the refine pass handles its candidates in place.
+// Candidates go to a list (wave-private LDS buffers, one global atomic per ~1000 entries) and are evaluated densely
+// by k_nn_exact; if the list (128 entries per query) overflows — near-identical features everywhere — a predicated
+// brute-force kernel takes over, so the result is exact for ANY input.
 #include "common.h"
 
 namespace {
@@ -35,19 +37,26 @@ __device__ inline unsigned short to_bf16_rne(float x) {
 }
 
 // One group of C/4 lanes per row: 16-B loads, 8-B bf16 stores, shuffle-reduced norm.
-// meta[i] = (kEpsRel |a|  or  |a| , |a|^2 + s, |a|^2 - s, 0) with s = kEpsAbs |a|^2; queries carry the eps factor.
+// meta[i] = (kEpsRel |a|  or  |a| , |a|^2 + s, |a|^2 - s, 0) with s = kEpsAbs |a|^2; queries carry the eps factor and
+// are stored as -2a, so the MFMA chain started from C = |b|^2 (+-s) yields |b|^2 - 2 a.b with no VALU work.
 template <int C>
-__global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scale, unsigned short* __restrict__ fb,
-                          unsigned short* __restrict__ fl, f32x4* __restrict__ meta, unsigned* __restrict__ u_init,
-                          unsigned long long* __restrict__ best_init) {
+__global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scale, float row_scale,
+                          unsigned short* __restrict__ fb, unsigned short* __restrict__ fl, f32x4* __restrict__ meta,
+                          unsigned* __restrict__ u_init, unsigned long long* __restrict__ best_init,
+                          unsigned* __restrict__ zero_me, unsigned* __restrict__ len_max) {
   constexpr int LPR = C / 4;   // lanes per row
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t / LPR;
   const int g = (int)(t - row * LPR);
-  float s = 0.f;
+  if (t == 0 && zero_me) {   // candidate counter and max target length (consumed by later launches)
+    zero_me[0] = 0u;
+    zero_me[1] = 0u;
+  }
+  float s = 0.f, row_len = 0.f;
   if (row < n) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(f + row * C + g * 4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(f + row * C + g * 4);
     s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    v *= row_scale;   // queries: -2 (a power of two: the split is that of a, scaled), targets: 1
     ushort4 o, ol;
     o.x = to_bf16_rne(v[0]); o.y = to_bf16_rne(v[1]); o.z = to_bf16_rne(v[2]); o.w = to_bf16_rne(v[3]);
     ol.x = to_bf16_rne(v[0] - __uint_as_float((unsigned)o.x << 16));   // a - hi is exact in fp32
@@ -62,15 +71,31 @@ __global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scal
   if (row < n && g == 0) {
     const float nn = s;
     const float sl = kEpsAbs * nn;
-    meta[row] = (f32x4){len_scale * sqrtf(nn), nn + sl, nn - sl, 0.f};
+    const float len = sqrtf(nn);
+    meta[row] = (f32x4){len_scale * len, nn + sl, nn - sl, 0.f};
     if (u_init) u_init[row] = 0x7F800000u;
     if (best_init) best_init[row] = ~0ull;
+    row_len = len;
+  }
+  if (len_max) {   // one atomic per wave (non-negative floats order like their bits)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) row_len = fmaxf(row_len, __shfl_xor(row_len, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(len_max, __float_as_uint(row_len));
   }
 }
 
-// REFINE = false: U_i = min_j (approx + eps).  REFINE = true: exact d for every pair with approx - eps <= U_i.
-// Workgroup = 4 waves x 64 queries; wave holds its 4 query tiles (16 rows each) as MFMA A operands in registers
-// and walks 16-row target tiles (B operand: one 16-B load per lane, 1 KB contiguous per tile).
+// REFINE = false: U_i = min_j (approx + eps).  REFINE = true: every pair with approx - eps <= U_i is appended to the
+// candidate list (exact evaluation happens densely in k_nn_exact).
+// Workgroup = 4 waves x 64 queries; a wave holds its 4 query tiles (16 rows each, hi + lo) as MFMA A operands in
+// registers.  Targets stream through LDS in chunks of 64 rows (hi, lo, meta), double buffered: the next chunk's
+// global loads are in flight while the current one feeds the MFMAs, one barrier per chunk; B fragments are
+// conflict-free ds_read_b128 (16 rows x 64 B contiguous per k-slice).
+// Candidates: per-lane 16-bit masks, ranked by a wave prefix sum into a wave-private LDS buffer (4-byte entries),
+// flushed to the global list with ONE atomicAdd per flush.  (Two alternatives measured slower on the bench's 58
+// candidates per query: per-element wave masks with v_mbcnt ranks, 149 us, and direct-to-global blocks, 174 us,
+// against 125 us for this form; the bound pass alone is 50 us.)
+constexpr int kCandBuf = 1280;   // per wave (flushed above 256); a 16-target tile adds <= 64 x 16 = 1024
+
 template <int C, bool REFINE>
 __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restrict__ qb,
                                                  const unsigned short* __restrict__ ql,
@@ -78,16 +103,23 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
                                                  const unsigned short* __restrict__ tb,
                                                  const unsigned short* __restrict__ tl,
                                                  const f32x4* __restrict__ tmeta, int64_t n1, int chunk,
-                                                 unsigned* __restrict__ U, const float* __restrict__ f0,
-                                                 const float* __restrict__ f1,
-                                                 unsigned long long* __restrict__ best) {
-  constexpr int KS = C / 32, QT = 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                 unsigned* __restrict__ U, unsigned long long* __restrict__ cand,
+                                                 unsigned* __restrict__ cand_count, unsigned cand_cap) {
+  // cand_count[1] = bits of max_j |b_j| (k_nn_prep): eps(i,j) <= kEpsRel |a_i| max|b| + s_i + s_j keeps the bound
+  // rigorous and makes its |a||b| part a per-QUERY constant, so the per-element epilogue is one min / one compare
+  constexpr int KS = C / 32, QT = 4, TR = 64;          // TR target rows per LDS stage
+  constexpr int LPT = (TR * C * 2) / 16 / 256;         // 16-B loads per thread per array and stage (C=32: 1)
+  __shared__ __attribute__((aligned(16))) unsigned short s_h[2][TR * C];
+  __shared__ __attribute__((aligned(16))) unsigned short s_l[2][TR * C];
+  __shared__ f32x4 s_m[2][TR];
+  __shared__ unsigned s_cand[REFINE ? 4 * kCandBuf : 1];   // (query within the workgroup) << 24 | (target - t0)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lq = lane >> 4;
   const int64_t q0 = (int64_t)blockIdx.x * 256 + wave * 64;
-  if (q0 >= n0) return;   // whole wave out of range (no barrier in this kernel)
+  const bool wave_live = q0 < n0;        // dead waves still stage and hit the barriers
   bf16x8 a[QT][KS], al[QT][KS];
-  float cq[QT][4], thr[QT][4], mn[QT][4];
+  float thr[QT][4], mn[QT][4];
+  const float len_max = __uint_as_float(cand_count[1]);
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     int64_t ra = q0 + qt * 16 + l16;
@@ -102,91 +134,154 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
       const int64_t row = q0 + qt * 16 + lq * 4 + r;
       const bool live = row < n0;
       const f32x4 m = qmeta[live ? row : n0 - 1];
-      cq[qt][r] = m[0];
       mn[qt][r] = __builtin_inff();
-      // candidate test of the refine pass: approx - eps - (|a|^2 - s) <= U - (|a|^2 - s)
-      thr[qt][r] = (REFINE && live) ? __uint_as_float(U[row]) - m[2] : -__builtin_inff();
+      // candidate test of the refine pass:  (|b|^2 - s_j - 2 a.b) <= U - (|a|^2 - s_i) + kEpsRel |a| max|b|
+      thr[qt][r] = (REFINE && live) ? __uint_as_float(U[row]) - m[2] + m[0] * len_max : -__builtin_inff();
     }
   }
   const int64_t t0 = (int64_t)blockIdx.y * chunk;
   const int64_t t1 = min((long long)(t0 + chunk), (long long)n1);
+  int ncand = 0;                         // entries in this wave's LDS buffer (wave-uniform)
+  unsigned* my_cand = s_cand + (REFINE ? wave * kCandBuf : 0);
 
-  auto load_tile = [&](int64_t jt, bf16x8 (&b)[KS], bf16x8 (&bl)[KS], f32x4& tm) {
-    int64_t j = jt + l16;
-    const bool live = j < t1;
-    if (!live) j = t1 - 1;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      b[ks] = *reinterpret_cast<const bf16x8*>(tb + j * C + ks * 32 + lq * 8);
-      bl[ks] = *reinterpret_cast<const bf16x8*>(tl + j * C + ks * 32 + lq * 8);
-    }
-    tm = tmeta[j];
-    if (!live) {   // a padded column can neither lower U nor become a candidate
-      tm[1] = __builtin_inff();
-      tm[2] = __builtin_inff();
-    }
+  auto flush = [&]() {
+    if (ncand == 0) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(cand_count, (unsigned)ncand);
+    base = __shfl(base, 0);
+    for (int e = lane; e < ncand; e += 64)
+      if (base + e < cand_cap) {          // past the capacity: dropped, the count tells (fallback)
+        const unsigned c = my_cand[e];
+        cand[base + e] = ((unsigned long long)(blockIdx.x * 256u + (c >> 24)) << 32) |
+                         (unsigned long long)(t0 + (c & 0xffffffu));
+      }
+    ncand = 0;
   };
-  auto consume = [&](int64_t jt, const bf16x8 (&b)[KS], const bf16x8 (&bl)[KS], const f32x4& tm) {
-    unsigned cand = 0;
+
+  // ---- staging registers for the next chunk
+  uint4 rh[LPT], rl[LPT];
+  f32x4 rm;
+  auto fetch = [&](int64_t jt) {          // global -> registers, rows clamped to the range
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {   // small terms first
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[qt][ks], b[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qt][ks], bl[ks], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qt][ks], b[ks], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (!REFINE) {
-          const float u = fmaf(cq[qt][r], tm[0], fmaf(-2.f, acc[r], tm[1]));
-          mn[qt][r] = fminf(mn[qt][r], u);
-        } else {
-          const float lo = fmaf(-cq[qt][r], tm[0], fmaf(-2.f, acc[r], tm[2]));
-          if (lo <= thr[qt][r]) cand |= 1u << (qt * 4 + r);
-        }
-      }
+    for (int u = 0; u < LPT; ++u) {
+      const int e = u * 256 + tid;        // 16-B element of the [TR, C] bf16 slab
+      int64_t j = jt + (e * 8) / C;
+      if (j >= t1) j = t1 - 1;
+      const int64_t off = j * C + (e * 8) % C;
+      rh[u] = *reinterpret_cast<const uint4*>(tb + off);
+      rl[u] = *reinterpret_cast<const uint4*>(tl + off);
     }
-    if (REFINE) {
-      // exact direct form for this lane's candidates (usually none; a few per query over the whole pass)
-      while (__any(cand != 0)) {
-        if (cand) {
-          const int e = __ffs((int)cand) - 1;
-          cand &= cand - 1;
-          const int64_t i = q0 + (e >> 2) * 16 + lq * 4 + (e & 3);
-          const int64_t j = jt + l16;
-          const float* x = f0 + i * C;
-          const float* y = f1 + j * C;
-          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-          for (int g = 0; g < C / 4; ++g) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + g * 4);
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + g * 4);
-            const float d0 = xv[0] - yv[0], d1 = xv[1] - yv[1], d2 = xv[2] - yv[2], d3 = xv[3] - yv[3];
-            s0 = fmaf(d0, d0, s0);
-            s1 = fmaf(d1, d1, s1);
-            s2 = fmaf(d2, d2, s2);
-            s3 = fmaf(d3, d3, s3);
-          }
-          const float d = (s0 + s1) + (s2 + s3);
-          atomicMin(&best[i], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j);
-        }
+    if (tid < TR) {
+      const int64_t j = jt + tid;
+      rm = tmeta[j < t1 ? j : t1 - 1];
+      if (j >= t1) {                      // a padded row can neither lower U nor become a candidate
+        rm[1] = __builtin_inff();
+        rm[2] = __builtin_inff();
       }
     }
   };
+  auto commit = [&](int buf) {            // registers -> LDS
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int e = u * 256 + tid;
+      *reinterpret_cast<uint4*>(&s_h[buf][e * 8]) = rh[u];
+      *reinterpret_cast<uint4*>(&s_l[buf][e * 8]) = rl[u];
+    }
+    if (tid < TR) s_m[buf][tid] = rm;
+  };
 
-  bf16x8 b0[KS], b1[KS], bl0[KS], bl1[KS];
-  f32x4 m0, m1;
-  if (t0 < t1) load_tile(t0, b0, bl0, m0);
-  for (int64_t jt = t0; jt < t1; jt += 32) {
-    if (jt + 16 < t1) load_tile(jt + 16, b1, bl1, m1);
-    consume(jt, b0, bl0, m0);
-    if (jt + 32 < t1) load_tile(jt + 32, b0, bl0, m0);
-    if (jt + 16 < t1) consume(jt + 16, b1, bl1, m1);
+  if (t0 < t1) {
+    fetch(t0);
+    commit(0);
   }
-  if (!REFINE) {
+  // every load issued so far (query fragments, meta) lands HERE: otherwise the compiler's counter bookkeeping puts
+  // an s_waitcnt vmcnt(0) at their first use INSIDE the loop, which also drains the next chunk's prefetch every
+  // iteration (vmcnt counts in order)
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t jt = t0; jt < t1; jt += TR, buf ^= 1) {
+    const bool more = jt + TR < t1;
+    if (more) fetch(jt + TR);
+    if (wave_live) {
+#pragma unroll
+      for (int tt = 0; tt < TR / 16; ++tt) {
+        if (jt + tt * 16 >= t1) break;
+        bf16x8 b[KS], bl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          b[ks] = *reinterpret_cast<const bf16x8*>(&s_h[buf][(tt * 16 + l16) * C + ks * 32 + lq * 8]);
+          bl[ks] = *reinterpret_cast<const bf16x8*>(&s_l[buf][(tt * 16 + l16) * C + ks * 32 + lq * 8]);
+        }
+        const f32x4 tm = s_m[buf][tt * 16 + l16];
+        // C operand = |b_j|^2 (+ s_j for the bound, - s_j for the refine test), the same for the lane's 4 rows; the
+        // three terms of all four query tiles are issued term-major: 4 independent accumulators between consecutive
+        // MFMAs on the same one (back-to-back dependent MFMAs would stall on the 8-pass latency)
+        const float c0 = REFINE ? tm[2] : tm[1];
+        const f32x4 cinit = {c0, c0, c0, c0};
+        f32x4 acc[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[qt][0], b[0], cinit, 0, 0, 0);   // small terms first
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qt][0], bl[0], acc[qt], 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < KS; ++ks) {
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[qt][ks], b[ks], acc[qt], 0, 0, 0);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qt][ks], bl[ks], acc[qt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qt][ks], b[ks], acc[qt], 0, 0, 0);
+        if (!REFINE) {
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              // plain v_min_f32 (fminf adds a canonicalising v_max per operand: 3 VALU instead of 1)
+              asm("v_min_f32 %0, %1, %2" : "=v"(mn[qt][r]) : "v"(mn[qt][r]), "v"(acc[qt][r]));
+        } else {
+          unsigned cmask = 0;
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (acc[qt][r] <= thr[qt][r]) cmask |= 1u << (qt * 4 + r);
+          if (__any(cmask != 0)) {
+            if (ncand > kCandBuf - 1024) flush();
+            // wave prefix sum of the per-lane candidate counts -> ranks in the wave-private buffer
+            const int c = __popc(cmask);
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const int t = __shfl_up(incl, d);
+              if (lane >= d) incl += t;
+            }
+            int pos = ncand + incl - c;
+            const unsigned j = (unsigned)(jt - t0) + tt * 16 + l16;       // chunk < 2^24 (checked on the host)
+            while (cmask) {
+              const int e = __ffs((int)cmask) - 1;
+              cmask &= cmask - 1;
+              const unsigned i = wave * 64 + (e >> 2) * 16 + lq * 4 + (e & 3);
+              my_cand[pos++] = (i << 24) | j;
+            }
+            ncand += __shfl(incl, 63);
+          }
+        }
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+  }
+  if (REFINE) flush();
+  if (!REFINE && wave_live) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -196,15 +291,88 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
         for (int d = 1; d < 16; d <<= 1) v = fminf(v, __shfl_xor(v, d));
         const int64_t row = q0 + qt * 16 + lq * 4 + r;
         if (l16 == 0 && row < n0) {
-          // + (|a|^2 + s); the true minimum is >= 0, so clamping keeps U an upper bound and its bits ordered
-          const float u = fmaxf(v + qmeta[row][1], 0.f);
+          // + (|a|^2 + s_i) + kEpsRel |a| max|b|; the true minimum is >= 0, so clamping keeps U an upper bound
+          // and its bits ordered
+          const f32x4 m = qmeta[row];
+          const float u = fmaxf(v + m[1] + m[0] * len_max, 0.f);
           atomicMin(&U[row], __float_as_uint(u));
         }
       }
   }
 }
 
+// One thread per candidate pair: the exact direct form in the oracle's order, 64-bit atomicMin like the brute-force
+// kernel.  Grid-stride over the device-side count.
+template <int C>
+__global__ __launch_bounds__(256) void k_nn_exact(const unsigned long long* __restrict__ cand,
+                                                  const unsigned* __restrict__ cand_count, unsigned cand_cap,
+                                                  const float* __restrict__ f0, const float* __restrict__ f1,
+                                                  unsigned long long* __restrict__ best) {
+  const unsigned n = min(*cand_count, cand_cap);
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const unsigned long long ij = cand[t];
+    const int64_t i = (int64_t)(ij >> 32), j = (int64_t)(ij & 0xffffffffull);
+    const float* x = f0 + i * C;
+    const float* y = f1 + j * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int g = 0; g < C / 4; ++g) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + g * 4);
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + g * 4);
+      const float d0 = xv[0] - yv[0], d1 = xv[1] - yv[1], d2 = xv[2] - yv[2], d3 = xv[3] - yv[3];
+      s0 = fmaf(d0, d0, s0);
+      s1 = fmaf(d1, d1, s1);
+      s2 = fmaf(d2, d2, s2);
+      s3 = fmaf(d3, d3, s3);
+    }
+    const float d = (s0 + s1) + (s2 + s3);
+    atomicMin(&best[i], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j);
+  }
+}
+
+// Only if the candidate list overflowed (near-identical features everywhere): exact brute force, predicated on the
+// device-side count so that the launch is a no-op otherwise.  One query per thread, wave-uniform target rows.
+template <int C>
+__global__ __launch_bounds__(256) void k_nn_fallback(const unsigned* __restrict__ cand_count, unsigned cand_cap,
+                                                     const float* __restrict__ f0, int64_t n0,
+                                                     const float* __restrict__ f1, int64_t n1, int chunk,
+                                                     unsigned long long* __restrict__ best) {
+  if (*cand_count <= cand_cap) return;
+  const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.y * chunk;
+  const int64_t t1 = min((long long)(t0 + chunk), (long long)n1);
+  const float* x = f0 + (qi < n0 ? qi : n0 - 1) * C;
+  float bd = __builtin_inff();
+  int bj = 0x7fffffff;
+  for (int64_t j = t0; j < t1; ++j) {
+    const float* __restrict__ y = f1 + j * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+    for (int g = 0; g < C / 4; ++g) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + g * 4);
+      const float d0 = xv[0] - y[4 * g], d1 = xv[1] - y[4 * g + 1], d2 = xv[2] - y[4 * g + 2], d3 = xv[3] - y[4 * g + 3];
+      s0 = fmaf(d0, d0, s0);
+      s1 = fmaf(d1, d1, s1);
+      s2 = fmaf(d2, d2, s2);
+      s3 = fmaf(d3, d3, s3);
+    }
+    const float d = (s0 + s1) + (s2 + s3);
+    if (d < bd) {
+      bd = d;
+      bj = (int)j;
+    }
+  }
+  if (qi < n0 && bj != 0x7fffffff)
+    atomicMin(&best[qi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj);
+}
+
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int64_t cand_capacity(int64_t n0) {   // 128 candidates per query
+  int64_t c = 128 * n0;
+  if (c < 65536) c = 65536;
+  return c < (1ll << 32) - 1 ? c : (1ll << 32) - 1;
+}
 
 template <int C>
 int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best, char* p,
@@ -215,21 +383,31 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
   unsigned short* tl = (unsigned short*)p;  p += al256((size_t)n1 * C * 2);
   f32x4* qmeta = (f32x4*)p;                 p += al256((size_t)n0 * 16);
   f32x4* tmeta = (f32x4*)p;                 p += al256((size_t)n1 * 16);
-  unsigned* U = (unsigned*)p;
+  unsigned* U = (unsigned*)p;               p += al256((size_t)n0 * 4);
+  unsigned* cand_count = (unsigned*)p;      p += 256;
+  unsigned long long* cand = (unsigned long long*)p;
+  const unsigned cap = (unsigned)cand_capacity(n0);
   constexpr int LPR = C / 4;
-  hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n0 * LPR, 256)), dim3(256), 0, st, f0, n0, kEpsRel, qb, ql,
-                     qmeta, U, best);
-  hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n1 * LPR, 256)), dim3(256), 0, st, f1, n1, 1.0f, tb, tl,
-                     tmeta, (unsigned*)nullptr, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n0 * LPR, 256)), dim3(256), 0, st, f0, n0, kEpsRel, -2.0f, qb,
+                     ql, qmeta, U, best, cand_count, (unsigned*)nullptr);
+  hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n1 * LPR, 256)), dim3(256), 0, st, f1, n1, 1.0f, 1.0f, tb, tl,
+                     tmeta, (unsigned*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr, cand_count + 1);
   const int64_t qblocks = cdiv64(n0, 256);
-  int64_t want = cdiv64(1024, qblocks);
-  int64_t chunk = cdiv64(cdiv64(n1, want), 32) * 32;
-  if (chunk < 128) chunk = 128;
+  int64_t want = cdiv64(768, qblocks);
+  int64_t chunk = cdiv64(cdiv64(n1, want), 64) * 64;
+  if (chunk < 256) chunk = 256;
+  if (chunk >= (1 << 24)) chunk = (1 << 24) - 64;
   const dim3 grid((unsigned)qblocks, (unsigned)cdiv64(n1, chunk));
   hipLaunchKernelGGL((k_nn_mfma<C, false>), grid, dim3(256), 0, st, qb, ql, qmeta, n0, tb, tl, tmeta, n1, (int)chunk, U,
-                     f0, f1, best);
+                     cand, cand_count, cap);
   hipLaunchKernelGGL((k_nn_mfma<C, true>), grid, dim3(256), 0, st, qb, ql, qmeta, n0, tb, tl, tmeta, n1, (int)chunk, U,
-                     f0, f1, best);
+                     cand, cand_count, cap);
+  hipLaunchKernelGGL((k_nn_exact<C>), dim3(1024), dim3(256), 0, st, cand, cand_count, cap, f0, f1, best);
+  // no-op unless the list overflowed
+  int64_t fchunk = cdiv64(n1, cdiv64(2048, qblocks));
+  if (fchunk < 64) fchunk = 64;
+  hipLaunchKernelGGL((k_nn_fallback<C>), dim3((unsigned)qblocks, (unsigned)cdiv64(n1, fchunk)), dim3(256), 0, st,
+                     cand_count, cap, f0, n0, f1, n1, (int)fchunk, best);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -239,7 +417,7 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
 APR_API size_t apr_feature_nn_fast_scratch_bytes(int64_t n0, int64_t n1, int32_t c) {
   if (n0 < 0 || n1 < 0 || c <= 0) return 0;
   return 2 * al256((size_t)n0 * c * 2) + 2 * al256((size_t)n1 * c * 2) + al256((size_t)n0 * 16) + al256((size_t)n1 * 16) +
-         al256((size_t)n0 * 4) + 256;
+         al256((size_t)n0 * 4) + 256 + al256((size_t)cand_capacity(n0) * 8) + 256;
 }
 
 APR_API int apr_feature_nn_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,

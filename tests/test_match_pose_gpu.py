@@ -221,3 +221,35 @@ def test_end_to_end_pair_pipeline(dev):
     assert info["n_valid"] == info_o["n_valid"] and info["inliers"] == info_o["inliers"]
     rte, rre = registration.rte_rre(T, T_o)
     assert rte < 1e-3 and rre < 1e-3
+
+
+def test_register_batch_equals_pair_by_pair(dev):
+    """B pairs through one batched encoder call give the per-pair results (features to fp32 summation-order noise;
+    with the same correspondences the pose is the same hypothesis)."""
+    from apr_amd.fcgf.pipeline import PairRegistration
+    from tests.helpers import model_pair, rel_l2
+    _, hm = model_pair("ResUNetBN2C", 32)
+    hm.eval()
+    pipe = PairRegistration(hm, 0.3, ransac_iters=30000)
+    pairs = []
+    for s in (0, 1, 2):
+        a, b, _ = synth.make_pair(s, n_beams=16, n_azimuth=900 + 100 * s)
+        pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    single = [pipe(a, b, seed=7 + i) for i, (a, b) in enumerate(pairs)]
+    batch = pipe.register_batch(pairs, seeds=[7, 8, 9])
+    # features: batched vs separate encoder calls
+    maps, coords = pipe.voxelize_batch([c for p in pairs for c in p])
+    F = pipe.encode_batch(coords)
+    off = 0
+    for k, (a, b) in enumerate(pairs):
+        c1, p0, p1, n0, n1 = pipe.voxelize_pair(a, b)
+        F0, F1 = pipe.encode_pair(c1, n0)
+        assert maps[2 * k].n == n0 and maps[2 * k + 1].n == n1
+        assert rel_l2(F[off:off + n0].cpu(), F0.cpu()) < 1e-6 and rel_l2(F[off + n0:off + n0 + n1].cpu(), F1.cpu()) < 1e-6
+        off += n0 + n1
+    for (T1, i1), (T2, i2) in zip(single, batch):
+        assert i1["n0"] == i2["n0"] and i1["n1"] == i2["n1"]
+        if i1["best_iteration"] == i2["best_iteration"]:      # identical correspondences -> identical search
+            assert i1["inliers"] == i2["inliers"] and np.allclose(T1, T2, atol=1e-9)
+        else:                                                # an NN near-tie flipped: still a valid registration
+            assert abs(i1["inliers"] - i2["inliers"]) <= max(5, 0.05 * i1["inliers"])
