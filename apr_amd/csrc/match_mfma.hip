@@ -43,16 +43,13 @@ template <int C>
 __global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scale, float row_scale,
                           unsigned short* __restrict__ fb, unsigned short* __restrict__ fl, f32x4* __restrict__ meta,
                           unsigned* __restrict__ u_init, unsigned long long* __restrict__ best_init,
-                          unsigned* __restrict__ zero_me, unsigned* __restrict__ len_max) {
+                          unsigned* __restrict__ zero_me) {
   constexpr int LPR = C / 4;   // lanes per row
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t / LPR;
   const int g = (int)(t - row * LPR);
-  if (t == 0 && zero_me) {   // candidate counter and max target length (consumed by later launches)
-    zero_me[0] = 0u;
-    zero_me[1] = 0u;
-  }
-  float s = 0.f, row_len = 0.f;
+  if (t == 0 && zero_me) zero_me[0] = 0u;   // candidate counter
+  float s = 0.f;
   if (row < n) {
     f32x4 v = *reinterpret_cast<const f32x4*>(f + row * C + g * 4);
     s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -75,12 +72,6 @@ __global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scal
     meta[row] = (f32x4){len_scale * len, nn + sl, nn - sl, 0.f};
     if (u_init) u_init[row] = 0x7F800000u;
     if (best_init) best_init[row] = ~0ull;
-    row_len = len;
-  }
-  if (len_max) {   // one atomic per wave (non-negative floats order like their bits)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) row_len = fmaxf(row_len, __shfl_xor(row_len, d));
-    if ((threadIdx.x & 63) == 0) atomicMax(len_max, __float_as_uint(row_len));
   }
 }
 
@@ -105,8 +96,8 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
                                                  const f32x4* __restrict__ tmeta, int64_t n1, int chunk,
                                                  unsigned* __restrict__ U, unsigned long long* __restrict__ cand,
                                                  unsigned* __restrict__ cand_count, unsigned cand_cap) {
-  // cand_count[1] = bits of max_j |b_j| (k_nn_prep): eps(i,j) <= kEpsRel |a_i| max|b| + s_i + s_j keeps the bound
-  // rigorous and makes its |a||b| part a per-QUERY constant, so the per-element epilogue is one min / one compare
+  // eps(i,j) <= kEpsRel |a_i| max_j|b_j| + s_i + s_j (max over THIS workgroup's target chunk) keeps the bound rigorous
+  // and makes its |a||b| part a per-query constant, so the per-element epilogue is one min / one compare
   constexpr int KS = C / 32, QT = 4, TR = 64;          // TR target rows per LDS stage
   constexpr int LPT = (TR * C * 2) / 16 / 256;         // 16-B loads per thread per array and stage (C=32: 1)
   __shared__ __attribute__((aligned(16))) unsigned short s_h[2][TR * C];
@@ -119,7 +110,16 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
   const bool wave_live = q0 < n0;        // dead waves still stage and hit the barriers
   bf16x8 a[QT][KS], al[QT][KS];
   float thr[QT][4], mn[QT][4];
-  const float len_max = __uint_as_float(cand_count[1]);
+  const int64_t t0 = (int64_t)blockIdx.y * chunk;
+  const int64_t t1 = min((long long)(t0 + chunk), (long long)n1);
+  __shared__ float s_lmax[4];
+  float len_max = 0.f;
+  for (int64_t j = t0 + tid; j < t1; j += 256) len_max = fmaxf(len_max, tmeta[j][0]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) len_max = fmaxf(len_max, __shfl_xor(len_max, d));
+  if (lane == 0) s_lmax[wave] = len_max;
+  __syncthreads();
+  len_max = fmaxf(fmaxf(s_lmax[0], s_lmax[1]), fmaxf(s_lmax[2], s_lmax[3]));
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     int64_t ra = q0 + qt * 16 + l16;
@@ -139,8 +139,6 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
       thr[qt][r] = (REFINE && live) ? __uint_as_float(U[row]) - m[2] + m[0] * len_max : -__builtin_inff();
     }
   }
-  const int64_t t0 = (int64_t)blockIdx.y * chunk;
-  const int64_t t1 = min((long long)(t0 + chunk), (long long)n1);
   int ncand = 0;                         // entries in this wave's LDS buffer (wave-uniform)
   unsigned* my_cand = s_cand + (REFINE ? wave * kCandBuf : 0);
 
@@ -389,9 +387,9 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
   const unsigned cap = (unsigned)cand_capacity(n0);
   constexpr int LPR = C / 4;
   hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n0 * LPR, 256)), dim3(256), 0, st, f0, n0, kEpsRel, -2.0f, qb,
-                     ql, qmeta, U, best, cand_count, (unsigned*)nullptr);
+                     ql, qmeta, U, best, cand_count);
   hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n1 * LPR, 256)), dim3(256), 0, st, f1, n1, 1.0f, 1.0f, tb, tl,
-                     tmeta, (unsigned*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr, cand_count + 1);
+                     tmeta, (unsigned*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr);
   const int64_t qblocks = cdiv64(n0, 256);
   int64_t want = cdiv64(768, qblocks);
   int64_t chunk = cdiv64(cdiv64(n1, want), 64) * 64;
