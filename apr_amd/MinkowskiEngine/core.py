@@ -206,22 +206,30 @@ class SparseTensor:
 
     def __iadd__(self, other):
         self._check_same_map(other)
-        ops.affine_act(self.F, residual=other.F, out=self.F)
+        if _tracking(self.F, other.F):
+            self.F = self.F + other.F          # autograd: out of place
+        else:
+            ops.affine_act(self.F, residual=other.F, out=self.F)
         return self
 
     def __add__(self, other):
         self._check_same_map(other)
+        if _tracking(self.F, other.F):
+            return self._like(self.F + other.F)
         return self._like(ops.affine_act(self.F, residual=other.F))
 
     def __repr__(self):
         return f"SparseTensor(N={len(self)}, C={self.F.shape[1]}, {self.coordinate_map_key})"
 
 
+def _tracking(*tensors):
+    """Autograd is recording and at least one of the tensors / parameters takes part in it."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def _no_grad_guard(module):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters(recurse=False)):
-        raise AprHipError(
-            "apr_amd sparse ops are forward-only (backward is SURVEY 8(f) next-3): "
-            "call them under torch.no_grad()")
+        raise AprHipError("this apr_amd op is forward-only: call it under torch.no_grad()")
 
 
 class MinkowskiNetwork(nn.Module):
@@ -296,11 +304,30 @@ class _ConvBase(nn.Module):
                   self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
                   relu=relu, out=out, n_out=n_out, plist=plist)
 
+    def _reverse_map(self, x: SparseTensor, nbr_fwd, ts_out):
+        """Map of the input gradient: (table, mirrored offsets?)  (backward)."""
+        ts = x.coordinate_map_key.stride
+        cm = x.coordinate_manager
+        if ts == ts_out:                       # same level: the same table under the mirrored offset
+            return nbr_fwd, True
+        if not self.TRANSPOSE:                 # fine -> coarse: its transposed-conv table (coarse rows per fine row)
+            return cm.kernel_map(ts_out, ts, self.kernel_size, True), False
+        return cm.kernel_map(ts_out, ts, self.kernel_size, False), False   # coarse -> fine: the strided table
+
     def forward(self, x: SparseTensor):
-        _no_grad_guard(self)
         if x.F.shape[1] != self.in_channels:
             raise AprHipError(f"conv expects {self.in_channels} input channels, got {x.F.shape[1]}")
         nbr, ts_out = self._maps(x)
+        if _tracking(x.F, self.kernel, self.bias):
+            # training: forward + both gradients on the HIP kernels through autograd (SURVEY 8(f) next-3)
+            if nbr is None:
+                F = x.F @ self.kernel
+            else:
+                nbr_bwd, flip = self._reverse_map(x, nbr, ts_out)
+                F = ops.SparseConvFunction.apply(x.F, self.kernel, nbr, nbr_bwd, flip)
+            if self.bias is not None:
+                F = F + self.bias
+            return x._like(F, CoordinateMapKey(ts_out))
         n_out = x.coordinate_manager.size(ts_out)
         F = self.run(x.F, nbr, n_out)
         return x._like(F, CoordinateMapKey(ts_out))
@@ -354,8 +381,8 @@ class MinkowskiBatchNorm(nn.Module):
 
     def forward(self, x: SparseTensor):
         bn = self.bn
-        if torch.is_grad_enabled() and bn.weight is not None and bn.weight.requires_grad:
-            raise AprHipError("apr_amd sparse ops are forward-only: call under torch.no_grad()")
+        if _tracking(x.F, bn.weight, bn.bias):
+            return x._like(bn(x.F))            # training: torch's BatchNorm1d (autograd + running statistics)
         if self.training or not bn.track_running_stats:
             mean, var = ops.bn_stats(x.F)
             if bn.track_running_stats:
@@ -382,11 +409,21 @@ class MinkowskiInstanceNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, num_features))
 
     def forward(self, x: SparseTensor):
-        _no_grad_guard(self)
         b = x.C[:, 0]
         nb = int(b.max().item()) + 1
         # rows of one cloud are contiguous (collate order is preserved by first-occurrence maps)
         counts = torch.bincount(b, minlength=nb).cpu().tolist()
+        if _tracking(x.F, self.weight, self.bias):
+            segs, r0 = [], 0                   # training: plain torch ops per cloud
+            for n in counts:
+                if n == 0:
+                    continue
+                seg = x.F[r0:r0 + n]
+                mean = seg.mean(0, keepdim=True)
+                var = seg.var(0, unbiased=False, keepdim=True)
+                segs.append((seg - mean) * torch.rsqrt(var + self.eps) * self.weight + self.bias)
+                r0 += n
+            return x._like(torch.cat(segs, 0))
         out = torch.empty_like(x.F)
         r0 = 0
         for n in counts:
@@ -407,6 +444,8 @@ class MinkowskiReLU(nn.Module):
 
 
 def relu(x: SparseTensor):
+    if _tracking(x.F):
+        return x._like(torch.relu(x.F))
     return x._like(ops.affine_act(x.F, relu=True))
 
 
@@ -416,6 +455,8 @@ def cat(*tensors):
     a = tensors[0]
     for t in tensors[1:]:
         a._check_same_map(t)
+    if _tracking(*[t.F for t in tensors]):
+        return a._like(torch.cat([t.F for t in tensors], 1))
     n = len(a)
     ctot = sum(t.F.shape[1] for t in tensors)
     out = torch.empty((n, ctot), dtype=torch.float32, device=a.F.device)

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "apr_pairlist_bytes": (_sz, [_i64, _i32]),
     "apr_pairlist_build": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
     "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
+    "apr_spconv_wgrad_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "apr_spconv_wgrad": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "apr_spconv_fwd_batch": (C.c_int, [_p, _i32, _p]),
     "apr_spconv_fwd_batch_timed": (C.c_int, [_p, _i32, _p, _p]),
     "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),

@@ -5,7 +5,11 @@ signature and sampling of HardestContrastiveLossTrainer (FCGF_APR/lib/trainer.py
 lib/complement_trainer.py:296-348): the three `np.random.choice` draws stay on the host RNG in the same
 order, everything after them (gathers, two nearest-negative searches, the positive-pair filter, both hinge
 terms and their means) runs in HIP kernels with no host round trip until the two scalars come back.
-Backward is SURVEY 8(f) next-3.
+
+Training: when the features take part in autograd the mining (gathers + the two
+nearest-negative searches) still runs on the HIP kernels under no_grad, and the loss itself is rebuilt from the
+mined indices with differentiable torch ops — the same expression as the reference, whose `min` passes gradients
+only to the arg-min element, i.e. to exactly the rows gathered here.
 """
 import numpy as np
 import torch
@@ -31,10 +35,27 @@ class HardestContrastiveLoss:
     def __init__(self, pos_thresh=0.1, neg_thresh=1.4):   # config.py:34-35
         self.pos_thresh, self.neg_thresh = pos_thresh, neg_thresh
 
-    @torch.no_grad()
     def contrastive_hardest_negative_loss(self, F0, F1, positive_pairs, num_pos=5192, num_hn_samples=2048, thresh=None,
                                           draws=None):
-        """-> (pos_loss, neg_loss) 0-d CPU tensors.  `draws=(sel0, sel1, pos_sel)` overrides the RNG (tests)."""
+        """-> (pos_loss, neg_loss).  Under no_grad: 0-d CPU tensors (forward value only).  With features that
+        require grad: differentiable 0-d GPU tensors.  `draws=(sel0, sel1, pos_sel)` overrides the RNG (tests)."""
+        track = torch.is_grad_enabled() and (F0.requires_grad or F1.requires_grad)
+        with torch.no_grad():
+            res = self._mine_and_reduce(F0, F1, positive_pairs, num_pos, num_hn_samples, draws, mine_only=track)
+        if not track:
+            return res
+        pos0_d, pos1_d, d01ind, d10ind, keys_d, hash_seed = res
+        posF0, posF1 = F0[pos0_d], F1[pos1_d]
+        d01 = torch.sqrt((posF0 - F1[d01ind]).pow(2).sum(1) + 1e-7)      # lib/metrics.py:pdist 'L2'
+        d10 = torch.sqrt((posF1 - F0[d10ind]).pow(2).sum(1) + 1e-7)
+        mask0 = ~torch.isin(pos0_d + d01ind * hash_seed, keys_d)
+        mask1 = ~torch.isin(d10ind + pos1_d * hash_seed, keys_d)
+        pos_loss = torch.relu((posF0 - posF1).pow(2).sum(1) - self.pos_thresh)
+        neg0 = torch.relu(self.neg_thresh - d01[mask0]).pow(2)
+        neg1 = torch.relu(self.neg_thresh - d10[mask1]).pow(2)
+        return pos_loss.mean(), (neg0.mean() + neg1.mean()) / 2
+
+    def _mine_and_reduce(self, F0, F1, positive_pairs, num_pos, num_hn_samples, draws, mine_only):
         N0, N1 = len(F0), len(F1)
         if not isinstance(positive_pairs, np.ndarray):
             positive_pairs = np.array(positive_pairs.cpu() if torch.is_tensor(positive_pairs) else positive_pairs,
@@ -64,6 +85,8 @@ class HardestContrastiveLoss:
         nn10 = torch.empty(p, dtype=torch.int64, device=dev)
         check(lib.apr_feature_nn(ptr(posF0), p, ptr(subF1), subF1.shape[0], c, ptr(nn01), stream()))
         check(lib.apr_feature_nn(ptr(posF1), p, ptr(subF0), subF0.shape[0], c, ptr(nn10), stream()))
+        if mine_only:       # packed (bits(d2) << 32 | index into the sub-sample) -> row indices of the full clouds
+            return (pos0_d, pos1_d, sel1_d[nn01 & 0xFFFFFFFF], sel0_d[nn10 & 0xFFFFFFFF], keys_d, int(hash_seed))
         out = torch.empty(6, dtype=torch.float64, device=dev)
         check(lib.apr_contrastive_reduce(ptr(posF0), ptr(posF1), p, c, ptr(nn01), ptr(nn10), ptr(sel0_d), ptr(sel1_d),
                                          ptr(pos0_d), ptr(pos1_d), ptr(keys_d), keys_d.shape[0], int(hash_seed),

@@ -117,13 +117,17 @@ class ResUNet2(ME.MinkowskiNetwork):
         out = MEF.relu(self.conv1_tr(out))
         out = self.final(out)
         if self.normalize_feature:
-            return ME.SparseTensor(ops.l2_normalize(out.F), coordinate_map_key=out.coordinate_map_key,
+            if torch.is_grad_enabled() and out.F.requires_grad:     # resunet.py:187-190, through autograd
+                F = out.F / torch.norm(out.F, p=2, dim=1, keepdim=True)
+            else:
+                F = ops.l2_normalize(out.F)
+            return ME.SparseTensor(F, coordinate_map_key=out.coordinate_map_key,
                                    coordinate_manager=out.coordinate_manager)
         return out
 
     # ------------------------------------------------------------------ fused
     def _can_fuse(self):
-        return (self.use_fused and not self.training and self.NORM_TYPE == 'BN'
+        return (self.use_fused and not self.training and not torch.is_grad_enabled() and self.NORM_TYPE == 'BN'
                 and self.BLOCK_NORM_TYPE == 'BN')
 
     def forward_fused(self, x):

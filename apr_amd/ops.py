@@ -255,6 +255,53 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
     return out
 
 
+def spconv_wgrad(x, dout, nbr, K, cin, cout):
+    """dW f32 [K, cin, cout] = sum_j [nbr[j,k] >= 0] x[nbr[j,k]]^T dout[j]  (nbr None: identity map, K = 1)."""
+    x, ldi = _rows(x, "spconv_wgrad.x")
+    dout, ldo = _rows(dout, "spconv_wgrad.dout")
+    n_out = dout.shape[0]
+    if x.shape[1] != cin or dout.shape[1] != cout:
+        raise _lib.AprHipError("spconv_wgrad: channel mismatch")
+    if nbr is not None and (nbr.dtype != torch.int32 or not nbr.is_contiguous() or tuple(nbr.shape) != (n_out, K)):
+        raise _lib.AprHipError("spconv_wgrad: nbr must be a contiguous int32 [n_out, K] tensor")
+    lib = _lib_()
+    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
+    sb = int(lib.apr_spconv_wgrad_scratch_bytes(n_out, K, cin, cout))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    check(lib.apr_spconv_wgrad(ptr(x), ldi, ptr(dout), ldo, ptr(nbr), n_out, K, cin, cout, ptr(dw), ptr(scratch), sb,
+                               stream()))
+    return dw
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """out = spconv(feats, nbr_fwd, kernel) with its two gradients on the HIP kernels:
+    d feats = spconv(dout, nbr_bwd, kernel[mirror]^T)  — the same operator over the reverse map;
+    d kernel = apr_spconv_wgrad.  `flip`: same-level map, reverse pairs sit under the mirrored offset K-1-k."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, nbr_fwd, nbr_bwd, flip):
+        K, cin, cout = kernel.shape
+        feats = feats.contiguous()
+        out = spconv(feats, nbr_fwd, K, cin, cout, pack_weights(kernel.detach()))
+        ctx.save_for_backward(feats, kernel)
+        ctx.maps = (nbr_fwd, nbr_bwd, bool(flip))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, kernel = ctx.saved_tensors
+        nbr_fwd, nbr_bwd, flip = ctx.maps
+        K, cin, cout = kernel.shape
+        dout = dout.contiguous()
+        din = dw = None
+        if ctx.needs_input_grad[0]:
+            wb = (kernel.flip(0) if flip else kernel).detach().transpose(1, 2).contiguous()
+            din = spconv(dout, nbr_bwd, K, cout, cin, pack_weights(wb))
+        if ctx.needs_input_grad[1]:
+            dw = spconv_wgrad(feats, dout, nbr_fwd, K, cin, cout)
+        return din, dw, None, None, None
+
+
 class SpconvBatch:
     """Collects sparse-conv launches and enqueues them with ONE library call (apr_spconv_fwd_batch)."""
 

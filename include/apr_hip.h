@@ -132,6 +132,16 @@ int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, con
                       const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
                       float* prod_scratch, void* stream);
 
+/* Weight gradient of apr_spconv_fwd (training; replaces what autograd does inside
+ * MinkowskiConvolution / MinkowskiConvolutionTranspose, FCGF_APR/lib/trainer.py:454-527):
+ *   dw f32[K, cin, cout] (plain layout, not packed) = sum_j [nbr[j,k] >= 0] in[nbr[j,k], :]^T dout[j, :].
+ * nbr NULL = identity map (K = 1).  Deterministic (per-chunk partial sums reduced in fixed order).
+ * The input gradient is apr_spconv_fwd itself: dout over the reverse map with transposed weights. */
+size_t apr_spconv_wgrad_scratch_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout);
+int apr_spconv_wgrad(const float* in, int64_t ldi, const float* dout, int64_t ldo, const int32_t* nbr, int64_t n_out,
+                     int32_t K, int32_t cin, int32_t cout, float* dw, void* scratch, size_t scratch_bytes,
+                     void* stream);
+
 /* One launch description of apr_spconv_fwd; apr_spconv_fwd_batch enqueues n of them back to back
  * from a single call (the 23 fused conv launches of one ResUNet encode), so a host binding pays
  * one FFI transition instead of 23 and can overlap several encodes from different host threads. */

@@ -1,0 +1,179 @@
+"""Backward passes: sparse conv / transposed conv gradients on the HIP kernels, the encoder in
+training mode and the hardest-contrastive loss, against autograd through the CPU oracle (torch ops)."""
+import numpy as np
+import pytest
+import torch
+
+from apr_amd import MinkowskiEngine as ME
+from apr_amd import ops, synth
+from apr_amd.fcgf.lib.trainer import HardestContrastiveLoss
+from oracle import match_pose_oracle as MO
+from oracle import me_oracle as OME
+from tests.helpers import model_pair, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv(x, nbr, W):
+    """Differentiable float64 reference: out[j] = sum_k x[nbr[j,k]] @ W[k] over the non-empty entries."""
+    out = torch.zeros(nbr.shape[0], W.shape[2], dtype=torch.float64)
+    for k in range(nbr.shape[1]):
+        j = np.nonzero(nbr[:, k] >= 0)[0]
+        if len(j):
+            out = out.index_add(0, torch.from_numpy(j), x[torch.from_numpy(nbr[j, k].astype(np.int64))] @ W[k])
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,K,n_in,n_out", [(32, 32, 27, 900, 900), (64, 128, 27, 700, 250), (128, 64, 27, 200, 900),
+                                                    (1, 32, 125, 1500, 1500), (96, 64, 27, 513, 1031), (3, 5, 27, 100, 77)])
+def test_wgrad_kernel_matches_autograd(dev, cin, cout, K, n_in, n_out):
+    rng = np.random.default_rng(cin + cout + K)
+    x = torch.from_numpy(rng.standard_normal((n_in, cin)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((n_out, cout)).astype(np.float32))
+    nbr = rng.integers(0, n_in, size=(n_out, K)).astype(np.int32)
+    nbr[rng.random((n_out, K)) > 0.3] = -1
+    W = torch.zeros(K, cin, cout, dtype=torch.float64, requires_grad=True)
+    (_ref_conv(x.double(), nbr, W) * g.double()).sum().backward()
+    dw = ops.spconv_wgrad(x.to(dev), g.to(dev), torch.from_numpy(nbr).to(dev), K, cin, cout)
+    assert rel_l2(dw.cpu(), W.grad) < 2e-6
+    again = ops.spconv_wgrad(x.to(dev), g.to(dev), torch.from_numpy(nbr).to(dev), K, cin, cout)
+    assert torch.equal(dw, again)                      # deterministic
+
+
+@pytest.mark.parametrize("kind", ["same", "strided", "transposed"])
+def test_conv_module_gradients(dev, kind):
+    """MinkowskiConvolution / Transpose under autograd: d input and d kernel vs autograd through the oracle conv."""
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(-6, 6, (3000, 3)).astype(np.float32)
+    c, _ = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+    C = OME.batched_coordinates([c])
+    cin, cout = 32, 64
+    F = rng.standard_normal((len(C), cin)).astype(np.float32)
+    # oracle chain: optional stride-2 conv first so that a coarse level exists
+    ox = OME.SparseTensor(torch.from_numpy(F).requires_grad_(True), coordinates=C)
+    hx = ME.SparseTensor(torch.from_numpy(F).to(dev).requires_grad_(True), coordinates=torch.from_numpy(C).to(dev))
+    Wd = torch.from_numpy((rng.standard_normal((27, cin, cin)) * 0.1).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32))
+    down_h = ME.MinkowskiConvolution(cin, cin, kernel_size=3, stride=2, dimension=3).to(dev)
+    with torch.no_grad():
+        down_h.kernel.copy_(Wd)
+    if kind == "same":
+        conv_h = ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, dimension=3).to(dev)
+        oy = OME.conv_forward(ox, W.clone().requires_grad_(True), 3, 1)
+        Wo = oy  # placeholder, replaced below
+    elif kind == "strided":
+        conv_h = ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=2, dimension=3).to(dev)
+    else:
+        conv_h = ME.MinkowskiConvolutionTranspose(cin, cout, kernel_size=3, stride=2, dimension=3).to(dev)
+    with torch.no_grad():
+        conv_h.kernel.copy_(W)
+    Wo = W.clone().requires_grad_(True)
+    Wdo = Wd.clone().requires_grad_(True)
+    if kind == "same":
+        oy = OME.conv_forward(ox, Wo, 3, 1)
+        hy = conv_h(hx)
+    elif kind == "strided":
+        oy = OME.conv_forward(ox, Wo, 3, 2)
+        hy = conv_h(hx)
+    else:
+        oy = OME.conv_forward(OME.conv_forward(ox, Wdo, 3, 2), Wo, 3, 2, transpose=True)
+        hy = conv_h(down_h(hx))
+    proj = torch.from_numpy(rng.standard_normal(tuple(oy.F.shape)).astype(np.float32))
+    assert rel_l2(hy.F.detach().cpu(), oy.F.detach()) < 1e-5
+    (oy.F * proj).sum().backward()
+    (hy.F * proj.to(dev)).sum().backward()
+    assert rel_l2(conv_h.kernel.grad.cpu(), Wo.grad) < 1e-5
+    assert rel_l2(hx.F.grad.cpu(), ox.F.grad) < 1e-5
+    if kind == "transposed":
+        assert rel_l2(down_h.kernel.grad.cpu(), Wdo.grad) < 1e-5
+
+
+def test_encoder_training_step_gradients(dev):
+    """ResUNetBN2C in train mode: forward, a scalar loss, backward — every parameter gradient and the BN running
+    statistics against the oracle network (same state_dict) on the CPU."""
+    om, hm = model_pair("ResUNetBN2C", 32)
+    om.train(); hm.train()
+    xyz, _, _ = synth.make_pair(5, n_beams=16, n_azimuth=700)
+    c, _ = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+    C = OME.batched_coordinates([c])
+    F = np.ones((len(C), 1), np.float32)
+    oy = om(OME.SparseTensor(torch.from_numpy(F), coordinates=C)).F
+    hy = hm(ME.SparseTensor(torch.from_numpy(F).to(dev), coordinates=torch.from_numpy(C).to(dev))).F
+    assert rel_l2(hy.detach().cpu(), oy.detach()) < 1e-4
+    proj = torch.from_numpy(np.random.default_rng(0).standard_normal(tuple(oy.shape)).astype(np.float32))
+    (oy * proj).sum().backward()
+    (hy * proj.to(dev)).sum().backward()
+    og = dict(om.named_parameters())
+    worst = 0.0
+    for name, p in hm.named_parameters():
+        assert p.grad is not None, name
+        worst = max(worst, rel_l2(p.grad.cpu(), og[name].grad))
+    assert worst < 2e-3, worst                       # fp32 through 23 conv + 22 BN layers, two different BN kernels
+    ob = dict(om.named_buffers())
+    for name, b in hm.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            assert torch.allclose(b.cpu(), ob[name], rtol=1e-3, atol=1e-5), name
+
+
+def test_hardest_contrastive_loss_backward(dev):
+    rng = np.random.default_rng(2)
+    n0, n1, c = 3000, 2800, 32
+    F0 = rng.standard_normal((n0, c)).astype(np.float32); F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+    F1 = rng.standard_normal((n1, c)).astype(np.float32); F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    pairs = np.stack([rng.permutation(n0)[:1500], rng.permutation(n1)[:1500]], 1).astype(np.int64)
+    F1[pairs[:, 1]] = F0[pairs[:, 0]] + 0.2 * rng.standard_normal((1500, c)).astype(np.float32)
+    sel0 = rng.choice(n0, 1024, replace=False); sel1 = rng.choice(n1, 1024, replace=False)
+    pos_sel = rng.choice(1500, 600, replace=False)
+    a = torch.from_numpy(F0).requires_grad_(True); b = torch.from_numpy(F1).requires_grad_(True)
+    pl_o, nl_o = MO.hardest_contrastive(a, b, pairs, sel0, sel1, pos_sel)
+    (pl_o + nl_o).backward()
+    ga = torch.from_numpy(F0).to(dev).requires_grad_(True); gb = torch.from_numpy(F1).to(dev).requires_grad_(True)
+    crit = HardestContrastiveLoss()
+    pl, nl = crit.contrastive_hardest_negative_loss(ga, gb, pairs, num_pos=600, num_hn_samples=1024,
+                                                    draws=(sel0, sel1, pos_sel))
+    assert abs(pl.item() - pl_o.item()) < 1e-5 and abs(nl.item() - nl_o.item()) < 1e-5
+    (pl + nl).backward()
+    assert rel_l2(ga.grad.cpu(), a.grad) < 1e-5 and rel_l2(gb.grad.cpu(), b.grad) < 1e-5
+
+
+def test_two_sgd_steps_follow_the_oracle(dev):
+    """The reference's training iteration (lib/trainer.py:454-527: encode both frames, hardest-contrastive loss,
+    backward, optimiser step) run twice on the HIP path and on the CPU oracle from the same weights, pairs and
+    random draws: losses and the updated weights stay together."""
+    om, hm = model_pair("ResUNetBN2C", 32, seed=4)
+    om.train(); hm.train()
+    xyz0, xyz1, T = synth.make_pair(9, n_beams=16, n_azimuth=600)
+    cs, pts = [], []
+    for xyz in (xyz0, xyz1):
+        c, sel = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+        cs.append(c); pts.append(xyz[sel])
+    # ground-truth positive pairs: voxels of frame 0 whose transformed point has a frame-1 voxel point within 0.3 m
+    p0 = pts[0].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    d = ((p0[:, None, :] - pts[1][None, :, :].astype(np.float64)) ** 2).sum(-1)
+    j = d.argmin(1)
+    keep = d[np.arange(len(j)), j] < 0.3 ** 2
+    pairs = np.stack([np.nonzero(keep)[0], j[keep]], 1).astype(np.int64)
+    assert len(pairs) > 200
+    C0, C1 = OME.batched_coordinates([cs[0]]), OME.batched_coordinates([cs[1]])
+    rng = np.random.default_rng(0)
+    opt_o = torch.optim.SGD(om.parameters(), lr=0.05, momentum=0.8)
+    opt_h = torch.optim.SGD(hm.parameters(), lr=0.05, momentum=0.8)
+    crit = HardestContrastiveLoss()
+    for step in range(2):
+        sel0 = rng.choice(len(C0), 512, replace=False); sel1 = rng.choice(len(C1), 512, replace=False)
+        pos_sel = rng.choice(len(pairs), 200, replace=False)
+        opt_o.zero_grad(); opt_h.zero_grad()
+        of0 = om(OME.SparseTensor(torch.ones(len(C0), 1), coordinates=C0)).F
+        of1 = om(OME.SparseTensor(torch.ones(len(C1), 1), coordinates=C1)).F
+        pl_o, nl_o = MO.hardest_contrastive(of0, of1, pairs, sel0, sel1, pos_sel)
+        (pl_o + nl_o).backward(); opt_o.step()
+        hf0 = hm(ME.SparseTensor(torch.ones(len(C0), 1, device=dev), coordinates=torch.from_numpy(C0).to(dev))).F
+        hf1 = hm(ME.SparseTensor(torch.ones(len(C1), 1, device=dev), coordinates=torch.from_numpy(C1).to(dev))).F
+        pl, nl = crit.contrastive_hardest_negative_loss(hf0, hf1, pairs, num_pos=200, num_hn_samples=512,
+                                                        draws=(sel0, sel1, pos_sel))
+        (pl + nl).backward(); opt_h.step()
+        assert abs(pl.item() - pl_o.item()) < 2e-3 * max(1.0, abs(pl_o.item())), (step, pl.item(), pl_o.item())
+        assert abs(nl.item() - nl_o.item()) < 2e-3 * max(1.0, abs(nl_o.item())), (step, nl.item(), nl_o.item())
+    op = dict(om.named_parameters())
+    for name, p in hm.named_parameters():
+        assert rel_l2(p.detach().cpu(), op[name].detach()) < 1e-3, name
