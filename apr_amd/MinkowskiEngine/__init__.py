@@ -15,7 +15,8 @@ reference call sites:
 
 `apr_amd.install_shims()` registers this package as `MinkowskiEngine` in
 sys.modules so `import MinkowskiEngine as ME` in the reference's files resolves
-here.  Forward only (backward is SURVEY 8(f) next-3); GPU tensors only.
+here.  Inference (no_grad / eval) runs the fused HIP plan; when autograd is recording the same modules
+run forward and backward through `ops.SparseConvFunction`.  GPU tensors only.
 """
 from .core import (CoordinateManager, CoordinateMapKey, SparseTensor, MinkowskiNetwork,  # noqa: F401
                    MinkowskiConvolution, MinkowskiConvolutionTranspose, MinkowskiBatchNorm,
