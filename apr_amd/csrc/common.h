@@ -39,6 +39,25 @@ void apr_set_error(const char* fmt, ...);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// match.hip: brute-force NN into an initialised `best`, run only if *run_if != 0 (NULL: always)
+int apr_internal_nn_brute(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,
+                          const unsigned* run_if, void* stream);
+
+#ifdef __HIPCC__
+// Inclusive prefix sum over the 64 lanes with DPP adds only (no ds_bpermute round trips, ~6 VALU instead of 6
+// LDS-crossbar shuffles): 4 shifts inside each row of 16 lanes, then the row totals are broadcast into the
+// following rows (gfx9 row_bcast:15 / row_bcast:31).
+__device__ inline int apr_wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+#endif
+
 // ---- packed voxel key: (b:10 | x:18 | y:18 | z:18), x/y/z biased by 2^17 ----
 #define APR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define APR_AXIS_BIAS (1 << 17)

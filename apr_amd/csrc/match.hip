@@ -28,7 +28,9 @@ constexpr int kTR = 64;  // granularity of the target split
 template <int C, int QPT>
 __global__ __launch_bounds__(256) void k_feature_nn(const float* __restrict__ f0, int64_t n0,
                                                     const float* __restrict__ f1, int64_t n1,
-                                                    int chunk, unsigned long long* __restrict__ best) {
+                                                    int chunk, unsigned long long* __restrict__ best,
+                                                    const unsigned* __restrict__ run_if) {
+  if (run_if && *run_if == 0u) return;   // predicated launch (fallback of the filter + refine path)
   const int tid = threadIdx.x;
   const int64_t qbase = (int64_t)blockIdx.x * 256 * QPT;
   f32x2 nq[QPT][C / 2];   // NEGATED query rows: d = b + (-a) = -(a - b), d*d is bit-identical
@@ -108,7 +110,9 @@ __global__ __launch_bounds__(256) void k_feature_nn(const float* __restrict__ f0
 template <int C, int QPT>
 __global__ __launch_bounds__(256) void k_feature_nn_lds(const float* __restrict__ f0, int64_t n0,
                                                         const float* __restrict__ f1, int64_t n1,
-                                                        int chunk, unsigned long long* __restrict__ best) {
+                                                        int chunk, unsigned long long* __restrict__ best,
+                                                        const unsigned* __restrict__ run_if) {
+  if (run_if && *run_if == 0u) return;
   __shared__ __attribute__((aligned(16))) float s_t[kTR * C];
   const int tid = threadIdx.x;
   const int64_t qbase = (int64_t)blockIdx.x * 256 * QPT;
@@ -206,7 +210,7 @@ __global__ void k_nn_unpack(const unsigned long long* __restrict__ best, int64_t
 
 template <int C, int QPT>
 int launch_nn_q(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best,
-                hipStream_t st) {
+                const unsigned* run_if, hipStream_t st) {
   const int64_t qblocks = cdiv64(n0, 256 * QPT);
   // enough target chunks to give >= ~4 workgroups per CU, at least one 64-row granule each
   int64_t want = cdiv64(1024, qblocks);
@@ -215,23 +219,36 @@ int launch_nn_q(const float* f0, int64_t n0, const float* f1, int64_t n1, unsign
   const int64_t msplit = cdiv64(n1, chunk);
   if (C <= 32)
     hipLaunchKernelGGL((k_feature_nn<C, QPT>), dim3((unsigned)qblocks, (unsigned)msplit), dim3(256), 0, st, f0,
-                       n0, f1, n1, (int)chunk, best);
+                       n0, f1, n1, (int)chunk, best, run_if);
   else
     hipLaunchKernelGGL((k_feature_nn_lds<C, QPT>), dim3((unsigned)qblocks, (unsigned)msplit), dim3(256), 0, st,
-                       f0, n0, f1, n1, (int)chunk, best);
+                       f0, n0, f1, n1, (int)chunk, best, run_if);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
 
 template <int C>
 int launch_nn(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best,
-              hipStream_t st) {
+              const unsigned* run_if, hipStream_t st) {
   static const int s_qpt = env_int("APR_NN_QPT", 0);
-  if (C <= 32 && s_qpt == 4) return launch_nn_q<C, 4>(f0, n0, f1, n1, best, st);
-  return launch_nn_q<C, (C <= 64) ? 2 : 1>(f0, n0, f1, n1, best, st);
+  if (C <= 32 && s_qpt == 4) return launch_nn_q<C, 4>(f0, n0, f1, n1, best, run_if, st);
+  return launch_nn_q<C, (C <= 64) ? 2 : 1>(f0, n0, f1, n1, best, run_if, st);
 }
 
 }  // namespace
+
+// brute force into an ALREADY initialised `best`, executed only if *run_if != 0 (device side); c in 16/32/64/128
+int apr_internal_nn_brute(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,
+                          const unsigned* run_if, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* b = (unsigned long long*)best;
+  if (c == 16) return launch_nn<16>(f0, n0, f1, n1, b, run_if, st);
+  if (c == 32) return launch_nn<32>(f0, n0, f1, n1, b, run_if, st);
+  if (c == 64) return launch_nn<64>(f0, n0, f1, n1, b, run_if, st);
+  if (c == 128) return launch_nn<128>(f0, n0, f1, n1, b, run_if, st);
+  apr_set_error("apr_internal_nn_brute: unsupported channel count %d", c);
+  return APR_EINVAL;
+}
 
 APR_API int apr_feature_nn(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c,
                            uint64_t* best, void* stream) {
@@ -242,10 +259,10 @@ APR_API int apr_feature_nn(const float* f0, int64_t n0, const float* f1, int64_t
   APR_HIP(hipMemsetAsync(best, 0xFF, (size_t)n0 * 8, st));
   unsigned long long* b = (unsigned long long*)best;
   const bool aligned = ((((uintptr_t)f0) | ((uintptr_t)f1)) & 15) == 0;
-  if (aligned && c == 16) return launch_nn<16>(f0, n0, f1, n1, b, st);
-  if (aligned && c == 32) return launch_nn<32>(f0, n0, f1, n1, b, st);
-  if (aligned && c == 64) return launch_nn<64>(f0, n0, f1, n1, b, st);
-  if (aligned && c == 128) return launch_nn<128>(f0, n0, f1, n1, b, st);
+  if (aligned && c == 16) return launch_nn<16>(f0, n0, f1, n1, b, nullptr, st);
+  if (aligned && c == 32) return launch_nn<32>(f0, n0, f1, n1, b, nullptr, st);
+  if (aligned && c == 64) return launch_nn<64>(f0, n0, f1, n1, b, nullptr, st);
+  if (aligned && c == 128) return launch_nn<128>(f0, n0, f1, n1, b, nullptr, st);
   const int64_t qblocks = cdiv64(n0, 256);
   int64_t chunk = cdiv64(n1, cdiv64(2048, qblocks));
   if (chunk < 64) chunk = 64;

@@ -18,8 +18,8 @@
 //           those — a handful per query — d is evaluated EXACTLY, in the oracle's order, and meets the others in the
 //           same 64-bit atomicMin on (bits(d) << 32 | j) as the brute-force kernel.
 // Candidates go to a list (wave-private LDS buffers, one global atomic per ~1000 entries) and are evaluated densely
-// by k_nn_exact; if the list (128 entries per query) overflows — near-identical features everywhere — a predicated
-// brute-force kernel takes over, so the result is exact for ANY input.
+// by k_nn_exact; if a wave's region of the list (2048 entries per 64 queries x one target chunk) overflows — near-
+// identical features everywhere — a predicated brute-force kernel takes over: the result is exact for ANY input.
 #include "common.h"
 
 namespace {
@@ -48,7 +48,10 @@ __global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scal
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t / LPR;
   const int g = (int)(t - row * LPR);
-  if (t == 0 && zero_me) zero_me[0] = 0u;   // candidate counter
+  if (t == 0 && zero_me) {   // overflow flag, shared-list counter
+    zero_me[0] = 0u;
+    zero_me[1] = 0u;
+  }
   float s = 0.f;
   if (row < n) {
     f32x4 v = *reinterpret_cast<const f32x4*>(f + row * C + g * 4);
@@ -81,11 +84,16 @@ __global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scal
 // registers.  Targets stream through LDS in chunks of 64 rows (hi, lo, meta), double buffered: the next chunk's
 // global loads are in flight while the current one feeds the MFMAs, one barrier per chunk; B fragments are
 // conflict-free ds_read_b128 (16 rows x 64 B contiguous per k-slice).
-// Candidates: per-lane 16-bit masks, ranked by a wave prefix sum into a wave-private LDS buffer (4-byte entries),
-// flushed to the global list with ONE atomicAdd per flush.  (Two alternatives measured slower on the bench's 58
-// candidates per query: per-element wave masks with v_mbcnt ranks, 149 us, and direct-to-global blocks, 174 us,
-// against 125 us for this form; the bound pass alone is 50 us.)
-constexpr int kCandBuf = 1280;   // per wave (flushed above 256); a 16-target tile adds <= 64 x 16 = 1024
+// Candidates: per-lane 16-bit masks, ranked by a DPP wave prefix sum into a wave-private LDS buffer (4-byte
+// entries), flushed with coalesced stores into the wave's OWN region of the global list (kCandWave slots) — no
+// global atomics at all (4000 waves bumping one counter at the end of the kernel cost ~15 us); the wave's count is
+// written once.  A wave that fills its region spills into one shared list (one atomic per flush, heavy waves only);
+// if that overflows too the flag arms the brute-force fallback.
+// (Measured slower on the bench's 58 candidates per query: per-element wave masks with v_mbcnt ranks, and
+// direct-to-global stores per candidate.)
+constexpr int kCandBuf = 1280;    // LDS entries per wave (flushed above 256); a 16-target tile adds <= 64 x 16 = 1024
+constexpr int kCandWave = 2048;   // global slots per wave
+constexpr int kDenseMin = 16;     // candidates in one 64 x 16 block from which the block is evaluated densely
 
 template <int C, bool REFINE>
 __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restrict__ qb,
@@ -95,7 +103,9 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
                                                  const unsigned short* __restrict__ tl,
                                                  const f32x4* __restrict__ tmeta, int64_t n1, int chunk,
                                                  unsigned* __restrict__ U, unsigned long long* __restrict__ cand,
-                                                 unsigned* __restrict__ cand_count, unsigned cand_cap) {
+                                                 unsigned* __restrict__ cand_count, unsigned* __restrict__ overflow,
+                                                 unsigned long long* __restrict__ shared_list, unsigned shared_cap,
+                                                 unsigned char* __restrict__ dense_flag, int dense_min) {
   // eps(i,j) <= kEpsRel |a_i| max_j|b_j| + s_i + s_j (max over THIS workgroup's target chunk) keeps the bound rigorous
   // and makes its |a||b| part a per-query constant, so the per-element epilogue is one min / one compare
   constexpr int KS = C / 32, QT = 4, TR = 64;          // TR target rows per LDS stage
@@ -142,17 +152,31 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
   int ncand = 0;                         // entries in this wave's LDS buffer (wave-uniform)
   unsigned* my_cand = s_cand + (REFINE ? wave * kCandBuf : 0);
 
+  const unsigned wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+  unsigned flushed = 0;                  // entries already in this wave's global region (wave-uniform)
+
   auto flush = [&]() {
     if (ncand == 0) return;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(cand_count, (unsigned)ncand);
-    base = __shfl(base, 0);
-    for (int e = lane; e < ncand; e += 64)
-      if (base + e < cand_cap) {          // past the capacity: dropped, the count tells (fallback)
-        const unsigned c = my_cand[e];
-        cand[base + e] = ((unsigned long long)(blockIdx.x * 256u + (c >> 24)) << 32) |
-                         (unsigned long long)(t0 + (c & 0xffffffu));
+    auto entry = [&](int e) {
+      const unsigned c = my_cand[e];
+      return ((unsigned long long)(blockIdx.x * 256u + (c >> 24)) << 32) | (unsigned long long)(t0 + (c & 0xffffffu));
+    };
+    if (flushed + ncand <= (unsigned)kCandWave) {
+      unsigned long long* dst = cand + (size_t)wave_id * kCandWave + flushed;
+      for (int e = lane; e < ncand; e += 64) dst[e] = entry(e);
+      flushed += ncand;
+    } else {
+      // this wave's region is full (heavy tail: clusters of near-identical features): the shared list takes the
+      // rest, one atomic per flush; only if THAT overflows too the brute-force fallback is armed
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&overflow[1], (unsigned)ncand);
+      base = __shfl(base, 0);
+      if (base + (unsigned)ncand <= shared_cap) {
+        for (int e = lane; e < ncand; e += 64) shared_list[base + e] = entry(e);
+      } else if (lane == 0) {
+        overflow[0] = 1u;
       }
+    }
     ncand = 0;
   };
 
@@ -252,15 +276,19 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (acc[qt][r] <= thr[qt][r]) cmask |= 1u << (qt * 4 + r);
+          if (lane == 0) dense_flag[(size_t)wave_id * (chunk >> 4) + ((jt - t0) >> 4) + tt] = 0;
           if (__any(cmask != 0)) {
             if (ncand > kCandBuf - 1024) flush();
             // wave prefix sum of the per-lane candidate counts -> ranks in the wave-private buffer
             const int c = __popc(cmask);
-            int incl = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-              const int t = __shfl_up(incl, d);
-              if (lane >= d) incl += t;
+            const int incl = apr_wave_incl_scan(c);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total >= dense_min) {
+              // a cluster of near-identical features: listing (and atomically reducing) dozens of pairs of this
+              // 64-query x 16-target block costs more than evaluating the whole block once -> k_nn_dense.
+              // One flag byte per wave-tile, no atomics (a shared counter stalled every dense tile ~1 us).
+              if (lane == 0) dense_flag[(size_t)wave_id * (chunk >> 4) + ((jt - t0) >> 4) + tt] = 1;
+              continue;
             }
             int pos = ncand + incl - c;
             const unsigned j = (unsigned)(jt - t0) + tt * 16 + l16;       // chunk < 2^24 (checked on the host)
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
               const unsigned i = wave * 64 + (e >> 2) * 16 + lq * 4 + (e & 3);
               my_cand[pos++] = (i << 24) | j;
             }
-            ncand += __shfl(incl, 63);
+            ncand += total;
           }
         }
       }
@@ -278,7 +306,10 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
     if (more) commit(buf ^ 1);
     __syncthreads();
   }
-  if (REFINE) flush();
+  if (REFINE) {
+    flush();
+    if (lane == 0) cand_count[wave_id] = flushed;
+  }
   if (!REFINE && wave_live) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
@@ -299,82 +330,148 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
   }
 }
 
-// One thread per candidate pair: the exact direct form in the oracle's order, 64-bit atomicMin like the brute-force
-// kernel.  Grid-stride over the device-side count.
+// Dense blocks: the refine pass left one flag byte per wave-tile (64 queries x 16 targets).  A wave reads 64 flags at
+// a time (interleaved so that clustered flags spread over all waves) and evaluates every flagged block:
+// lane = query with its row in registers, the 16 target rows wave-uniform (scalar loads), the oracle's direct form
+// for all 1024 pairs, a running strict-< minimum per lane (ascending j: ties keep the smaller index), ONE atomicMin
+// per query and block.
 template <int C>
-__global__ __launch_bounds__(256) void k_nn_exact(const unsigned long long* __restrict__ cand,
-                                                  const unsigned* __restrict__ cand_count, unsigned cand_cap,
-                                                  const float* __restrict__ f0, const float* __restrict__ f1,
+__global__ __launch_bounds__(256) void k_nn_dense(const unsigned char* __restrict__ dense_flag, int chunk,
+                                                  unsigned qwaves, unsigned nchunk, const float* __restrict__ f0,
+                                                  int64_t n0, const float* __restrict__ f1, int64_t n1,
                                                   unsigned long long* __restrict__ best) {
-  const unsigned n = min(*cand_count, cand_cap);
-  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    const unsigned long long ij = cand[t];
-    const int64_t i = (int64_t)(ij >> 32), j = (int64_t)(ij & 0xffffffffull);
-    const float* x = f0 + i * C;
-    const float* y = f1 + j * C;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int g = 0; g < C / 4; ++g) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + g * 4);
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + g * 4);
-      const float d0 = xv[0] - yv[0], d1 = xv[1] - yv[1], d2 = xv[2] - yv[2], d3 = xv[3] - yv[3];
-      s0 = fmaf(d0, d0, s0);
-      s1 = fmaf(d1, d1, s1);
-      s2 = fmaf(d2, d2, s2);
-      s3 = fmaf(d3, d3, s3);
+  const int lane = threadIdx.x & 63;
+  const unsigned tpc = (unsigned)chunk >> 4;                        // tiles per chunk
+  const unsigned nflag = qwaves * nchunk * tpc;                     // < 2^32 (checked on the host)
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  // group g, lane l looks at flag l * ngroups + g: the (up to chunk/16) dense tiles of one clustered refine wave are
+  // consecutive flags, this interleaving hands them to different waves here
+  const unsigned ngroups = (nflag + 63) / 64;
+  for (unsigned g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < ngroups; g += nwaves) {
+    const unsigned f = (unsigned)lane * ngroups + g;
+    bool flagged = false;
+    if (f < nflag) {
+      const unsigned wave_id = f / tpc, tile = f % tpc;
+      const int64_t q0 = (int64_t)(wave_id % qwaves) * 64;
+      const int64_t t0 = (int64_t)(wave_id / qwaves) * chunk;
+      const int64_t j0 = t0 + (int64_t)tile * 16;
+      // only slots the refine pass wrote: live query wave, tile inside its chunk
+      if (q0 < n0 && j0 < min((long long)(t0 + chunk), (long long)n1)) flagged = dense_flag[f] != 0;
     }
-    const float d = (s0 + s1) + (s2 + s3);
-    atomicMin(&best[i], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j);
+    unsigned long long m = __ballot(flagged);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const unsigned fb = (unsigned)src * ngroups + g;              // wave-uniform
+      const unsigned wave_id = fb / tpc, tile = fb % tpc;
+      const unsigned dq = __builtin_amdgcn_readfirstlane((wave_id % qwaves) * 64u);
+      const unsigned t0 = __builtin_amdgcn_readfirstlane((wave_id / qwaves) * (unsigned)chunk);
+      const unsigned ju = __builtin_amdgcn_readfirstlane(t0 + tile * 16u);   // uniform: rows via scalar loads
+      const int64_t q = (int64_t)dq + lane;
+      const int64_t j0 = (int64_t)ju;
+      const int64_t j1 = min(min((long long)(j0 + 16), (long long)((int64_t)t0 + chunk)), (long long)n1);
+      const float* x = f0 + (q < n0 ? q : n0 - 1) * C;
+      f32x4 xv[C / 4];
+#pragma unroll
+      for (int g = 0; g < C / 4; ++g) xv[g] = *reinterpret_cast<const f32x4*>(x + g * 4);
+      float bd = __builtin_inff();
+      int bj = 0x7fffffff;
+#pragma unroll 2
+      for (int jj = 0; jj < 16; ++jj) {
+        const int64_t j = (j0 + jj < j1) ? j0 + jj : j1 - 1;      // clamped re-reads of the last row never win (strict <)
+        const float* __restrict__ y = f1 + j * C;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int g = 0; g < C / 4; ++g) {
+          const float d0 = xv[g][0] - y[4 * g], d1 = xv[g][1] - y[4 * g + 1];
+          const float d2 = xv[g][2] - y[4 * g + 2], d3 = xv[g][3] - y[4 * g + 3];
+          s0 = fmaf(d0, d0, s0);
+          s1 = fmaf(d1, d1, s1);
+          s2 = fmaf(d2, d2, s2);
+          s3 = fmaf(d3, d3, s3);
+        }
+        const float dd = (s0 + s1) + (s2 + s3);
+        if (dd < bd) {
+          bd = dd;
+          bj = (int)j;
+        }
+      }
+      if (q < n0 && bj != 0x7fffffff) {
+        const unsigned long long mine = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
+        if (mine < __builtin_nontemporal_load(&best[q])) atomicMin(&best[q], mine);
+      }
+    }
   }
 }
 
-// Only if the candidate list overflowed (near-identical features everywhere): exact brute force, predicated on the
-// device-side count so that the launch is a no-op otherwise.  One query per thread, wave-uniform target rows.
+// One thread per candidate pair: the exact direct form in the oracle's order, 64-bit atomicMin like the brute-force
+// kernel.  Block b walks the regions of the 4 waves of refine workgroup b.
 template <int C>
-__global__ __launch_bounds__(256) void k_nn_fallback(const unsigned* __restrict__ cand_count, unsigned cand_cap,
-                                                     const float* __restrict__ f0, int64_t n0,
-                                                     const float* __restrict__ f1, int64_t n1, int chunk,
-                                                     unsigned long long* __restrict__ best) {
-  if (*cand_count <= cand_cap) return;
-  const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t t0 = (int64_t)blockIdx.y * chunk;
-  const int64_t t1 = min((long long)(t0 + chunk), (long long)n1);
-  const float* x = f0 + (qi < n0 ? qi : n0 - 1) * C;
-  float bd = __builtin_inff();
-  int bj = 0x7fffffff;
-  for (int64_t j = t0; j < t1; ++j) {
-    const float* __restrict__ y = f1 + j * C;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 4
-    for (int g = 0; g < C / 4; ++g) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + g * 4);
-      const float d0 = xv[0] - y[4 * g], d1 = xv[1] - y[4 * g + 1], d2 = xv[2] - y[4 * g + 2], d3 = xv[3] - y[4 * g + 3];
-      s0 = fmaf(d0, d0, s0);
-      s1 = fmaf(d1, d1, s1);
-      s2 = fmaf(d2, d2, s2);
-      s3 = fmaf(d3, d3, s3);
-    }
-    const float d = (s0 + s1) + (s2 + s3);
-    if (d < bd) {
-      bd = d;
-      bj = (int)j;
+__global__ __launch_bounds__(256) void k_nn_exact(const unsigned long long* __restrict__ cand,
+                                                  const unsigned* __restrict__ cand_count, unsigned nwg,
+                                                  const unsigned long long* __restrict__ shared_list,
+                                                  const unsigned* __restrict__ overflow, unsigned shared_cap,
+                                                  const float* __restrict__ f0, const float* __restrict__ f1,
+                                                  unsigned long long* __restrict__ best) {
+  // blocks [0, nwg): the 4 wave regions of refine workgroup b, 64 threads each; blocks [nwg, gridDim.x): the shared
+  // overflow list
+  const bool shared = blockIdx.x >= nwg;
+  {
+    const unsigned wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned n = shared ? min(overflow[1], shared_cap) : min(cand_count[wave_id], (unsigned)kCandWave);
+    const unsigned long long* src = shared ? shared_list : cand + (size_t)wave_id * kCandWave;
+    const unsigned first = shared ? (blockIdx.x - nwg) * 256u + threadIdx.x : (threadIdx.x & 63u);
+    const unsigned step = shared ? (gridDim.x - nwg) * 256u : 64u;
+    for (unsigned t = first; t < n; t += step) {
+      const unsigned long long ij = src[t];
+      const int64_t i = (int64_t)(ij >> 32), j = (int64_t)(ij & 0xffffffffull);
+      const float* x = f0 + i * C;
+      const float* y = f1 + j * C;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int g = 0; g < C / 4; ++g) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + g * 4);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + g * 4);
+        const float d0 = xv[0] - yv[0], d1 = xv[1] - yv[1], d2 = xv[2] - yv[2], d3 = xv[3] - yv[3];
+        s0 = fmaf(d0, d0, s0);
+        s1 = fmaf(d1, d1, s1);
+        s2 = fmaf(d2, d2, s2);
+        s3 = fmaf(d3, d3, s3);
+      }
+      const float d = (s0 + s1) + (s2 + s3);
+      // best[i] only ever decreases: a (possibly stale) read that is already <= this pair proves it cannot win and
+      // saves the atomic — clusters put thousands of candidates on the same few hundred queries
+      const unsigned long long mine = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+      if (mine < __builtin_nontemporal_load(&best[i])) atomicMin(&best[i], mine);
     }
   }
-  if (qi < n0 && bj != 0x7fffffff)
-    atomicMin(&best[qi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj);
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int64_t cand_capacity(int64_t n0) {   // 128 candidates per query
-  int64_t c = 128 * n0;
+int64_t shared_capacity(int64_t n0) {   // shared overflow list: 64 candidates per query
+  int64_t c = 64 * n0;
   if (c < 65536) c = 65536;
-  return c < (1ll << 32) - 1 ? c : (1ll << 32) - 1;
+  return c < (1ll << 31) ? c : (1ll << 31) - 1;
+}
+
+// refine grid: query blocks of 256 x target chunks (multiples of 64 rows) so that ~768 workgroups exist
+void nn_grid(int64_t n0, int64_t n1, int64_t* qblocks, int64_t* chunk, int64_t* nchunk) {
+  *qblocks = cdiv64(n0, 256);
+  const int64_t want = cdiv64(768, *qblocks);
+  int64_t c = cdiv64(cdiv64(n1, want), 64) * 64;
+  if (c < 256) c = 256;
+  if (c >= (1 << 24)) c = (1 << 24) - 64;
+  *chunk = c;
+  *nchunk = cdiv64(n1, c);
 }
 
 template <int C>
 int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best, char* p,
              hipStream_t st) {
+  int64_t qblocks, chunk, nchunk;
+  nn_grid(n0, n1, &qblocks, &chunk, &nchunk);
+  const int64_t nwaves = qblocks * nchunk * 4;
   unsigned short* qb = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);
   unsigned short* ql = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);
   unsigned short* tb = (unsigned short*)p;  p += al256((size_t)n1 * C * 2);
@@ -382,30 +479,35 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
   f32x4* qmeta = (f32x4*)p;                 p += al256((size_t)n0 * 16);
   f32x4* tmeta = (f32x4*)p;                 p += al256((size_t)n1 * 16);
   unsigned* U = (unsigned*)p;               p += al256((size_t)n0 * 4);
-  unsigned* cand_count = (unsigned*)p;      p += 256;
-  unsigned long long* cand = (unsigned long long*)p;
-  const unsigned cap = (unsigned)cand_capacity(n0);
+  unsigned* overflow = (unsigned*)p;        p += 256;
+  unsigned* cand_count = (unsigned*)p;      p += al256((size_t)nwaves * 4);
+  unsigned long long* cand = (unsigned long long*)p;   p += al256((size_t)nwaves * kCandWave * 8);
+  unsigned long long* shared_list = (unsigned long long*)p;   p += al256((size_t)shared_capacity(n0) * 8);
+  unsigned char* dense_flag = (unsigned char*)p;              // one byte per (64 queries x 16 targets) wave-tile
+  const unsigned shared_cap = (unsigned)shared_capacity(n0);
   constexpr int LPR = C / 4;
   hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n0 * LPR, 256)), dim3(256), 0, st, f0, n0, kEpsRel, -2.0f, qb,
-                     ql, qmeta, U, best, cand_count);
+                     ql, qmeta, U, best, overflow);
   hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n1 * LPR, 256)), dim3(256), 0, st, f1, n1, 1.0f, 1.0f, tb, tl,
                      tmeta, (unsigned*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr);
-  const int64_t qblocks = cdiv64(n0, 256);
-  int64_t want = cdiv64(768, qblocks);
-  int64_t chunk = cdiv64(cdiv64(n1, want), 64) * 64;
-  if (chunk < 256) chunk = 256;
-  if (chunk >= (1 << 24)) chunk = (1 << 24) - 64;
-  const dim3 grid((unsigned)qblocks, (unsigned)cdiv64(n1, chunk));
+  static const int s_dense_min = env_int("APR_NN_DENSE_MIN", kDenseMin);
+  const dim3 grid((unsigned)qblocks, (unsigned)nchunk);
   hipLaunchKernelGGL((k_nn_mfma<C, false>), grid, dim3(256), 0, st, qb, ql, qmeta, n0, tb, tl, tmeta, n1, (int)chunk, U,
-                     cand, cand_count, cap);
+                     cand, cand_count, overflow, shared_list, shared_cap, dense_flag, 0);
   hipLaunchKernelGGL((k_nn_mfma<C, true>), grid, dim3(256), 0, st, qb, ql, qmeta, n0, tb, tl, tmeta, n1, (int)chunk, U,
-                     cand, cand_count, cap);
-  hipLaunchKernelGGL((k_nn_exact<C>), dim3(1024), dim3(256), 0, st, cand, cand_count, cap, f0, f1, best);
-  // no-op unless the list overflowed
-  int64_t fchunk = cdiv64(n1, cdiv64(2048, qblocks));
-  if (fchunk < 64) fchunk = 64;
-  hipLaunchKernelGGL((k_nn_fallback<C>), dim3((unsigned)qblocks, (unsigned)cdiv64(n1, fchunk)), dim3(256), 0, st,
-                     cand_count, cap, f0, n0, f1, n1, (int)fchunk, best);
+                     cand, cand_count, overflow, shared_list, shared_cap, dense_flag, s_dense_min);
+  const unsigned nwg = (unsigned)(qblocks * nchunk);
+  hipLaunchKernelGGL((k_nn_exact<C>), dim3(nwg + 256), dim3(256), 0, st, cand, cand_count, nwg, shared_list, overflow,
+                     shared_cap, f0, f1, best);
+  if ((uint64_t)qblocks * 4 * (uint64_t)nchunk * (uint64_t)(chunk / 16) + 64 >= (1ull << 32)) {
+    apr_set_error("apr_feature_nn_fast: problem too large for the dense-block flags");
+    return APR_EINVAL;
+  }
+  hipLaunchKernelGGL((k_nn_dense<C>), dim3(1024), dim3(256), 0, st, dense_flag, (int)chunk, (unsigned)(qblocks * 4),
+                     (unsigned)nchunk, f0, n0, f1, n1, best);
+  // exact for ANY input: if the lists overflowed, the brute-force kernel (a no-op launch otherwise) redoes the search
+  int rc = apr_internal_nn_brute(f0, n0, f1, n1, C, (uint64_t*)best, overflow, st);
+  if (rc != APR_OK) return rc;
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -414,8 +516,12 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
 
 APR_API size_t apr_feature_nn_fast_scratch_bytes(int64_t n0, int64_t n1, int32_t c) {
   if (n0 < 0 || n1 < 0 || c <= 0) return 0;
+  int64_t qblocks, chunk, nchunk;
+  nn_grid(n0 > 0 ? n0 : 1, n1 > 0 ? n1 : 1, &qblocks, &chunk, &nchunk);
+  const size_t nwaves = (size_t)(qblocks * nchunk * 4);
   return 2 * al256((size_t)n0 * c * 2) + 2 * al256((size_t)n1 * c * 2) + al256((size_t)n0 * 16) + al256((size_t)n1 * 16) +
-         al256((size_t)n0 * 4) + 256 + al256((size_t)cand_capacity(n0) * 8) + 256;
+         al256((size_t)n0 * 4) + 256 + al256(nwaves * 4) + al256(nwaves * kCandWave * 8) +
+         al256((size_t)shared_capacity(n0) * 8) + al256((size_t)(qblocks * 4) * (size_t)nchunk * (size_t)(chunk / 16) + 64) + 512;
 }
 
 APR_API int apr_feature_nn_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,

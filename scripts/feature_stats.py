@@ -25,7 +25,7 @@ for w in (0.0, 1e-7, 3e-6, 2e-5, 2e-4, 2e-3, 1.6e-2):
 uq = torch.unique(F1, dim=0).shape[0]
 print("distinct target rows:", uq, "of", n1)
 
-# candidate count of the filter + refine path (cand_count sits after the U array in the scratch blob)
+# candidate count of the filter + refine path (overflow flag, then per-wave counts, sit after the U array)
 from apr_amd import _lib
 from apr_amd._lib import ptr, stream, check
 lib = _lib.load()
@@ -37,9 +37,29 @@ scratch = torch.zeros(sb + 256, dtype=torch.uint8, device=dev)
 best = torch.empty(n0, dtype=torch.int64, device=dev)
 check(lib.apr_feature_nn_fast(ptr(f0), n0, ptr(f1), n1, c, ptr(best), ptr(scratch), sb, stream()))
 torch.cuda.synchronize()
+qblocks = (n0 + 255) // 256
+want = (768 + qblocks - 1) // qblocks
+chunk = max(256, ((((n1 + want - 1) // want) + 63) // 64) * 64)
+nwaves = qblocks * ((n1 + chunk - 1) // chunk) * 4
 base = (-scratch.data_ptr()) % 256
 off = base + 2 * al(n0 * c * 2) + 2 * al(n1 * c * 2) + al(n0 * 16) + al(n1 * 16) + al(n0 * 4)
-cnt = scratch[off:off + 8].view(torch.int32).cpu().numpy()
+ovf = int(scratch[off:off + 4].view(torch.int32).cpu()[0])
+cnt = scratch[off + 256:off + 256 + 4 * nwaves].view(torch.int32).cpu().numpy()
+shared = int(scratch[off + 4:off + 8].view(torch.int32).cpu()[0])
+print("fast path: candidates", int(cnt.sum()) + shared, "=", (cnt.sum() + shared) / n0, "per query; per-wave regions", int(cnt.sum()), "(max", int(cnt.max()), "of 2048), shared list", shared, "; fallback flag", ovf)
+
 import numpy as np
-print("fast path: candidates", int(cnt[0]), "=", cnt[0] / n0, "per query; max|b| =", float(np.array([cnt[1]], np.int32).view(np.float32)[0]),
-      "; capacity", 128 * n0)
+shared_cap = max(65536, 64 * n0)
+nchunk = (n1 + chunk - 1) // chunk
+foff = off + 256 + al(nwaves * 4) + al(nwaves * 2048 * 8) + al(shared_cap * 8)
+nflag = nwaves * (chunk // 16)
+flags = scratch[foff:foff + nflag].cpu().numpy().reshape(nwaves, chunk // 16)
+# only slots the refine pass wrote (live query waves, tiles inside the chunk)
+qw = qblocks * 4
+valid = np.zeros_like(flags, dtype=bool)
+for w in range(nwaves):
+    q0 = (w % qw) * 64; t0 = (w // qw) * chunk
+    if q0 < n0:
+        nt = (min(t0 + chunk, n1) - t0 + 15) // 16
+        valid[w, :max(nt, 0)] = True
+print("dense tiles:", int((flags[valid] != 0).sum()), "of", int(valid.sum()), "; flag values seen:", np.unique(flags[valid])[:8])
