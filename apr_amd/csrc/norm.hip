@@ -17,10 +17,21 @@ __global__ void k_bn_partial(const float* __restrict__ x, int64_t ld, int64_t n,
   const int64_t r1 = min((long long)(r0 + kRowsPerBlock), (long long)n);
   double s = 0.0, s2 = 0.0;
   if (col < c) {
-    for (int64_t r = r0 + ty; r < r1; r += 4) {
-      double v = (double)x[r * ld + col];
-      s += v;
-      s2 += v * v;
+    // 8 independent loads in flight per thread, then the fp64 accumulation in row order (a plain loop serialises
+    // one L2 round trip per row: 18 us per call on 28 k rows)
+    for (int64_t rb = r0 + ty; rb < r1; rb += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = rb + 4 * u;
+        v[u] = r < r1 ? x[r * ld + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double d = (double)v[u];
+        s += d;
+        s2 += d * d;
+      }
     }
   }
   s_sum[ty][tx] = s;
@@ -40,9 +51,19 @@ __global__ void k_bn_finish(const double* __restrict__ partial, int nblk, int64_
   int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= c) return;
   double s = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += partial[((int64_t)b * 2 + 0) * c + col];
-    s2 += partial[((int64_t)b * 2 + 1) * c + col];
+  for (int b0 = 0; b0 < nblk; b0 += 8) {
+    double a[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = b0 + u < nblk;
+      a[u] = ok ? partial[((int64_t)(b0 + u) * 2 + 0) * c + col] : 0.0;
+      q[u] = ok ? partial[((int64_t)(b0 + u) * 2 + 1) * c + col] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s += a[u];
+      s2 += q[u];
+    }
   }
   double m = s / (double)n;
   double v = s2 / (double)n - m * m;
