@@ -27,9 +27,12 @@ from .common import get_norm
 from .residual_block import get_block
 
 
-# stages of the fused plan that take the weight-stationary conv path (few pairs per tile, large Cin*Cout);
-# measured per layer on MI355X (scripts/layer_bench.py), override with APR_WS_STAGES="conv3,block4,..." / "none"
-WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", "block3_tr", "conv2_tr", "block2_tr")
+# stages of the fused plan that take the weight-stationary conv path (few pairs per tile, large Cin*Cout); chosen from
+# per-layer timings (scripts/layer_bench.py) AND whole-pipeline throughput with two steps in flight: at the finest
+# level (conv2_tr, block2_tr, 64 channels x >100 k rows per call) the path is faster in isolation but streams its
+# product rows through HBM and costs the concurrently running kernels more than it saves (-4 % pairs/s), so those
+# two stay on the tile kernel.  Override with APR_WS_STAGES="conv3,block4,..." / "none".
+WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", "block3_tr")
 
 
 def _ws_stages():
