@@ -34,20 +34,20 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=18)
     ap.add_argument("--model", default="ResUNetBN2C")
     ap.add_argument("--n-out", type=int, default=32)
     ap.add_argument("--ransac-iters", type=int, default=4000000)
-    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs cycled through")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--pool", type=int, default=12, help="distinct synthetic pairs cycled through")
+    ap.add_argument("--streams", type=int, default=3,
                     help="pairs in flight per GPU: each on its own HIP stream + host thread (a 28 k-voxel pair "
                          "cannot fill 256 CUs alone, so independent pairs overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pairs-per-step", type=int, default=1,
                     help="independent pairs batched into one encoder call per step (value counts pairs, not steps)")
-    ap.set_defaults(pairs_per_step=4)
+    ap.set_defaults(pairs_per_step=6)
     return ap.parse_args()
 
 
