@@ -27,6 +27,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (needs oracle/_ref)")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=0,
+                    help="> 0: also measure throughput with this many pairs in flight (one host thread + HIP stream each)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     np.random.seed(0); torch.manual_seed(0)
@@ -63,6 +65,39 @@ def main():
            "neighbor_limits": LIMITS, "ms": {"grid_subsample_0.3": r[0], "collate(12 radius + 3 subsample)": r[1],
                                              "KPFCNN forward": r[2], "sampling + RANSAC(50000,1000)": r[3]},
            "pairs_per_s": 1e3 / r.sum()}
+    if args.streams > 0:
+        import threading
+
+        @torch.no_grad()
+        def one(rep):
+            pts, lens = point_ops.grid_subsample(torch.cat([ta, tb]), np.array([len(a), len(b)], np.int32), 0.3)
+            src, tgt = pts[:lens[0]], pts[lens[0]:]
+            ones = lambda p: torch.ones((len(p), 1), device=dev)
+            bt = collate_fn_descriptor([(src, tgt, ones(src), ones(tgt))], cfg, LIMITS)
+            feats, ov, sal = model(bt)
+            n0 = int(lens[0])
+            rng = np.random.RandomState(rep)     # per-call RNG: np.random.seed is process-global
+            s_p, s_f, _ = BU.sample_by_score(src, feats[:n0], ov[:n0] * sal[:n0], 5000, rng=rng)
+            t_p, t_f, _ = BU.sample_by_score(tgt, feats[n0:], ov[n0:] * sal[n0:], 5000, rng=rng)
+            return BU.ransac_pose_estimation(s_p, t_p, s_f, t_f, distance_threshold=0.3, ransac_n=4, seed=rep)
+
+        total = 12 * args.streams
+        streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+
+        def worker(w):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[w]):
+                for i in range(w, total, args.streams):
+                    one(i)
+                streams[w].synchronize()
+
+        for _ in range(2):       # second round is timed
+            t0 = sync()
+            ts = [threading.Thread(target=worker, args=(w,)) for w in range(args.streams)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            t1 = sync()
+        out["pairs_per_s_in_flight"] = {"streams": args.streams, "pairs_per_s": total / (t1 - t0)}
     if args.cpu:
         from oracle import kpfcnn_oracle as KO
         from oracle import match_pose_oracle as MO
