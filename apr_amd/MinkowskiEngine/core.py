@@ -43,31 +43,39 @@ class CoordinateManager:
     the dense neighbour table the sparse-conv kernel consumes.
     """
 
-    def __init__(self, coordinates: torch.Tensor):
-        self.maps = {1: ops.build_map(coordinates)}
+    def __init__(self, coordinates: torch.Tensor = None, base_map=None):
+        """`coordinates`: unique int32 [n,4] rows.  `base_map`: adopt an `ops.CoordMap` that already de-duplicated
+        raw voxel coordinates (its rows ARE the stride-1 map: no second hash build; may still be unfinalised)."""
+        if (coordinates is None) == (base_map is None):
+            raise AprHipError("CoordinateManager: give either coordinates or base_map")
+        self._adopted = base_map is not None
+        self.maps = {1: base_map if self._adopted else ops.build_map(coordinates)}
         self._kmaps = {}
         self._plists = {}
         self._plist_counters = None
-        self.device = coordinates.device
+        self.device = self.maps[1].keys.device
 
     # -- coordinate maps -----------------------------------------------------
-    def _finalize(self):
+    def _finalize(self, extras=()):
         pend = [m for m in self.maps.values() if m.n is None]
-        if pend:
-            ops.finalize_maps(pend)
+        fetched = []
+        if pend or extras:
+            fetched = ops.finalize_maps(pend, extras)
             m1 = self.maps[1]
-            if m1.n != m1.n_in:
+            if not self._adopted and m1.n != m1.n_in:
                 raise AprHipError(
                     f"SparseTensor: {m1.n_in - m1.n} duplicate coordinates; quantize first "
                     "(ME.utils.sparse_quantize)")
+        return fetched
 
-    def build_pyramid(self, strides):
-        """Enqueue all missing strided maps back to back and sync ONCE."""
+    def build_pyramid(self, strides, extras=()):
+        """Enqueue all missing strided maps back to back and sync ONCE (`extras`: small device int tensors fetched
+        in the same sync, returned as numpy arrays)."""
         for ts in sorted(strides):
             if ts not in self.maps:
                 src = self.maps[ts // 2]
                 self.maps[ts] = ops.build_map(src.coords, floor_to=ts, n_in_dev=src.n_dev if src.n is None else None)
-        self._finalize()
+        return self._finalize(extras)
 
     def get_map(self, ts):
         if ts not in self.maps:

@@ -168,6 +168,24 @@ __global__ void k_table_init(unsigned long long* __restrict__ keys, int* __restr
   }
 }
 
+// counts[b] = number of map rows whose first input row lies in [offsets[b], offsets[b+1]): `first` is ascending
+// (first-occurrence order), so two binary searches per segment over its valid prefix [0, *n_dev)
+__global__ void k_segment_counts(const long long* __restrict__ first, const int* __restrict__ n_dev,
+                                 const long long* __restrict__ offsets, int nseg, int* __restrict__ counts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nseg) return;
+  const int n = *n_dev;
+  auto lower = [&](long long v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (first[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  counts[b] = lower(offsets[b + 1]) - lower(offsets[b]);
+}
+
 // One thread per (out row, offset) probe; consecutive lanes -> consecutive offsets of
 // one row, so the nbr store is fully coalesced and the 16-B coordinate load is a
 // broadcast within the wave.
@@ -251,6 +269,16 @@ APR_API int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk_cnt, nblk, blk_off, n_out);
   hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(kBlock), 0, st, (const int4*)coords_in, n, n_dev, floor_to,
                      flags, blk_off, slot_of, vals, (int4*)out_coords, (long long*)out_first);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_segment_counts(const int64_t* first, const int32_t* n_dev, const int64_t* offsets, int32_t nseg,
+                               int32_t* counts, void* stream) {
+  APR_CHECK_ARG(nseg >= 0 && first && n_dev && offsets && counts, "apr_segment_counts: bad arguments");
+  if (nseg == 0) return APR_OK;
+  hipLaunchKernelGGL(k_segment_counts, dim3((unsigned)cdiv64(nseg, 64)), dim3(64), 0, (hipStream_t)stream,
+                     (const long long*)first, n_dev, (const long long*)offsets, nseg, counts);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

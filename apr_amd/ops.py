@@ -38,11 +38,16 @@ def _rows(t, name):
 # voxel hashing / coordinate maps
 # ----------------------------------------------------------------------------
 
-def voxelize(xyz: torch.Tensor, voxel_size: float, batch: int = 0) -> torch.Tensor:
-    """xyz f32[n,3] -> int32 [n,4] (batch, floor(xyz / voxel_size))."""
+def voxelize(xyz: torch.Tensor, voxel_size: float, batch: int = 0, out=None) -> torch.Tensor:
+    """xyz f32[n,3] -> int32 [n,4] (batch, floor(xyz / voxel_size)); `out`: a contiguous [n,4] int32 row slice."""
     xyz = _f32(xyz, "voxelize.xyz").contiguous()
     n = xyz.shape[0]
-    coords = torch.empty((n, 4), dtype=torch.int32, device=xyz.device)
+    if out is None:
+        coords = torch.empty((n, 4), dtype=torch.int32, device=xyz.device)
+    else:
+        if out.dtype != torch.int32 or tuple(out.shape) != (n, 4) or not out.is_contiguous() or out.device != xyz.device:
+            raise _lib.AprHipError("voxelize: `out` must be a contiguous int32 [n,4] tensor on the same device")
+        coords = out
     check(_lib_().apr_voxelize(ptr(xyz), n, float(voxel_size), int(batch), ptr(coords), stream()))
     return coords
 
@@ -81,12 +86,37 @@ def build_map(coords_in: torch.Tensor, floor_to: int = 0, n_in_dev=None, want_fi
     return m
 
 
-def finalize_maps(maps):
-    """One host sync for any number of pending maps: fetch row counts + status flags."""
+def segment_counts(m: CoordMap, offsets: torch.Tensor) -> torch.Tensor:
+    """Rows of map `m` (built with want_first over concatenated point sets) per segment [offsets[b], offsets[b+1]).
+    -> int32 [len(offsets) - 1] on the device (no sync; `m` may still be unfinalised)."""
+    if m.first is None:
+        raise _lib.AprHipError("segment_counts: build the map with want_first=True")
+    if offsets.dtype != torch.int64 or not offsets.is_cuda or offsets.dim() != 1:
+        raise _lib.AprHipError("segment_counts: offsets must be an int64 GPU vector")
+    offsets = offsets.contiguous()
+    nseg = offsets.shape[0] - 1
+    counts = torch.empty(max(nseg, 0), dtype=torch.int32, device=offsets.device)
+    check(_lib_().apr_segment_counts(ptr(m.first), ptr(m.n_dev), ptr(offsets), nseg, ptr(counts), stream()))
+    return counts
+
+
+def finalize_maps(maps, extras=()):
+    """One host sync for any number of pending maps: fetch row counts + status flags (+ any small int32 device
+    tensors in `extras`, returned as numpy arrays)."""
     pend = [m for m in maps if m.n is None]
-    if not pend:
-        return
-    host = torch.cat([torch.cat([m.n_dev, m.status]) for m in pend]).cpu().numpy()
+    if not pend and not extras:
+        return []
+    parts = [torch.cat([m.n_dev, m.status]) for m in pend] + [e.reshape(-1).to(torch.int32) for e in extras]
+    host = torch.cat(parts).cpu().numpy()
+    out, pos = [], 2 * len(pend)
+    for e in extras:
+        out.append(host[pos:pos + e.numel()].copy())
+        pos += e.numel()
+    _apply_finalize(pend, host)
+    return out
+
+
+def _apply_finalize(pend, host):
     for i, m in enumerate(pend):
         if host[2 * i + 1] != 0:
             raise _lib.AprHipError(

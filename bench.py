@@ -245,8 +245,8 @@ def main():
         nprof = max(1, min(args.steps, 5))
         for i in range(nprof):       # the same encoder call as the timed steps: B pairs = 2B frames per call
             batch = [pairs[(i * B + j) % len(pairs)] for j in range(B)]
-            _, coords = pipe.voxelize_batch([c for p in batch for c in p])
-            pipe.encode_batch(coords)
+            cm = pipe.voxelize_batch([c for p in batch for c in p])[0]
+            pipe.encode_batch(cm)
         ops.PROFILE = None
         s = prof.summary()
         log(f"roofline pass: {s}")

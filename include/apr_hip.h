@@ -80,6 +80,12 @@ int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_dev, int
                   int32_t* out_coords, int64_t* out_first, int32_t* n_out,
                   int32_t* status, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Rows per input segment of a map built over CONCATENATED point sets (a batch of frames voxelised in one build):
+ * counts[b] = #{rows r < *n_dev : offsets[b] <= out_first[r] < offsets[b+1]}; out_first is ascending, the count
+ * stays on the device so that it can be fetched together with the map sizes in the caller's single sync. */
+int apr_segment_counts(const int64_t* out_first, const int32_t* n_dev, const int64_t* offsets, int32_t nseg,
+                       int32_t* counts, void* stream);
+
 /* Kernel map (neighbour table) of one sparse convolution:
  *   nbr[j, o] = row i of the input map with c_in[i] == c_out[j] + offset(o) * scale,
  *   or -1.  offset(o) enumerates {-h..h}^3 x fastest.  scale = +ts_in for a
