@@ -21,6 +21,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libapr_hip.so")
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _f64, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
+class PairDesc(C.Structure):
+    """apr_pair_desc (include/apr_hip.h)."""
+    _fields_ = [("f0", C.c_void_p), ("n0", C.c_int64), ("f1", C.c_void_p), ("n1", C.c_int64),
+                ("xyz0", C.c_void_p), ("xyz1", C.c_void_p), ("seed", C.c_uint64)]
+
+
 class SpconvDesc(C.Structure):
     """struct apr_spconv_desc (include/apr_hip.h)."""
     _fields_ = [("inp", C.c_void_p), ("ldi", C.c_int64), ("nbr", C.c_void_p), ("n_out", C.c_int64),
@@ -66,6 +72,8 @@ PROTOTYPES = {
     "apr_ransac_geometric_scratch_bytes": (_sz, [_i64, _i64, _i64]),
     "apr_ransac_pose_geometric": (C.c_int, [_p, _i64, _p, _i64, _p, _f64, _f64, _i64, _i64, _u64, _p, _sz, _p, _p]),
     "apr_irls_pose": (C.c_int, [_p, _p, _p, _i64, _p, _p, _sz, _p]),
+    "apr_match_pose_batch_scratch_bytes": (_sz, [_i32, _i64, _i64, _i32, _i64]),
+    "apr_match_pose_batch": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p]),
     "apr_irls_scratch_bytes": (_sz, [_i64]),
     "apr_contrastive_reduce": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _f32, _f32, _p, _p]),
     "apr_grid_subsample_scratch_bytes": (_sz, [_i64]),

@@ -95,13 +95,13 @@ class PairRegistration:
             offs.append(offs[-1] + n)
         # rows of frame b are rows offs[b]:offs[b+1]; their representative points sit at first[...] - point offset
         pts = [xyz[first[offs[b]:offs[b + 1]] - poffs[b]].contiguous() for b, xyz in enumerate(clouds)]
-        # all NN searches are enqueued before the first RANSAC call synchronises
-        corr = [ops.feature_nn(F[offs[2 * i]:offs[2 * i + 1]], F[offs[2 * i + 1]:offs[2 * i + 2]])
-                for i in range(len(pairs))]
+        # matching + pose of all B pairs: one library call, one host synchronisation
+        res = ops.match_pose_batch([F[offs[2 * i]:offs[2 * i + 1]] for i in range(len(pairs))],
+                                   [F[offs[2 * i + 1]:offs[2 * i + 2]] for i in range(len(pairs))],
+                                   pts[0::2], pts[1::2], self.distance_threshold, self.edge_length, self.ransac_iters,
+                                   seeds=list(seeds))
         out = []
-        for i, seed in enumerate(seeds):
-            T, info = ops.ransac_pose(pts[2 * i], pts[2 * i + 1], corr[i], self.distance_threshold, self.edge_length,
-                                      self.ransac_iters, seed)
+        for i, (T, info) in enumerate(res):
             info.update(n0=counts[2 * i], n1=counts[2 * i + 1])
             out.append((T, info))
         return out

@@ -507,6 +507,48 @@ def ransac_pose(xyz0, xyz1, corr, max_dist, edge_ratio=0.9, max_iter=4000000, se
     return T, info
 
 
+def match_pose_batch(feats0, feats1, pts0, pts1, max_dist, edge_ratio=0.9, max_iter=4000000, seeds=None):
+    """B pairs: feature NN + RANSAC/Kabsch each, ONE library call and ONE host synchronisation.
+
+    feats0[i] [n0_i, C] / feats1[i] [n1_i, C] (row slices of the encoder output are fine), pts0[i] / pts1[i] f32 [n, 3].
+    -> list of (T float64 [4,4] numpy, info dict), identical to feature_nn + ransac_pose per pair."""
+    B = len(feats0)
+    if not (B == len(feats1) == len(pts0) == len(pts1)) or B == 0:
+        raise _lib.AprHipError("match_pose_batch: need the same (non-zero) number of entries in every list")
+    if seeds is None:
+        seeds = range(B)
+    lib = _lib_()
+    descs = (_lib.PairDesc * B)()
+    keep = []
+    c = feats0[0].shape[1]
+    n0m = n1m = 0
+    for i in range(B):
+        f0 = _f32(feats0[i], "match_pose_batch.feats0").contiguous()
+        f1 = _f32(feats1[i], "match_pose_batch.feats1").contiguous()
+        p0 = _f32(pts0[i], "match_pose_batch.pts0").contiguous()
+        p1 = _f32(pts1[i], "match_pose_batch.pts1").contiguous()
+        if f0.shape[1] != c or f1.shape[1] != c or p0.shape != (f0.shape[0], 3) or p1.shape != (f1.shape[0], 3):
+            raise _lib.AprHipError("match_pose_batch: inconsistent shapes in pair %d" % i)
+        keep += [f0, f1, p0, p1]
+        d = descs[i]
+        d.f0, d.n0, d.f1, d.n1 = f0.data_ptr(), f0.shape[0], f1.data_ptr(), f1.shape[0]
+        d.xyz0, d.xyz1, d.seed = p0.data_ptr(), p1.data_ptr(), int(seeds[i]) & 0xFFFFFFFFFFFFFFFF
+        n0m, n1m = max(n0m, f0.shape[0]), max(n1m, f1.shape[0])
+    sb = int(lib.apr_match_pose_batch_scratch_bytes(B, n0m, n1m, c, int(max_iter)))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=keep[0].device)
+    res = (C.c_double * (20 * B))()
+    check(lib.apr_match_pose_batch(descs, B, c, float(max_dist), float(edge_ratio), int(max_iter), ptr(scratch), sb, res,
+                                   stream()))
+    r = np.array(list(res), dtype=np.float64).reshape(B, 20)
+    out = []
+    for i in range(B):
+        n0 = descs[i].n0
+        out.append((r[i, :16].reshape(4, 4).copy(),
+                    dict(inliers=int(r[i, 16]), rmse=float(r[i, 17]), best_iteration=int(r[i, 18]),
+                         n_valid=int(r[i, 19]), fitness=float(r[i, 16]) / max(n0, 1))))
+    return out
+
+
 def ransac_pose_geometric(xyz0, xyz1, corr, max_dist, edge_ratio=0.9, max_iter=50000, max_validation=1000, seed=0):
     """open3d <= 0.11 flavour (Predator_APR): first `max_validation` survivors, geometric inlier count."""
     xyz0 = _f32(xyz0, "ransac.xyz0").contiguous()

@@ -247,6 +247,22 @@ int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float* xyz1, 
                               int64_t max_iter, int64_t max_validation, uint64_t seed,
                               void* scratch, size_t scratch_bytes, double* result_host, void* stream);
 
+/* B independent pairs, matching + pose, in ONE call and ONE host synchronisation: per pair apr_feature_nn_fast
+ * (apr_feature_nn for channel counts other than 32/64/128) -> apr_nn_unpack -> single-round RANSAC, enqueued back to
+ * back on `stream`; results_host f64[B][20] in the layout of apr_ransac_pose.  Identical results to the per-pair
+ * entry points (a pair whose hypothesis list overflows is redone through apr_ransac_pose).  This is the body of the
+ * reference's per-pair loop after the encoder (FCGF_APR/scripts/test_apr.py:139-156), batched. */
+typedef struct {
+  const float* f0; int64_t n0;     /* features of frame 0 (queries), row-major [n0, c], 16-byte aligned */
+  const float* f1; int64_t n1;     /* features of frame 1 (targets) [n1, c] */
+  const float* xyz0;               /* representative points of frame 0, f32 [n0, 3] */
+  const float* xyz1;               /* ... of frame 1, f32 [n1, 3] */
+  uint64_t seed;                   /* RANSAC hypothesis stream of this pair */
+} apr_pair_desc;
+size_t apr_match_pose_batch_scratch_bytes(int32_t B, int64_t n0_max, int64_t n1_max, int32_t c, int64_t max_iter);
+int apr_match_pose_batch(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist, double edge_ratio,
+                         int64_t max_iter, void* scratch, size_t scratch_bytes, double* results_host, void* stream);
+
 /* Robust linearised 6-DoF pose (20 IRLS iterations), replaces
  * est_quad_linear_robust (FCGF_APR/util/transform_estimation.py:89-116).
  * pts0/pts1 f32[n,3] paired, weight f32[n] nullable; T_host f32[16]; syncs. */

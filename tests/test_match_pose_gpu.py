@@ -256,3 +256,29 @@ def test_register_batch_equals_pair_by_pair(dev):
             assert i1["inliers"] == i2["inliers"] and np.allclose(T1, T2, atol=1e-9)
         else:                                                # an NN near-tie flipped: still a valid registration
             assert abs(i1["inliers"] - i2["inliers"]) <= max(5, 0.05 * i1["inliers"])
+
+
+def test_match_pose_batch_equals_per_pair_calls(dev):
+    """apr_match_pose_batch (one call, one sync) == feature_nn + ransac_pose pair by pair, bit for bit; one of the
+    pairs has perfect correspondences and more than 2^20 valid hypotheses, i.e. takes the overflow replay."""
+    cases = []
+    for s, (n, inl) in enumerate([(3000, 0.4), (2200, 0.25), (1500, 0.6)]):
+        xyz0, xyz1, F0, F1, _ = _synthetic_pair(20 + s, n=n, inlier=inl)
+        cases.append((xyz0, xyz1, F0, F1))
+    # perfect pair: identical features in the same order -> every hypothesis survives both checkers
+    rng = np.random.default_rng(77)
+    q = rng.uniform(-15, 15, (260, 3)).astype(np.float32)
+    R = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    t = (q.astype(np.float64) @ R.T + np.array([0.5, 1.5, -0.25])).astype(np.float32)
+    Fp = rng.standard_normal((260, 32)).astype(np.float32)
+    cases.append((q, t, Fp, Fp.copy()))
+    g = lambda a: torch.from_numpy(a).to(dev)
+    iters = 1200000
+    seeds = [3, 4, 5, 6]
+    batch = ops.match_pose_batch([g(c[2]) for c in cases], [g(c[3]) for c in cases], [g(c[0]) for c in cases],
+                                 [g(c[1]) for c in cases], 0.3, 0.9, iters, seeds=seeds)
+    for (xyz0, xyz1, F0, F1), (Tb, ib), seed in zip(cases, batch, seeds):
+        corr = ops.feature_nn(g(F0), g(F1))
+        T, info = ops.ransac_pose(g(xyz0), g(xyz1), corr, 0.3, 0.9, iters, seed)
+        assert info == ib and np.array_equal(T, Tb)
+    assert batch[3][1]["n_valid"] == iters and batch[3][1]["inliers"] == 260
