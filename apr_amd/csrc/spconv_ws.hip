@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
       if (my_p < p_end) {
         float* dst = prod + (int64_t)my_p * cout + col0 + q * 4;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(dst + cb * 16) = acc[cb];
+        for (int cb = 0; cb < 4; ++cb)   // written once, read once by k_ws_reduce: keep it out of the caches' way
+          __builtin_nontemporal_store(acc[cb], reinterpret_cast<f32x4*>(dst + cb * 16));
       }
       g = gn;
       my_p = np;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_ws_reduce(const float* __restrict__ pro
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     p[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (pid[k] >= 0) p[k] = *reinterpret_cast<const f32x4*>(prod + (int64_t)pid[k] * cout + col);
+    if (pid[k] >= 0) p[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(prod + (int64_t)pid[k] * cout + col));
   }
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
