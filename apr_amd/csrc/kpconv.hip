@@ -200,51 +200,108 @@ __global__ void k_group_max(const float* __restrict__ y, int64_t ldy, int n, int
 
 // Multi-head attention with channel layout c = d * heads + h (gcn.py:94-116):
 //   out[n, d*heads+h] = sum_m softmax_m( sum_d q[n,d,h] k[m,d,h] / sqrt(dim) ) v[m,d,h]
-// One workgroup per (n, h): scores in LDS (M <= 4096), two-pass softmax, fp32.
+// One workgroup per (kMhaQ = 8 queries, head): every key / value row fetched from global memory serves 8 queries
+// (one workgroup per query re-read all of K and V for each of them: 2 MB x 4000 workgroups per call).  Scores of
+// the 8 queries in LDS ([8][M], M <= ~1800), two-pass softmax per query in fixed order, fp32.
+constexpr int kMhaQ = 8;
+
 __global__ __launch_bounds__(256) void k_mha(const float* __restrict__ q, const float* __restrict__ kk,
                                              const float* __restrict__ v, int n, int m, int dim, int heads,
                                              float* __restrict__ out) {
-  extern __shared__ float s_sc[];  // [m] scores + [dim] query
-  float* s_q = s_sc + m;
+  extern __shared__ float s_sc[];            // [kMhaQ][m] scores, then [kMhaQ][dim] queries
+  float* s_q = s_sc + kMhaQ * (m > 256 ? m : 256);
   __shared__ float s_red[256];
-  const int ni = blockIdx.x / heads, h = blockIdx.x % heads;
+  __shared__ float s_inv[kMhaQ];
+  const int nqb = (n + kMhaQ - 1) / kMhaQ;
+  const int qb = blockIdx.x % nqb, h = blockIdx.x / nqb;
+  const int n0 = qb * kMhaQ;
   const int c = dim * heads;
-  for (int d = threadIdx.x; d < dim; d += 256) s_q[d] = q[(int64_t)ni * c + d * heads + h];
+  for (int e = threadIdx.x; e < kMhaQ * dim; e += 256) {
+    const int qi = e / dim, d = e - qi * dim;
+    const int row = min(n0 + qi, n - 1);
+    s_q[e] = q[(int64_t)row * c + d * heads + h];
+  }
   __syncthreads();
   const float scl = 1.f / sqrtf((float)dim);
-  float mx = -__builtin_inff();
+  float mx[kMhaQ];
+#pragma unroll
+  for (int qi = 0; qi < kMhaQ; ++qi) mx[qi] = -__builtin_inff();
   for (int j = threadIdx.x; j < m; j += 256) {
-    float s = 0.f;
-    for (int d = 0; d < dim; ++d) s = fmaf(s_q[d], kk[(int64_t)j * c + d * heads + h], s);
-    s *= scl;
-    s_sc[j] = s;
-    mx = fmaxf(mx, s);
+    float s[kMhaQ];
+#pragma unroll
+    for (int qi = 0; qi < kMhaQ; ++qi) s[qi] = 0.f;
+    const float* krow = kk + (int64_t)j * c + h;
+    for (int d = 0; d < dim; ++d) {
+      const float kv = krow[d * heads];
+#pragma unroll
+      for (int qi = 0; qi < kMhaQ; ++qi) s[qi] = fmaf(s_q[qi * dim + d], kv, s[qi]);
+    }
+#pragma unroll
+    for (int qi = 0; qi < kMhaQ; ++qi) {
+      s[qi] *= scl;
+      s_sc[qi * m + j] = s[qi];
+      mx[qi] = fmaxf(mx[qi], s[qi]);
+    }
   }
-  s_red[threadIdx.x] = mx;
-  __syncthreads();
-  for (int st = 128; st >= 1; st >>= 1) {
-    if (threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+  // per-query max, then exp + sum (same reduction tree as before: results per query do not depend on kMhaQ)
+  for (int qi = 0; qi < kMhaQ; ++qi) {
+    s_red[threadIdx.x] = mx[qi];
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+      __syncthreads();
+    }
+    const float m_q = s_red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < m; j += 256) {
+      const float e = expf(s_sc[qi * m + j] - m_q);
+      s_sc[qi * m + j] = e;
+      sum += e;
+    }
+    s_red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) s_inv[qi] = 1.f / s_red[0];
     __syncthreads();
   }
-  mx = s_red[0];
-  __syncthreads();
-  float sum = 0.f;
-  for (int j = threadIdx.x; j < m; j += 256) {
-    float e = expf(s_sc[j] - mx);
-    s_sc[j] = e;
-    sum += e;
+  // out[q][d] = sum_j p[q][j] v[j][d]: thread (d, g) owns channel d and the keys j = g (mod ngrp); 4 value loads
+  // in flight per thread (a plain loop over all keys is one dependent L2 round trip per key: 250 us per call), the
+  // ngrp partial sums meet in LDS in fixed order
+  const int d = threadIdx.x % dim, grp = threadIdx.x / dim, ngrp = 256 / dim;   // dim divides 256 (checked on the host)
+  float acc[kMhaQ];
+#pragma unroll
+  for (int qi = 0; qi < kMhaQ; ++qi) acc[qi] = 0.f;
+  const float* vcol = v + d * heads + h;
+  for (int j0 = grp; j0 < m; j0 += 4 * ngrp) {
+    float vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * ngrp;
+      vv[u] = j < m ? vcol[(int64_t)j * c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * ngrp;
+      if (j < m) {
+#pragma unroll
+        for (int qi = 0; qi < kMhaQ; ++qi) acc[qi] = fmaf(s_sc[qi * m + j], vv[u], acc[qi]);
+      }
+    }
   }
-  s_red[threadIdx.x] = sum;
+  __syncthreads();                       // all probabilities consumed: reuse the head of s_sc for the partial sums
+  float* s_part = s_sc;                  // [ngrp][kMhaQ][dim] = 256 * kMhaQ floats <= the score area (>= kMhaQ * 256)
+#pragma unroll
+  for (int qi = 0; qi < kMhaQ; ++qi) s_part[(grp * kMhaQ + qi) * dim + d] = acc[qi];
   __syncthreads();
-  for (int st = 128; st >= 1; st >>= 1) {
-    if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
-    __syncthreads();
-  }
-  const float inv = 1.f / s_red[0];
-  for (int d = threadIdx.x; d < dim; d += 256) {
-    float a = 0.f;
-    for (int j = 0; j < m; ++j) a = fmaf(s_sc[j], v[(int64_t)j * c + d * heads + h], a);
-    out[(int64_t)ni * c + d * heads + h] = a * inv;
+  for (int e = threadIdx.x; e < kMhaQ * dim; e += 256) {
+    const int qi = e / dim, dd = e - qi * dim;
+    float sum = 0.f;
+    for (int g = 0; g < ngrp; ++g) sum += s_part[(g * kMhaQ + qi) * dim + dd];
+    if (n0 + qi < n) out[(int64_t)(n0 + qi) * c + dd * heads + h] = sum * s_inv[qi];
   }
 }
 
@@ -382,9 +439,13 @@ APR_API int apr_group_max(const float* y, int64_t ldy, int32_t n, int32_t k, int
 APR_API int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
                     float* out, void* stream) {
   APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0, "apr_mha: bad arguments");
-  APR_CHECK_ARG((size_t)(m + dim) * 4 <= 60 * 1024, "apr_mha: at most %d keys supported", (60 * 1024) / 4 - dim);
-  hipLaunchKernelGGL(k_mha, dim3((unsigned)(n * heads)), dim3(256), (size_t)(m + dim) * 4, (hipStream_t)stream, q, k, v,
-                     n, m, dim, heads, out);
+  APR_CHECK_ARG(dim <= 256 && 256 % dim == 0, "apr_mha: head dimension %d must divide 256", dim);
+  // scores [kMhaQ][m] (reused for the [256 / dim][kMhaQ][dim] partial sums: needs m >= 256) + queries [kMhaQ][dim]
+  const size_t lds = (size_t)kMhaQ * ((m > 256 ? m : 256) + dim) * 4;
+  APR_CHECK_ARG(lds <= 60 * 1024, "apr_mha: at most %d keys supported", (int)((60 * 1024) / 4 / kMhaQ - dim));
+  const unsigned nqb = (unsigned)((n + kMhaQ - 1) / kMhaQ);
+  hipLaunchKernelGGL(k_mha, dim3(nqb * (unsigned)heads), dim3(256), lds, (hipStream_t)stream, q, k, v, n, m, dim, heads,
+                     out);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

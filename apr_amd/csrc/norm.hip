@@ -7,23 +7,24 @@ namespace {
 
 constexpr int kRowsPerBlock = 256;
 
-// partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over this block's rows
-__global__ void k_bn_partial(const float* __restrict__ x, int64_t ld, int64_t n, int c,
-                             double* __restrict__ partial) {
-  __shared__ double s_sum[4][64], s_sq[4][64];
+// partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over this block's rows.
+// 1024 threads = 64 columns x 16 row lanes: a thread sums 16 rows (two batches of 8 independent loads), the 16 row
+// lanes meet in LDS in fixed order.  (256 threads x 64 rows each was a chain of 8 dependent L2 round trips per
+// thread: 18 us per call whatever the size.)
+__global__ __launch_bounds__(1024) void k_bn_partial(const float* __restrict__ x, int64_t ld, int64_t n, int c,
+                                                     double* __restrict__ partial) {
+  __shared__ double s_sum[16][64], s_sq[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 + tx;
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
   const int64_t r1 = min((long long)(r0 + kRowsPerBlock), (long long)n);
   double s = 0.0, s2 = 0.0;
   if (col < c) {
-    // 8 independent loads in flight per thread, then the fp64 accumulation in row order (a plain loop serialises
-    // one L2 round trip per row: 18 us per call on 28 k rows)
-    for (int64_t rb = r0 + ty; rb < r1; rb += 32) {
+    for (int64_t rb = r0 + ty; rb < r1; rb += 128) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int64_t r = rb + 4 * u;
+        const int64_t r = rb + 16 * u;
         v[u] = r < r1 ? x[r * ld + col] : 0.f;
       }
 #pragma unroll
@@ -38,33 +39,49 @@ __global__ void k_bn_partial(const float* __restrict__ x, int64_t ld, int64_t n,
   s_sq[ty][tx] = s2;
   __syncthreads();
   if (ty == 0 && col < c) {
-    double a = s_sum[0][tx] + s_sum[1][tx] + s_sum[2][tx] + s_sum[3][tx];
-    double b = s_sq[0][tx] + s_sq[1][tx] + s_sq[2][tx] + s_sq[3][tx];
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      a += s_sum[g][tx];
+      b += s_sq[g][tx];
+    }
     partial[((int64_t)blockIdx.x * 2 + 0) * c + col] = a;
     partial[((int64_t)blockIdx.x * 2 + 1) * c + col] = b;
   }
 }
 
-__global__ void k_bn_finish(const double* __restrict__ partial, int nblk, int64_t n, int c,
-                            float* __restrict__ mean, float* __restrict__ var, float eps,
-                            float* __restrict__ scale, float* __restrict__ shift) {
-  int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= c) return;
+// One workgroup per 64 columns: 4 groups of threads each sum a quarter of the block partials (8 loads in flight),
+// the groups meet in LDS in fixed order.
+__global__ __launch_bounds__(256) void k_bn_finish(const double* __restrict__ partial, int nblk, int64_t n, int c,
+                                                   float* __restrict__ mean, float* __restrict__ var, float eps,
+                                                   float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double s_a[4][64], s_q[4][64];
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
   double s = 0.0, s2 = 0.0;
-  for (int b0 = 0; b0 < nblk; b0 += 8) {
-    double a[8], q[8];
+  if (col < c) {
+    for (int b0 = grp; b0 < nblk; b0 += 32) {
+      double a[8], q[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool ok = b0 + u < nblk;
-      a[u] = ok ? partial[((int64_t)(b0 + u) * 2 + 0) * c + col] : 0.0;
-      q[u] = ok ? partial[((int64_t)(b0 + u) * 2 + 1) * c + col] : 0.0;
-    }
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 4 * u;
+        const bool ok = b < nblk;
+        a[u] = ok ? partial[((int64_t)b * 2 + 0) * c + col] : 0.0;
+        q[u] = ok ? partial[((int64_t)b * 2 + 1) * c + col] : 0.0;
+      }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      s += a[u];
-      s2 += q[u];
+      for (int u = 0; u < 8; ++u) {
+        s += a[u];
+        s2 += q[u];
+      }
     }
   }
+  s_a[grp][tx] = s;
+  s_q[grp][tx] = s2;
+  __syncthreads();
+  if (grp != 0 || col >= c) return;
+  s = ((s_a[0][tx] + s_a[1][tx]) + s_a[2][tx]) + s_a[3][tx];
+  s2 = ((s_q[0][tx] + s_q[1][tx]) + s_q[2][tx]) + s_q[3][tx];
   double m = s / (double)n;
   double v = s2 / (double)n - m * m;
   const float mf = (float)m, vf = (float)(v > 0.0 ? v : 0.0);
@@ -123,9 +140,9 @@ APR_API int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c, float
   APR_CHECK_ARG(n > 0 && c > 0 && ld >= c, "apr_bn_stats: bad shape n=%lld c=%d", (long long)n, c);
   APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_bn_stats: scratch too small");
   const int nblk = (int)cdiv64(n, kRowsPerBlock);
-  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, n, c,
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, n, c,
                      (double*)scratch);
-  hipLaunchKernelGGL(k_bn_finish, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_bn_finish, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const double*)scratch, nblk, n, c, mean, var, 0.f, (float*)nullptr, (float*)nullptr);
   APR_LAUNCH_CHECK();
   return APR_OK;
@@ -136,9 +153,9 @@ APR_API int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, fl
   APR_CHECK_ARG(n > 0 && c > 0 && ld >= c && eps >= 0.f, "apr_norm_params: bad arguments");
   APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_norm_params: scratch too small");
   const int nblk = (int)cdiv64(n, kRowsPerBlock);
-  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, n, c,
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, n, c,
                      (double*)scratch);
-  hipLaunchKernelGGL(k_bn_finish, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_bn_finish, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const double*)scratch, nblk, n, c, (float*)nullptr, (float*)nullptr, eps, scale, shift);
   APR_LAUNCH_CHECK();
   return APR_OK;
