@@ -156,9 +156,16 @@ __global__ void k_gather_pool(const float* __restrict__ x, int64_t ldx, int ns, 
       m = (idx >= 0 && idx < ns) ? x[(int64_t)idx * ldx + col] : 0.f;
     } else {
       m = -__builtin_inff();
-      for (int h = 0; h < H; ++h) {
-        const int idx = inds[qi * H + h];
-        m = fmaxf(m, (idx >= 0 && idx < ns) ? x[(int64_t)idx * ldx + col] : 0.f);
+      for (int h0 = 0; h0 < H; h0 += 8) {     // 8 index loads, then 8 gathers in flight (not 2 dependent trips per h)
+        int idx[8];
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) idx[u] = (h0 + u < H) ? inds[qi * H + h0 + u] : -2;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = (idx[u] >= 0 && idx[u] < ns) ? x[(int64_t)idx[u] * ldx + col] : (idx[u] == -2 ? -__builtin_inff() : 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
       }
     }
     out[qi * ldo + col] = m;

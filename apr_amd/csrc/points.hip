@@ -143,20 +143,41 @@ __global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pt
                                                     int* __restrict__ out_len) {
   __shared__ int s_raw[4][kCellCap];
   __shared__ int s_ord[4][kCellCap];
+  __shared__ int s_hist[kMaxBatch];      // cells per cloud seen by this workgroup (one global atomic per bin at the end;
+                                         // an atomic per CELL on 2 addresses serialised the whole kernel: 134 -> 40 us)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 4 + wave;
-  if (c >= *n_cells_dev) return;
+  if (threadIdx.x < kMaxBatch) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int ncell = *n_cells_dev;
+  // grid-stride over the cells (the host only knows an upper bound): wave-uniform loop, no barrier inside
+  for (int c = blockIdx.x * 4 + wave; c < ncell; c += gridDim.x * 4) {
   const int lo = start[c], hi = start[c + 1];
   const int m = hi - lo;
   const int* ord;
   if (m <= kCellCap) {
-    for (int e = lane; e < m; e += 64) s_raw[wave][e] = sorted[lo + e];
-    for (int e = lane; e < m; e += 64) {
-      const int v = s_raw[wave][e];
-      int rank = 0;
-      for (int o = 0; o < m; ++o) rank += s_raw[wave][o] < v ? 1 : 0;
-      s_ord[wave][rank] = v;
+    // rank sort: a lane keeps its (up to 16) values in registers and every LDS read of another value is compared
+    // against all of them (one LDS read per 16 comparisons; the dense cells next to the sensor hold ~1000 points
+    // and set the kernel's duration)
+    int v[kCellCap / 64], rank[kCellCap / 64];
+#pragma unroll
+    for (int u = 0; u < kCellCap / 64; ++u) {
+      const int e = lane + 64 * u;
+      v[u] = e < m ? sorted[lo + e] : 0x7fffffff;
+      rank[u] = 0;
+      if (e < m) s_raw[wave][e] = v[u];
     }
+    __builtin_amdgcn_wave_barrier();
+    const int nu = (m + 63) >> 6;                    // wave-uniform
+    for (int o = 0; o < m; ++o) {
+      const int x = s_raw[wave][o];
+#pragma unroll
+      for (int u = 0; u < kCellCap / 64; ++u)
+        if (u < nu) rank[u] += x < v[u] ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kCellCap / 64; ++u)
+      if (lane + 64 * u < m) s_ord[wave][rank[u]] = v[u];
+    __builtin_amdgcn_wave_barrier();
     ord = s_ord[wave];
   } else {   // very dense cell: in-place insertion sort by one lane (rare)
     if (lane == 0)
@@ -170,13 +191,36 @@ __global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pt
       }
     ord = sorted + lo;
   }
-  if (lane != 0) return;
+  // the points of the cell are fetched by all lanes in parallel into LDS (the rank buffer is free again), lane 0 then
+  // adds them in index order from LDS: same fp32 sum order as the reference, without one dependent global round
+  // trip per point
+  const bool staged = 3 * m <= kCellCap;
+  float* s_val = reinterpret_cast<float*>(s_raw[wave]);
+  if (staged) {
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < m; e += 64) {
+      const int64_t i = ord[e];
+      s_val[3 * e] = pts[3 * i];
+      s_val[3 * e + 1] = pts[3 * i + 1];
+      s_val[3 * e + 2] = pts[3 * i + 2];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane != 0) continue;
   float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int a = 0; a < m; ++a) {
-    const int64_t i = ord[a];
-    sx = __fadd_rn(sx, pts[3 * i]);
-    sy = __fadd_rn(sy, pts[3 * i + 1]);
-    sz = __fadd_rn(sz, pts[3 * i + 2]);
+  if (staged) {
+    for (int a = 0; a < m; ++a) {
+      sx = __fadd_rn(sx, s_val[3 * a]);
+      sy = __fadd_rn(sy, s_val[3 * a + 1]);
+      sz = __fadd_rn(sz, s_val[3 * a + 2]);
+    }
+  } else {
+    for (int a = 0; a < m; ++a) {
+      const int64_t i = ord[a];
+      sx = __fadd_rn(sx, pts[3 * i]);
+      sy = __fadd_rn(sy, pts[3 * i + 1]);
+      sz = __fadd_rn(sz, pts[3 * i + 2]);
+    }
   }
   const float inv = (float)(1.0 / (double)m);
   out_pts[3 * (int64_t)c] = __fmul_rn(sx, inv);
@@ -190,7 +234,10 @@ __global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pt
       out_feats[(int64_t)c * fdim + f] = __fdiv_rn(sacc, fc);
     }
   }
-  atomicAdd(&out_len[cell_coords[c].x], 1);
+  atomicAdd(&s_hist[cell_coords[c].x], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < kMaxBatch && s_hist[threadIdx.x]) atomicAdd(&out_len[threadIdx.x], s_hist[threadIdx.x]);
 }
 
 // ---- radius search ---------------------------------------------------------------------------
@@ -445,7 +492,7 @@ APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengt
   if (rc != APR_OK) return rc;
   int* out_len_dev = w.cursor;  // cursor is dead after k_fill; reuse its first nb ints
   APR_HIP(hipMemsetAsync(out_len_dev, 0, kMaxBatch * 4, st));
-  hipLaunchKernelGGL(k_barycentre, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, pts, w.cell_coords,
+  hipLaunchKernelGGL(k_barycentre, dim3((unsigned)(cdiv64(n, 4) < 4096 ? cdiv64(n, 4) : 4096)), dim3(256), 0, st, pts, w.cell_coords,
                      w.n_cells, w.start, w.sorted, feats, fdim, out_pts, out_feats, out_len_dev);
   APR_LAUNCH_CHECK();
   int status = 0;
