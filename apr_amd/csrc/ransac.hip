@@ -252,16 +252,28 @@ __global__ __launch_bounds__(256) void k_score(const float4* __restrict__ rec, i
     for (int k = 0; k < 12; ++k) T[k] = hyps[h].T[k];
     int cnt = 0;
     double e2 = 0.0;
-    for (int64_t i = threadIdx.x; i < n0; i += 256) {
-      const float4 a = rec[2 * i], b = rec[2 * i + 1];
-      const double sx = a.x, sy = a.y, sz = a.z;
-      double dx = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - (double)b.x;
-      double dy = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - (double)b.y;
-      double dz = T[8] * sx + T[9] * sy + T[10] * sz + T[11] - (double)b.z;
-      double d2 = dx * dx + dy * dy + dz * dz;
-      if (d2 < thr_lt) {   // <=> sqrt(d2) < max_dist
-        ++cnt;
-        e2 += d2;
+    for (int64_t i0 = threadIdx.x; i0 < n0; i0 += 4 * 256) {   // 4 records in flight, consumed in index order
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + u * 256;
+        if (i < n0) {
+          a[u] = rec[2 * i];
+          b[u] = rec[2 * i + 1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u * 256 >= n0) break;
+        const double sx = a[u].x, sy = a[u].y, sz = a[u].z;
+        double dx = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - (double)b[u].x;
+        double dy = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - (double)b[u].y;
+        double dz = T[8] * sx + T[9] * sy + T[10] * sz + T[11] - (double)b[u].z;
+        double d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < thr_lt) {   // <=> sqrt(d2) < max_dist
+          ++cnt;
+          e2 += d2;
+        }
       }
     }
     for (int d = 32; d >= 1; d >>= 1) {
