@@ -7,6 +7,29 @@ from .. import _lib, ops
 from .._lib import check, ptr, stream
 
 
+def tracking(*tensors):
+    """Autograd is recording and one of the tensors / parameters takes part: the modules then run differentiable torch
+    ops (the reference's own formulation) instead of the forward-only HIP kernels."""
+    return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
+def gather_pad(x, inds):
+    """x[inds] where index len(x) addresses an appended zero row (blocks.py:71-102 `gather` on the padded tensor)."""
+    return torch.cat((x, torch.zeros_like(x[:1])), 0)[inds.long()]
+
+
+def instance_norm_rows(x, eps):
+    mu = x.mean(0, keepdim=True)
+    var = x.var(0, unbiased=False, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps)
+
+
+def _act(y, leaky, relu):
+    if leaky is not None:
+        return torch.nn.functional.leaky_relu(y, leaky)
+    return torch.relu(y) if relu else y
+
+
 def _i32(t, name):
     if t.dtype != torch.int32:
         t = t.to(torch.int32)
@@ -122,5 +145,8 @@ def score_head(x_col):
 
 def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=None):
     """Per-channel normalisation over all rows, no affine (InstanceNorm1d on [1,C,N]) + activation."""
+    if tracking(x, residual):
+        y = instance_norm_rows(x, eps)
+        return _act(y if residual is None else y + residual, leaky, relu)
     scale, shift = ops.norm_params(x, eps)
     return ops.affine_act(x, scale=scale, shift=shift, residual=residual, relu=relu, leaky=leaky, out=out)

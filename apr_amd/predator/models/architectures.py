@@ -77,8 +77,15 @@ class KPFCNN(nn.Module):
         score = torch.where(torch.isnan(score), torch.zeros_like(score), score)
         return torch.where(torch.isinf(score), torch.zeros_like(score), score)
 
-    @torch.no_grad()
     def forward(self, batch):
+        """`model.eval()` (or grad disabled): HIP kernels under no_grad.  `model.train()` with grad enabled and
+        parameters requiring grad: the same graph on differentiable torch ops."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward(batch, True)
+        with torch.no_grad():
+            return self._forward(batch, False)
+
+    def _forward(self, batch, grad):
         x = batch['features'].clone().detach()
         len_src_c = int(batch['stack_lengths'][-1][0])
         pcd_c = batch['points'][-1]
@@ -101,16 +108,23 @@ class KPFCNN(nn.Module):
         feats_c = torch.cat([src_feats_c, tgt_feats_c], dim=0)
         feats_c = conv1x1(feats_c, self.proj_gnn, self._c[1])
         scores_c_raw = conv1x1(feats_c, self.proj_score, self._c[2])          # [N_c, 1]
-        feats_gnn_norm = ops.l2_normalize(feats_c)
+        feats_gnn_norm = (torch.nn.functional.normalize(feats_c, p=2, dim=1) if grad else ops.l2_normalize(feats_c))
         feats_gnn_raw = feats_c
 
         # 4. cross saliency: softmax(<src, tgt> / T) @ scores, both directions, never forming N x N
         src_n, tgt_n = feats_gnn_norm[:len_src_c], feats_gnn_norm[len_src_c:]
         src_s, tgt_s = scores_c_raw[:len_src_c], scores_c_raw[len_src_c:]
-        temperature = float(torch.exp(self.epsilon) + 0.03)
-        s1 = kp_ops.softmax_matvec(src_n, tgt_n, tgt_s, temperature)
-        s2 = kp_ops.softmax_matvec(tgt_n, src_n, src_s, temperature)
-        scores_saliency = torch.cat((s1, s2), dim=0).unsqueeze(1)
+        if grad:    # architectures.py:176-181 (the N_c x N_c product is ~1 k x 1 k at the coarsest level)
+            temperature = torch.exp(self.epsilon) + 0.03
+            inner = torch.matmul(src_n, tgt_n.t())
+            s1 = torch.matmul(torch.softmax(inner / temperature, dim=1), tgt_s)
+            s2 = torch.matmul(torch.softmax(inner.t() / temperature, dim=1), src_s)
+            scores_saliency = torch.cat((s1, s2), dim=0)
+        else:
+            temperature = float(torch.exp(self.epsilon) + 0.03)
+            s1 = kp_ops.softmax_matvec(src_n, tgt_n, tgt_s, temperature)
+            s2 = kp_ops.softmax_matvec(tgt_n, src_n, src_s, temperature)
+            scores_saliency = torch.cat((s1, s2), dim=0).unsqueeze(1)
 
         if self.condition and self.add_cross_overlap:
             x = torch.cat([scores_c_raw, scores_saliency, feats_gnn_raw], dim=1)
@@ -127,6 +141,11 @@ class KPFCNN(nn.Module):
                 x = torch.cat([x, skip_x.pop()], dim=1)
             x = block_op(x, batch)
         x = x.contiguous()
+        if grad:    # architectures.py:197-212
+            feats_f = torch.nn.functional.normalize(x[:, :self.final_feats_dim], p=2, dim=1)
+            scores_overlap = self.regular_score(torch.clamp(torch.sigmoid(x[:, self.final_feats_dim]), min=0, max=1))
+            scores_saliency = self.regular_score(torch.clamp(torch.sigmoid(x[:, self.final_feats_dim + 1]), min=0, max=1))
+            return feats_f, scores_overlap, scores_saliency
         feats_f = ops.l2_normalize(x[:, :self.final_feats_dim])
         scores_overlap = kp_ops.score_head(x[:, self.final_feats_dim])
         scores_saliency = kp_ops.score_head(x[:, self.final_feats_dim + 1])

@@ -6,7 +6,8 @@ UnaryBlock :477-510, LastUnaryBlock :513-536, SimpleBlock :539-593, ResnetBottle
 NearestUpsampleBlock :697-712, MaxPoolBlock :715-726, block_decider :385-433), so a reference
 state_dict loads unchanged.  Only the rigid KPConv the APR configs use is implemented
 (KP_influence 'linear', aggregation 'sum', not deformable); other settings raise.
-Forward only; call under torch.no_grad().
+Inference runs the HIP kernels; when autograd is recording (training) every block switches
+to differentiable torch ops with the reference's formulation — KPConv backward kernels are a later round.
 """
 import math
 
@@ -25,10 +26,14 @@ def _param_key(*ts):
 
 
 def max_pool(x, inds):
+    if kp_ops.tracking(x):
+        return kp_ops.gather_pad(x, inds).max(1)[0]
     return kp_ops.gather_pool(x, inds, "max")
 
 
 def closest_pool(x, inds):
+    if kp_ops.tracking(x):
+        return kp_ops.gather_pad(x, inds[:, 0])
     return kp_ops.gather_pool(x, inds, "closest")
 
 
@@ -63,8 +68,22 @@ class KPConv(nn.Module):
         return self._packed
 
     def forward(self, q_pts, s_pts, neighb_inds, x):
+        if kp_ops.tracking(x, self.weights):
+            return self._forward_autograd(q_pts, s_pts, neighb_inds, x)
         wf = kp_ops.kpconv_weighted(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.KP_extent)
         return kp_ops.linear(wf, self._weight())
+
+    def _forward_autograd(self, q_pts, s_pts, inds, x):
+        """blocks.py:229-374, rigid / linear influence / sum aggregation, with plain torch ops."""
+        s_pad = torch.cat((s_pts, torch.zeros_like(s_pts[:1]) + 1e6), 0)
+        neighbors = s_pad[inds.long()] - q_pts.unsqueeze(1)                          # [n, h, 3]
+        sq = torch.sum((neighbors.unsqueeze(2) - self.kernel_points) ** 2, dim=3)      # [n, h, k]
+        w = torch.clamp(1 - torch.sqrt(sq) / self.KP_extent, min=0.0).transpose(1, 2)  # [n, k, h]
+        nx = kp_ops.gather_pad(x, inds)                                              # [n, h, cin]
+        weighted = torch.matmul(w, nx).permute(1, 0, 2)                              # [k, n, cin]
+        out = torch.sum(torch.matmul(weighted, self.weights), dim=0)
+        num = torch.sum(torch.gt(torch.sum(nx, dim=-1), 0.0), dim=-1)
+        return out / torch.max(num, torch.ones_like(num)).unsqueeze(1)
 
     def __repr__(self):
         return 'KPConv(radius: {:.2f}, extent: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(
@@ -85,6 +104,9 @@ class BatchNormBlock(nn.Module):
     def forward(self, x, leaky=None, residual=None):
         if self.use_bn:
             return kp_ops.instance_norm_act(x, eps=self.batch_norm.eps, leaky=leaky, residual=residual)
+        if kp_ops.tracking(x, self.bias, residual):
+            y = x + self.bias
+            return kp_ops._act(y if residual is None else y + residual, leaky, False)
         return ops.affine_act(x, shift=self.bias, leaky=leaky, residual=residual)
 
 
@@ -107,7 +129,7 @@ class UnaryBlock(nn.Module):
         return self._packed
 
     def forward(self, x, batch=None):
-        y = kp_ops.linear(x, self._weight())
+        y = self.mlp(x) if kp_ops.tracking(x, self.mlp.weight) else kp_ops.linear(x, self._weight())
         return self.batch_norm(y, leaky=None if self.no_relu else 0.1)
 
 
@@ -119,6 +141,8 @@ class LastUnaryBlock(nn.Module):
         self._packed, self._key = None, None
 
     def forward(self, x, batch=None):
+        if kp_ops.tracking(x, self.mlp.weight):
+            return self.mlp(x)
         key = _param_key(self.mlp.weight)
         if key != self._key:
             self._packed = kp_ops.pack_linear(self.mlp.weight.detach().t())
@@ -175,7 +199,7 @@ class ResnetBottleneckBlock(nn.Module):
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
         # unary2 (no ReLU) + shortcut + LeakyReLU fused into the normalisation epilogue
-        y = kp_ops.linear(x, self.unary2._weight())
+        y = self.unary2.mlp(x) if kp_ops.tracking(x, self.unary2.mlp.weight) else kp_ops.linear(x, self.unary2._weight())
         return self.unary2.batch_norm(y, leaky=0.1, residual=shortcut)
 
 

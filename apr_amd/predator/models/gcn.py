@@ -32,6 +32,9 @@ class _Packed:
 
 def conv1x1(x, conv, cache, relu=False):
     """Conv1d / Conv2d with kernel size 1 on rows: x [N,cin] -> [N,cout] (+ bias)."""
+    if kp_ops.tracking(x, conv.weight, conv.bias):
+        y = torch.nn.functional.linear(x, conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1]), conv.bias)
+        return torch.relu(y) if relu else y
     bias = None if conv.bias is None else conv.bias.detach()
     return kp_ops.linear(x, cache.get(conv), shift=bias, relu=relu)
 
@@ -50,6 +53,11 @@ class SelfAttention(nn.Module):
 
     def _edge_conv(self, feats, knn, conv, cache, eps):
         n = feats.shape[0]
+        if kp_ops.tracking(feats, conv.weight):
+            ctr = feats.unsqueeze(1).expand(-1, knn.shape[1], -1)
+            e = torch.cat((ctr, feats[knn.long()] - ctr), dim=2).reshape(n * knn.shape[1], -1)
+            y = kp_ops.instance_norm_rows(conv1x1(e, conv, cache), eps)          # InstanceNorm2d over n*k
+            return torch.nn.functional.leaky_relu(y, 0.2).reshape(n, knn.shape[1], -1).max(1)[0]
         e = kp_ops.edge_features(feats, knn)                   # [n*k, 2c]
         y = conv1x1(e, conv, cache)                            # [n*k, c']
         scale, shift = kp_ops.ops.norm_params(y, eps)          # InstanceNorm2d: per channel over n*k
@@ -89,6 +97,11 @@ class MultiHeadedAttention(nn.Module):
 
     def forward(self, query, key, value):
         q, k, v = [conv1x1(x, l, c) for l, x, c in zip(self.proj, (query, key, value), self._c[:3])]
+        if kp_ops.tracking(q, k, v):
+            qh, kh, vh = (t.view(-1, self.dim, self.num_heads) for t in (q, k, v))      # channel c = d*heads + h
+            prob = torch.softmax(torch.einsum('ndh,mdh->hnm', qh, kh) / self.dim ** .5, dim=-1)
+            x = torch.einsum('hnm,mdh->ndh', prob, vh).reshape(q.shape[0], -1)
+            return conv1x1(x, self.merge, self._c[3])
         x = kp_ops.mha(q, k, v, self.num_heads)
         return conv1x1(x, self.merge, self._c[3])
 
@@ -126,8 +139,12 @@ class GCN(nn.Module):
         """coords [N,3], desc [N,C] (row-major) -> updated descriptors."""
         for layer, name in zip(self.layers, self.names):
             if name == 'cross':
-                desc0 = kp_ops.ops.affine_act(layer(desc0, desc1), residual=desc0)
-                desc1 = kp_ops.ops.affine_act(layer(desc1, desc0), residual=desc1)
+                if kp_ops.tracking(desc0, desc1, *layer.parameters()):
+                    desc0 = desc0 + layer(desc0, desc1)
+                    desc1 = desc1 + layer(desc1, desc0)
+                else:
+                    desc0 = kp_ops.ops.affine_act(layer(desc0, desc1), residual=desc0)
+                    desc1 = kp_ops.ops.affine_act(layer(desc1, desc0), residual=desc1)
             elif name == 'self':
                 desc0 = layer(coords0, desc0)
                 desc1 = layer(coords1, desc1)

@@ -129,3 +129,51 @@ def test_kpfcnn_matches_oracle_other_seed(dev):
     feats, ov, sal = model(batch)
     assert rel_l2(feats.cpu(), ref[0]) < 1e-4
     assert (ov.cpu() - ref[1]).abs().max() < 1e-4 and (sal.cpu() - ref[2]).abs().max() < 1e-4
+
+
+def test_kpfcnn_training_path_gradients(dev):
+    """SURVEY 8(f) next-3, Predator side: with autograd recording the KPFCNN runs on differentiable torch ops; its
+    outputs equal the HIP inference path and every parameter gradient equals autograd through the CPU oracle."""
+    if not PREF.available():
+        pytest.skip("oracle/_ref not built")
+    np.random.seed(7)
+    torch.manual_seed(7)
+    cfg, lim = kitti_config(), [30, 30, 30, 30]
+    model = KPFCNN(cfg).to(dev)
+    a, b, _ = synth.make_pair(13, n_beams=16, n_azimuth=400)
+    pts, lens = PREF.subsample_batch(np.concatenate([a, b]), np.array([len(a), len(b)], np.int32), sampleDl=0.3)
+    src, tgt = pts[:lens[0]], pts[lens[0]:]
+    batch = collate_fn_descriptor([(src, tgt, np.ones((len(src), 1), np.float32), np.ones((len(tgt), 1), np.float32))],
+                                  cfg, lim)
+    model.eval()
+    f_inf, ov_inf, sal_inf = model(batch)                      # eval: HIP kernels, no autograd
+    assert not f_inf.requires_grad
+    model.train()
+    f, ov, sal = model(batch)                                  # train + grad enabled: torch-op path
+    assert f.requires_grad and rel_l2(f.detach().cpu(), f_inf.cpu()) < 1e-4
+    assert (ov.detach() - ov_inf).abs().max() < 1e-4 and (sal.detach() - sal_inf).abs().max() < 1e-4
+    rng = np.random.default_rng(0)
+    pf = torch.from_numpy(rng.standard_normal(tuple(f.shape)).astype(np.float32))
+    po = torch.from_numpy(rng.standard_normal(tuple(ov.shape)).astype(np.float32))
+    ps = torch.from_numpy(rng.standard_normal(tuple(sal.shape)).astype(np.float32))
+    ((f * pf.to(dev)).sum() + (ov * po.to(dev)).sum() + (sal * ps.to(dev)).sum()).backward()
+    sd = {k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() else v.cpu())
+          for k, v in model.state_dict().items()}
+    rf, ro, rs = KO.kpfcnn_forward.__wrapped__(sd, cfg, KO.collate(src, tgt, cfg, lim))   # undecorated: autograd on
+    ((rf * pf).sum() + (ro * po).sum() + (rs * ps).sum()).backward()
+    checked, worst = 0, 0.0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g_ref = sd[name].grad
+        if g_ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        if float(g_ref.norm()) < 1e-3:        # biases in front of an instance norm: analytically zero, fp32 noise
+            assert float((p.grad.cpu() - g_ref).norm()) < 1e-4, name
+            continue
+        worst = max(worst, rel_l2(p.grad.cpu(), g_ref))
+        checked += 1
+    # fp32 through ~40 layers of KPConv + instance norms, GPU vs CPU reductions, neighbour order inside distance ties
+    assert checked > 50 and worst < 2e-2, (checked, worst)
