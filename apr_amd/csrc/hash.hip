@@ -32,39 +32,52 @@ __device__ inline int4 load_coord(const int4* coords, int64_t i, int floor_to) {
 }
 
 // Insert every row; the slot keeps the smallest row index of its key.
+// Consecutive rows of a LiDAR scan mostly fall into the same voxel (a beam sweeps ~8 points through a 0.3 m voxel at
+// 10 m range): inside a wave only the FIRST lane of every run of equal keys probes the table and issues the atomics
+// (it also holds the smallest row index of the run); the other lanes of the run receive the slot by shuffle.
 __global__ void k_insert(const int4* __restrict__ coords, int64_t n, const int* __restrict__ n_dev,
                          int floor_to, unsigned long long* __restrict__ keys, int* __restrict__ vals,
                          uint32_t mask, int* __restrict__ slot_of, int* __restrict__ status) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   if (n_dev) n = min((long long)n, (long long)*n_dev);
-  if (i >= n) return;
-  int4 c = load_coord(coords, i, floor_to);
-  if (!apr_key_in_range(c.x, c.y, c.z, c.w)) {
-    *status = 1;
-    slot_of[i] = -1;
-    return;
+  const bool live = i < n;
+  unsigned long long key = APR_KEY_EMPTY;     // never a real key: dead and out-of-range lanes start their own run
+  bool ok = false;
+  if (live) {
+    const int4 c = load_coord(coords, i, floor_to);
+    ok = apr_key_in_range(c.x, c.y, c.z, c.w);
+    if (ok) key = apr_pack_key(c.x, c.y, c.z, c.w);
+    else *status = 1;
   }
-  unsigned long long key = apr_pack_key(c.x, c.y, c.z, c.w);
-  uint32_t slot = apr_hash_u64(key) & mask;
-  for (uint32_t probe = 0; probe <= mask; ++probe) {
-    unsigned long long prev = keys[slot];
-    if (prev != key) {
-      if (prev != APR_KEY_EMPTY) {
-        slot = (slot + 1) & mask;
-        continue;
+  const unsigned long long prev = __shfl_up(key, 1);
+  const bool head = lane == 0 || key != prev || !ok;
+  const unsigned long long heads = __ballot(head);
+  const int leader = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));   // first lane of this lane's run
+  int slot = -1;
+  if (head && ok) {
+    uint32_t sl = apr_hash_u64(key) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+      unsigned long long p = keys[sl];
+      if (p != key) {
+        if (p != APR_KEY_EMPTY) {
+          sl = (sl + 1) & mask;
+          continue;
+        }
+        p = atomicCAS(&keys[sl], APR_KEY_EMPTY, key);
+        if (p != APR_KEY_EMPTY && p != key) {
+          sl = (sl + 1) & mask;
+          continue;
+        }
       }
-      prev = atomicCAS(&keys[slot], APR_KEY_EMPTY, key);
-      if (prev != APR_KEY_EMPTY && prev != key) {
-        slot = (slot + 1) & mask;
-        continue;
-      }
+      atomicMin(&vals[sl], (int)i);
+      slot = (int)sl;
+      break;
     }
-    atomicMin(&vals[slot], (int)i);
-    slot_of[i] = (int)slot;
-    return;
+    if (slot < 0) *status = 2;  // table full (cannot happen with cap >= 2n)
   }
-  *status = 2;  // table full (cannot happen with cap >= 2n)
-  slot_of[i] = -1;
+  slot = __shfl(slot, leader);
+  if (live) slot_of[i] = ok ? slot : -1;
 }
 
 // flag[i] = row i is the first occurrence of its key; per-block counts.
