@@ -49,7 +49,19 @@ class CoordinateManager:
         if (coordinates is None) == (base_map is None):
             raise AprHipError("CoordinateManager: give either coordinates or base_map")
         self._adopted = base_map is not None
-        self.maps = {1: base_map if self._adopted else ops.build_map(coordinates)}
+        if self._adopted and base_map.n_in > 4 * 65536:
+            # the de-duplicating table was sized for the RAW points (2 x 1.4 M slots, ~50 MB for a 12-frame step) and
+            # holds ~10x fewer voxels: every kernel-map probe into it would miss L2.  Re-insert the unique rows into
+            # a table of their own size, chained on the device-side row count (no sync).
+            # Its size is a GUESS (a scan puts >= ~8 points into a voxel): rows / 4; `_finalize` compares it with the
+            # true count and falls back to the big table if the guess was too small.
+            self._compact_rows = max(65536, base_map.n_in // 4)
+            compact = ops.build_map(base_map.coords[:self._compact_rows], n_in_dev=base_map.n_dev)
+            self.maps = {1: compact}
+            self._dedup = base_map
+        else:
+            self.maps = {1: base_map if self._adopted else ops.build_map(coordinates)}
+            self._dedup = None
         self._kmaps = {}
         self._plists = {}
         self._plist_counters = None
@@ -58,9 +70,19 @@ class CoordinateManager:
     # -- coordinate maps -----------------------------------------------------
     def _finalize(self, extras=()):
         pend = [m for m in self.maps.values() if m.n is None]
+        if self._dedup is not None and self._dedup.n is None:
+            pend.append(self._dedup)
         fetched = []
         if pend or extras:
             fetched = ops.finalize_maps(pend, extras)
+            if self._dedup is not None and self._dedup.n > self._compact_rows:
+                # more voxels than the compact table was sized for: adopt the big table after all and rebuild
+                # whatever was chained behind the truncated one (second sync; never on LiDAR-density input)
+                strides = [ts for ts in self.maps if ts != 1]
+                self.maps = {1: self._dedup}
+                self._dedup = None
+                self._kmaps, self._plists = {}, {}
+                self.build_pyramid(strides)
             m1 = self.maps[1]
             if not self._adopted and m1.n != m1.n_in:
                 raise AprHipError(

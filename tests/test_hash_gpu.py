@@ -91,3 +91,35 @@ def test_negative_coordinates_floor(dev):
     ocm = OME.CoordinateManager(C0)
     for ts in (2, 4):
         assert np.array_equal(cm.get_map(ts).coords.cpu().numpy(), ocm.get_coords(ts))
+
+
+def test_batched_dedup_map_compaction_and_fallback(dev):
+    """PairRegistration.voxelize_batch builds ONE hash over all raw points and re-inserts the unique voxels into a
+    table sized by a guess (rows / 4).  Dense scans take that compact table; a sparse cloud (every point its own voxel)
+    exceeds the guess and must fall back to the big table — either way coordinates, sizes and kernel maps equal the
+    plain per-tensor path."""
+    import torch
+    from apr_amd import MinkowskiEngine as ME
+    from apr_amd.fcgf.pipeline import PairRegistration
+    rng = np.random.default_rng(0)
+    sparse = [rng.uniform(-200, 200, (160000, 3)).astype(np.float32) for _ in range(2)]      # ~1 point per voxel
+    dense = [np.repeat(rng.uniform(-40, 40, (20000, 3)), 9, axis=0).astype(np.float32) +      # 9 points per voxel
+             rng.uniform(0, 0.01, (180000, 3)).astype(np.float32) for _ in range(2)]
+    for clouds, expect_fallback in ((sparse, True), (dense, False)):
+        pipe = PairRegistration(torch.nn.Identity(), 0.3)
+        tc = [torch.from_numpy(c).to(dev) for c in clouds]
+        cm, counts, first, poffs = pipe.voxelize_batch(tc)
+        assert (cm._dedup is None) == expect_fallback
+        # reference: per-frame quantisation, then a plain coordinate manager
+        rows = []
+        for b, c in enumerate(tc):
+            m = ops.build_map(ops.voxelize(c, 0.3, b), want_first=True)
+            ops.finalize_maps([m])
+            rows.append(m.coords)
+        ref = ME.CoordinateManager(torch.cat(rows))
+        assert counts == [len(r) for r in rows]
+        for ts in (1, 2, 4, 8):
+            assert torch.equal(cm.get_coordinates(ts), ref.get_coordinates(ts)), ts
+        assert torch.equal(cm.kernel_map(1, 1, 3), ref.kernel_map(1, 1, 3))
+        assert torch.equal(cm.kernel_map(2, 4, 3), ref.kernel_map(2, 4, 3))
+        assert torch.equal(cm.kernel_map(4, 2, 3, True), ref.kernel_map(4, 2, 3, True))
