@@ -301,7 +301,8 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* count
   int64_t per_cu = (160 * 1024) / (int64_t)lds;
   if (per_cu > 8) per_cu = 8;
   int64_t target = 256 * per_cu;
-  if (target > 768) target = 768;
+  static const int s_target = env_int("APR_WS_TARGET", 768);   // A/B switch
+  if (target > s_target) target = s_target;
   int64_t gx = cdiv64(target, cout / 64);
   const int64_t need = cdiv64(n_out * (int64_t)K, 64) + K;
   if (gx > need) gx = need;
