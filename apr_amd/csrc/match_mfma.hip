@@ -376,10 +376,7 @@ __global__ __launch_bounds__(256) void k_nn_dense(const unsigned char* __restric
       for (int g = 0; g < C / 4; ++g) xv[g] = *reinterpret_cast<const f32x4*>(x + g * 4);
       float bd = __builtin_inff();
       int bj = 0x7fffffff;
-#pragma unroll 2
-      for (int jj = 0; jj < 16; ++jj) {
-        const int64_t j = (j0 + jj < j1) ? j0 + jj : j1 - 1;      // clamped re-reads of the last row never win (strict <)
-        const float* __restrict__ y = f1 + j * C;
+      auto consume = [&](const float (&y)[C], int64_t j) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int g = 0; g < C / 4; ++g) {
@@ -394,6 +391,38 @@ __global__ __launch_bounds__(256) void k_nn_dense(const unsigned char* __restric
         if (dd < bd) {
           bd = dd;
           bj = (int)j;
+        }
+      };
+      auto row_of = [&](int jj) { return (j0 + jj < j1) ? j0 + jj : j1 - 1; };   // clamped re-reads never win (strict <)
+      if constexpr (C <= 32) {
+        // two SGPR row sets ping-pong (as in k_feature_nn): row jj+1 is in flight while row jj is consumed; scalar
+        // loads return out of order, so the previous fetch is drained before the next one is issued
+        float ra[C], rb[C];
+        auto fetch = [&](float (&dst)[C], int jj) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_sched_barrier(0);
+          const float* __restrict__ y = f1 + row_of(jj) * C;
+#pragma unroll
+          for (int c = 0; c < C; ++c) dst[c] = y[c];
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        fetch(ra, 0);
+#pragma unroll 1
+        for (int jj = 0; jj < 16; jj += 2) {
+          fetch(rb, jj + 1);
+          consume(ra, row_of(jj));
+          fetch(ra, jj + 2 < 16 ? jj + 2 : 15);
+          consume(rb, row_of(jj + 1));
+        }
+      } else {
+#pragma unroll 2
+        for (int jj = 0; jj < 16; ++jj) {
+          const int64_t j = row_of(jj);
+          const float* __restrict__ yp = f1 + j * C;
+          float y[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) y[c] = yp[c];
+          consume(y, j);
         }
       }
       if (q < n0 && bj != 0x7fffffff) {
