@@ -21,6 +21,18 @@ __global__ void k_voxelize(const float* __restrict__ xyz, int64_t n, float vs, i
   coords[i] = make_int4(batch, (int)floorf(x), (int)floorf(y), (int)floorf(z));
 }
 
+// the same for the concatenated frames of a batch: the batch index of point i is the segment [offsets[b], offsets[b+1])
+// it falls into (<= a dozen segments: a short scan)
+__global__ void k_voxelize_segments(const float* __restrict__ xyz, int64_t n, float vs,
+                                    const long long* __restrict__ offsets, int nseg, int4* __restrict__ coords) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int b = 0;
+  while (b + 1 < nseg && i >= offsets[b + 1]) ++b;
+  float x = xyz[3 * i + 0] / vs, y = xyz[3 * i + 1] / vs, z = xyz[3 * i + 2] / vs;
+  coords[i] = make_int4(b, (int)floorf(x), (int)floorf(y), (int)floorf(z));
+}
+
 __device__ inline int4 load_coord(const int4* coords, int64_t i, int floor_to) {
   int4 c = coords[i];
   if (floor_to > 0) {
@@ -282,6 +294,16 @@ APR_API int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk_cnt, nblk, blk_off, n_out);
   hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(kBlock), 0, st, (const int4*)coords_in, n, n_dev, floor_to,
                      flags, blk_off, slot_of, vals, (int4*)out_coords, (long long*)out_first);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_voxelize_segments(const float* xyz, int64_t n, float voxel_size, const int64_t* offsets, int32_t nseg,
+                                  int32_t* coords, void* stream) {
+  APR_CHECK_ARG(n >= 0 && voxel_size > 0.f && nseg >= 1 && nseg <= 1024 && offsets, "apr_voxelize_segments: bad arguments");
+  if (n == 0) return APR_OK;
+  hipLaunchKernelGGL(k_voxelize_segments, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, xyz, n,
+                     voxel_size, (const long long*)offsets, nseg, (int4*)coords);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

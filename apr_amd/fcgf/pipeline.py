@@ -62,14 +62,17 @@ class PairRegistration:
         offs = [0]
         for n in npts:
             offs.append(offs[-1] + n)
-        coords_all = torch.empty((offs[-1], 4), dtype=torch.int32, device=dev)
-        for b, xyz in enumerate(clouds):
-            ops.voxelize(xyz, self.voxel_size, b, out=coords_all[offs[b]:offs[b + 1]])
+        xyz_all = torch.cat(clouds) if len(clouds) > 1 else clouds[0].contiguous()     # one 17 MB copy per 12-frame step
+        offs_dev = torch.tensor(offs, dtype=torch.int64).to(dev, non_blocking=True)
+        coords_all = ops.voxelize_segments(xyz_all, self.voxel_size, offs_dev)         # one launch for all frames
         m = ops.build_map(coords_all, want_first=True)
-        counts_dev = ops.segment_counts(m, torch.tensor(offs, dtype=torch.int64).to(dev, non_blocking=True))
+        counts_dev = ops.segment_counts(m, offs_dev)
         cm = ME.CoordinateManager(base_map=m)
         (counts,) = cm.build_pyramid([2, 4, 8], extras=[counts_dev])
-        return cm, [int(c) for c in counts], m.first, offs
+        # representative point of every voxel row: ONE gather over the concatenated points (frame b = rows
+        # sum(counts[:b]) .. + counts[b], contiguous)
+        pts_all = xyz_all[m.first]
+        return cm, [int(c) for c in counts], m.first, offs, pts_all
 
     @torch.no_grad()
     def encode_batch(self, cm):
@@ -88,13 +91,12 @@ class PairRegistration:
         if seeds is None:
             seeds = range(len(pairs))
         clouds = [c for p in pairs for c in p]
-        cm, counts, first, poffs = self.voxelize_batch(clouds)
+        cm, counts, first, poffs, pts_all = self.voxelize_batch(clouds)
         F = self.encode_batch(cm)
         offs = [0]
         for n in counts:
             offs.append(offs[-1] + n)
-        # rows of frame b are rows offs[b]:offs[b+1]; their representative points sit at first[...] - point offset
-        pts = [xyz[first[offs[b]:offs[b + 1]] - poffs[b]].contiguous() for b, xyz in enumerate(clouds)]
+        pts = [pts_all[offs[b]:offs[b + 1]] for b in range(len(clouds))]     # rows of frame b (contiguous slices)
         # matching + pose of all B pairs: one library call, one host synchronisation
         res = ops.match_pose_batch([F[offs[2 * i]:offs[2 * i + 1]] for i in range(len(pairs))],
                                    [F[offs[2 * i + 1]:offs[2 * i + 2]] for i in range(len(pairs))],

@@ -52,6 +52,18 @@ def voxelize(xyz: torch.Tensor, voxel_size: float, batch: int = 0, out=None) -> 
     return coords
 
 
+def voxelize_segments(xyz_all: torch.Tensor, voxel_size: float, offsets: torch.Tensor) -> torch.Tensor:
+    """Concatenated frames f32 [n,3] + int64 GPU offsets [nseg+1] -> int32 [n,4] with the frame index as batch id."""
+    xyz_all = _f32(xyz_all, "voxelize_segments.xyz").contiguous()
+    if offsets.dtype != torch.int64 or not offsets.is_cuda or offsets.dim() != 1 or offsets.shape[0] < 2:
+        raise _lib.AprHipError("voxelize_segments: offsets must be an int64 GPU vector of nseg + 1 entries")
+    n = xyz_all.shape[0]
+    coords = torch.empty((n, 4), dtype=torch.int32, device=xyz_all.device)
+    check(_lib_().apr_voxelize_segments(ptr(xyz_all), n, float(voxel_size), ptr(offsets.contiguous()),
+                                        offsets.shape[0] - 1, ptr(coords), stream()))
+    return coords
+
+
 class CoordMap:
     """One coordinate map: unique int32 [n,4] rows + its hash table (key -> row)."""
 

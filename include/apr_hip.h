@@ -80,6 +80,11 @@ int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_dev, int
                   int32_t* out_coords, int64_t* out_first, int32_t* n_out,
                   int32_t* status, void* scratch, size_t scratch_bytes, void* stream);
 
+/* apr_voxelize for the concatenated frames of a batch: point i gets batch index b with offsets[b] <= i < offsets[b+1]
+ * (offsets i64[nseg+1] on the device, nseg <= 1024). */
+int apr_voxelize_segments(const float* xyz, int64_t n, float voxel_size, const int64_t* offsets, int32_t nseg,
+                          int32_t* coords, void* stream);
+
 /* Rows per input segment of a map built over CONCATENATED point sets (a batch of frames voxelised in one build):
  * counts[b] = #{rows r < *n_dev : offsets[b] <= out_first[r] < offsets[b+1]}; out_first is ascending, the count
  * stays on the device so that it can be fetched together with the map sizes in the caller's single sync. */

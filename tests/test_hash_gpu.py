@@ -108,7 +108,7 @@ def test_batched_dedup_map_compaction_and_fallback(dev):
     for clouds, expect_fallback in ((sparse, True), (dense, False)):
         pipe = PairRegistration(torch.nn.Identity(), 0.3)
         tc = [torch.from_numpy(c).to(dev) for c in clouds]
-        cm, counts, first, poffs = pipe.voxelize_batch(tc)
+        cm, counts, first, poffs, _ = pipe.voxelize_batch(tc)
         assert (cm._dedup is None) == expect_fallback
         # reference: per-frame quantisation, then a plain coordinate manager
         rows = []

@@ -238,7 +238,7 @@ def test_register_batch_equals_pair_by_pair(dev):
     single = [pipe(a, b, seed=7 + i) for i, (a, b) in enumerate(pairs)]
     batch = pipe.register_batch(pairs, seeds=[7, 8, 9])
     # features: batched vs separate encoder calls
-    cm, counts, first, poffs = pipe.voxelize_batch([c for p in pairs for c in p])
+    cm, counts, first, poffs, pts_all = pipe.voxelize_batch([c for p in pairs for c in p])
     F = pipe.encode_batch(cm)
     off = 0
     for k, (a, b) in enumerate(pairs):
@@ -247,7 +247,7 @@ def test_register_batch_equals_pair_by_pair(dev):
         assert counts[2 * k] == n0 and counts[2 * k + 1] == n1
         # one batched hash build == per-frame builds: same voxels in the same order, same representative points
         assert torch.equal(cm.get_coordinates(1)[off:off + n0, 1:], c1[:n0, 1:])
-        assert torch.equal(a[first[off:off + n0] - poffs[2 * k]], p0)
+        assert torch.equal(a[first[off:off + n0] - poffs[2 * k]], p0) and torch.equal(pts_all[off:off + n0], p0)
         assert rel_l2(F[off:off + n0].cpu(), F0.cpu()) < 1e-6 and rel_l2(F[off + n0:off + n0 + n1].cpu(), F1.cpu()) < 1e-6
         off += n0 + n1
     for (T1, i1), (T2, i2) in zip(single, batch):
