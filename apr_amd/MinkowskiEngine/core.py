@@ -118,9 +118,15 @@ class CoordinateManager:
         nbr = self._kmaps.get(key)
         if nbr is None:
             in_map, out_map = self.get_map(ts_in), self.get_map(ts_out)
-            # regular: c_in = c_out + o*ts_in ; transposed (coarse->fine): c_coarse = c_fine - o*ts_fine
-            scale = -ts_out if transpose else ts_in
-            nbr = ops.kernel_map(out_map, in_map, kernel_size, scale)
+            if transpose and ts_in == 2 * ts_out:
+                # coarse -> fine: the transpose of the strided fine -> coarse table (same (fine, coarse, offset)
+                # triples), which the encoder builds anyway: a scatter instead of n_fine * K hash probes
+                fwd = self.kernel_map(ts_out, ts_in, kernel_size, False)
+                nbr = ops.kernel_map_transpose(fwd, out_map.n)
+            else:
+                # regular: c_in = c_out + o*ts_in ; transposed (coarse->fine): c_coarse = c_fine - o*ts_fine
+                scale = -ts_out if transpose else ts_in
+                nbr = ops.kernel_map(out_map, in_map, kernel_size, scale)
             self._kmaps[key] = nbr
         return nbr
 

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "apr_map_scratch_bytes": (_sz, [_i64]),
     "apr_voxelize": (C.c_int, [_p, _i64, _f32, _i32, _p, _p]),
     "apr_map_build": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "apr_kernel_map_transpose": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     "apr_voxelize_segments": (C.c_int, [_p, _i64, C.c_float, _p, _i32, _p, _p]),
     "apr_segment_counts": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
     "apr_kernel_map": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p]),

@@ -235,6 +235,14 @@ __global__ void k_kernel_map(const int4* __restrict__ out_coords, int64_t n_out,
   }
 }
 
+// nbrT[i][k] = j  for every entry nbr[j][k] = i >= 0 (each (i, k) has at most one source: plain stores)
+__global__ void k_map_transpose(const int* __restrict__ nbr, int64_t total, int K, int* __restrict__ nbr_t) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int i = nbr[t];
+  if (i >= 0) nbr_t[(int64_t)i * K + (int)(t % K)] = (int)(t / K);
+}
+
 }  // namespace
 
 APR_API int64_t apr_hash_capacity(int64_t n) {
@@ -294,6 +302,19 @@ APR_API int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk_cnt, nblk, blk_off, n_out);
   hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(kBlock), 0, st, (const int4*)coords_in, n, n_dev, floor_to,
                      flags, blk_off, slot_of, vals, (int4*)out_coords, (long long*)out_first);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t,
+                                     void* stream) {
+  APR_CHECK_ARG(n_out >= 0 && n_in >= 0 && K >= 1 && (nbr || n_out == 0) && (nbr_t || n_in == 0),
+                "apr_kernel_map_transpose: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_in > 0) APR_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * K * 4, st));      // -1 everywhere
+  if (n_out > 0)
+    hipLaunchKernelGGL(k_map_transpose, dim3((unsigned)cdiv64(n_out * K, kBlock)), dim3(kBlock), 0, st, nbr,
+                       n_out * (int64_t)K, K, nbr_t);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -52,6 +52,16 @@ def voxelize(xyz: torch.Tensor, voxel_size: float, batch: int = 0, out=None) -> 
     return coords
 
 
+def kernel_map_transpose(nbr: torch.Tensor, n_in: int) -> torch.Tensor:
+    """nbr int32 [n_out, K] over an n_in-row input map -> its transpose int32 [n_in, K] (see apr_kernel_map_transpose)."""
+    if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2:
+        raise _lib.AprHipError("kernel_map_transpose: nbr must be a contiguous int32 [n_out, K] tensor")
+    n_out, K = nbr.shape
+    out = torch.empty((n_in, K), dtype=torch.int32, device=nbr.device)
+    check(_lib_().apr_kernel_map_transpose(ptr(nbr), n_out, K, n_in, ptr(out), stream()))
+    return out
+
+
 def voxelize_segments(xyz_all: torch.Tensor, voxel_size: float, offsets: torch.Tensor) -> torch.Tensor:
     """Concatenated frames f32 [n,3] + int64 GPU offsets [nseg+1] -> int32 [n,4] with the frame index as batch id."""
     xyz_all = _f32(xyz_all, "voxelize_segments.xyz").contiguous()

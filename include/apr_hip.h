@@ -80,6 +80,12 @@ int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_dev, int
                   int32_t* out_coords, int64_t* out_first, int32_t* n_out,
                   int32_t* status, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Transpose of a kernel map: nbr i32[n_out, K] (rows of an n_in-row map, -1 = empty) -> nbr_t i32[n_in, K] with
+ * nbr_t[i][k] = j  <=>  nbr[j][k] = i.  The table of a transposed (coarse -> fine) convolution is exactly the transpose
+ * of the strided (fine -> coarse) table the encoder already built: a memset + one scatter instead of n_in * K hash
+ * probes.  Requires that no (i, k) occurs twice in nbr (true for kernel maps). */
+int apr_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t, void* stream);
+
 /* apr_voxelize for the concatenated frames of a batch: point i gets batch index b with offsets[b] <= i < offsets[b+1]
  * (offsets i64[nseg+1] on the device, nseg <= 1024). */
 int apr_voxelize_segments(const float* xyz, int64_t n, float voxel_size, const int64_t* offsets, int32_t nseg,

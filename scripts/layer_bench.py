@@ -5,9 +5,12 @@ import torch, numpy as np
 from apr_amd import ops, synth
 from apr_amd.MinkowskiEngine.core import CoordinateManager
 dev = torch.device("cuda:0")
-xyz0, xyz1, _ = synth.make_pair(0)
+NF = int(os.environ.get("FRAMES", "2"))          # frames per encoder call (bench default: 12)
+frames = []
+for s in range((NF + 1) // 2):
+    xyz0, xyz1, _ = synth.make_pair(s); frames += [xyz0, xyz1]
 maps = []
-for b, xyz in enumerate((xyz0, xyz1)):
+for b, xyz in enumerate(frames[:NF]):
     c = ops.voxelize(torch.from_numpy(xyz).to(dev), 0.3, b); maps.append(ops.build_map(c))
 ops.finalize_maps(maps)
 cm = CoordinateManager(torch.cat([m.coords for m in maps]))
@@ -45,7 +48,7 @@ for name, ti, to, cin, cout, tr in layers:
         return e0.elapsed_time(e1) * 1000 / 20
     ops.spconv(x, nbr, 27, cin, cout, wp, out=out); batched()
     us = batched()
-    line = f"{name:18s} rows={cm.size(to):6d} P={P:7d} tile {us:7.1f} us {2.0*P*cin*cout/us/1e6:6.1f} TF"
+    line = f"{name:18s} rows={cm.size(to):6d} P={P:7d} tile {us:7.1f} us {2.0*P*cin*cout/us/1e6:6.1f} TF {(4.0*P*(cin+cout)+8*P)/us/1e3:6.0f} GB/s"
     if ops.ws_supported(27, cin, cout):
         t_build = timeit(lambda: ops.build_pairlist(nbr))
         pl = cm.pair_list(ti, to, 3, tr).build()
@@ -53,5 +56,5 @@ for name, ti, to, cin, cout, tr in layers:
         ops.spconv(x, nbr, 27, cin, cout, wp, out=out2, plist=pl); batched(pl, out2)
         us2 = batched(pl, out2)
         err = float((out2 - out).norm() / out.norm())
-        line += f" | ws {us2:7.1f} us {2.0*P*cin*cout/us2/1e6:6.1f} TF  (pairlist build {t_build:5.1f} us, rel diff {err:.1e})"
+        line += f" | ws {us2:7.1f} us {2.0*P*cin*cout/us2/1e6:6.1f} TF {(4.0*P*(cin+cout)+8*P)/us2/1e3:6.0f} GB/s  (pairlist build {t_build:5.1f} us, rel diff {err:.1e})"
     print(line, flush=True)

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from apr_amd import ops, synth
+from apr_amd._lib import AprHipError
 from oracle import me_oracle as OME
 
 pytestmark = pytest.mark.gpu
@@ -78,6 +79,14 @@ def test_pyramid_and_kernel_maps(dev):
         nbr = cm.kernel_map(tc, tf, 3, True).cpu().numpy()
         ref = OME.transpose_map(ocm.get_map(tf, tc, 3), len(ocm.get_coords(tf)))
         assert np.array_equal(nbr, ref), (tc, tf)
+        # ... and the hash-probe build of the same table (the path taken when the strides are not 2:1)
+        probe = ops.kernel_map(cm.get_map(tf), cm.get_map(tc), 3, -tf).cpu().numpy()
+        assert np.array_equal(probe, ref), (tc, tf)
+    # transpose of an empty / single-row table
+    e = ops.kernel_map_transpose(torch.empty((0, 27), dtype=torch.int32, device=dev), 5)
+    assert e.shape == (5, 27) and bool((e == -1).all())
+    with pytest.raises(AprHipError):
+        ops.kernel_map_transpose(torch.empty((3, 27), dtype=torch.int64, device=dev), 5)
 
 
 def test_negative_coordinates_floor(dev):
