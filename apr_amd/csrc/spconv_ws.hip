@@ -23,6 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRows = 512;   // rows per block in the pair-list build (fewer, larger blocks: the K range counters are
                              // contended by every block, ~55 atomics per address on a 28 k-row map)
 constexpr int kBuildWaves = 8;
+constexpr int kMaxG = 64;  // <= 4096 pairs per unit (12 frames per call: 1.3 M pairs over 768 resident units need 27)
 
 struct PairHeader {   // the caller's 32 counters (zero before apr_pairlist_build)
   int cnt[32];        // pairs of offset k; they sit at pair_in[k * n_out .. k * n_out + cnt[k])
@@ -124,44 +125,62 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_pairs_build(const int* __r
 // once per unit (8 independent 16-B loads in flight per thread), then each wave walks 16-pair groups: gather
 // rows -> registers (prefetched one 64-channel chunk ahead, across group boundaries), B fragments from LDS
 // (conflict-free ds_read_b128), cin/64 * 64 MFMAs into 16 accumulator registers.
+template <int NCH>   // cin / 64 when it is 1, 2 or 4; 0 = read it at run time
 __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in, int64_t ldi, PairViews v, int K,
                                                     int cin, int cout, const float* __restrict__ wp,
                                                     float* __restrict__ prod, int n_out, int target_units) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];   // [g = cin/4][col 64][4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the step loop below stays on the SALU
   const int r16 = lane & 15, q = lane >> 4;
   const int col0 = blockIdx.y * 64;
   const int cinG = cin >> 2;
-  const int nchunk = cin >> 6;   // cin % 64 == 0 on this path
+  const int nchunk = NCH ? NCH : cin >> 6;   // cin % 64 == 0 on this path
   // unit table in registers: every wave redoes the 32-entry scan (no LDS, no barrier)
   const int cnt_l = (lane < K) ? v.hdr->cnt[lane] : 0;
   int P = cnt_l;
   for (int d = 16; d >= 1; d >>= 1) P += __shfl_xor(P, d);
   P = __shfl(P, 0);   // lanes >= 32 hold no offsets
-  // pairs per unit: as few as possible (parallelism) while all units fit the chip in ONE round of workgroups
+  // pairs per unit: as few as possible (parallelism) while ALL units fit the chip in ONE round of workgroups.  The
+  // estimate from the total ignores the partial last unit of every offset (up to K extra units): a grid that is a
+  // few units short sends some workgroups round twice and doubles the kernel time, so G grows until the real count
+  // fits (a handful of 5-step wave reductions).
   int G = (int)((((int64_t)(P + 63) >> 6) * gridDim.y + target_units - 1) / target_units);
-  G = G < 1 ? 1 : (G > 16 ? 16 : G);
-  const int span = 64 * G;
-  const int units = (cnt_l + span - 1) / span;
-  int incl = units;
-  for (int d = 1; d < 32; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
+  G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
+  int span, units, incl;
+  for (;;) {
+    span = 64 * G;
+    units = (cnt_l + span - 1) / span;
+    incl = units;
+    for (int d = 1; d < 32; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (__shfl(incl, 31) <= (int)gridDim.x || G >= kMaxG) break;
+    ++G;
   }
   const int total_units = __shfl(incl, 31);
 
   for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
     const int k = __popcll(__ballot(lane < K && incl <= unit));
-    const int excl = __shfl(incl - units, k);
+    const int excl = __builtin_amdgcn_readfirstlane(__shfl(incl - units, k));
     const int region = k * n_out;
     const int p_begin = region + (unit - excl) * span;
-    const int p_end = min(p_begin + span, region + __shfl(cnt_l, k));
+    const int p_end = min(p_begin + span, region + __builtin_amdgcn_readfirstlane(__shfl(cnt_l, k)));
     const int ngroups = (p_end - p_begin + 15) >> 4;
 
     // first group's rows (index load overlaps the weight staging)
     int g = wave;
     int my_p = p_begin + g * 16 + r16;
-    int idx = (g < ngroups) ? v.pair_in[my_p < p_end ? my_p : p_begin] : 0;
+    // row indices are unsigned: the 64-bit row offset is then ONE v_mad_u64_u32 (a signed index costs a sign
+    // extension that the compiler places right behind the index load, i.e. a wait for it inside the wrong step)
+    const unsigned ldi32 = (unsigned)ldi;
+    unsigned idx = (g < ngroups) ? (unsigned)v.pair_in[my_p < p_end ? my_p : p_begin] : 0u;
+    unsigned idx_n = 0;   // row of the wave's second group: requested before the rows of the first, so that inside the step
+    {                // loop "index older than rows older than stores" holds on every path (counted vmcnt waits)
+      const int np = p_begin + (g + 4) * 16 + r16;
+      if (g + 4 < ngroups) idx_n = (unsigned)v.pair_in[np < p_end ? np : p_begin];
+    }
     {
       const float* src = wp + ((int64_t)k * cinG * cout + col0) * 4 + lane * 4;
       for (int g0 = wave; g0 < cinG; g0 += 32) {
@@ -174,54 +193,72 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
           if (g0 + 4 * u < cinG) *reinterpret_cast<f32x4*>(&s_w[((g0 + 4 * u) * 64 + lane) * 4]) = t[u];
       }
     }
-    f32x4 an[4];
-    const float* abase = in + (int64_t)idx * ldi + q * 4;
+    // Flat (group, chunk) pipeline over this wave's groups g = wave, wave + 4, ...: two register buffers used in
+    // turn (the loop is unrolled by two, no copies), the next step's rows are requested BEFORE the step's 64 MFMAs
+    // and the row index of the group after next one step before its rows are — so every load has a full step
+    // (>= 2048 MFMA cycles) to land.  Left to itself the compiler sinks a prefetch written as "a = an; an = load"
+    // to the end of the step and waits for it there; the sched_barrier keeps issue order = program order.
+    f32x4 bufA[4], bufB[4];
+    const float* abase = in + (uint64_t)idx * ldi32 + q * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) an[j] = *reinterpret_cast<const f32x4*>(abase + j * 16);
+    for (int j = 0; j < 4; ++j) bufA[j] = *reinterpret_cast<const f32x4*>(abase + j * 16);
     __syncthreads();
 
-    while (g < ngroups) {
-      const int gn = g + 4;
-      const int np = p_begin + gn * 16 + r16;
-      const int idx_n = (gn < ngroups) ? v.pair_in[np < p_end ? np : p_begin] : idx;
-      f32x4 acc[4];
+    const int nsteps = (g < ngroups) ? ((ngroups - g + 3) >> 2) * nchunk : 0;
+    int c = 0;
+    f32x4 acc[4];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int chunk = 0; chunk < nchunk; ++chunk) {
-        f32x4 a[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = an[j];
-        // prefetch: next chunk of this group, or chunk 0 of the wave's next group (a harmless re-read at the end)
-        const bool last = chunk + 1 == nchunk;
-        const float* nb = last ? in + (int64_t)idx_n * ldi + q * 4 : abase + (chunk + 1) * 64;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) an[j] = *reinterpret_cast<const f32x4*>(nb + j * 16);
-        const float* wb = s_w + (chunk * 16 * 64) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 b[4];
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
-            b[cb] = *reinterpret_cast<const f32x4*>(wb + ((j * 4 + q) * 64 + cb * 16 + r16) * 4);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-              acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[cb][t], a[j][t], acc[cb], 0, 0, 0);
-        }
-      }
-      // D^T: lane (r16 = pair, q) holds channels cb*16 + 4q .. +3 of its pair
-      if (my_p < p_end) {
-        float* dst = prod + (int64_t)my_p * cout + col0 + q * 4;
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)   // written once, read once by k_ws_reduce: keep it out of the caches' way
-          __builtin_nontemporal_store(acc[cb], reinterpret_cast<f32x4*>(dst + cb * 16));
-      }
-      g = gn;
-      my_p = np;
-      idx = idx_n;
-      abase = in + (int64_t)idx * ldi + q * 4;
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define APR_WS_STEP(cur, nxt)                                                                                     \
+    {                                                                                                             \
+      const bool last = (c + 1 == nchunk);                                                                        \
+      const float* nb = last ? in + (uint64_t)idx_n * ldi32 + q * 4 : abase + (c + 1) * 64;                             \
+      /* row of the group after next: always requested (clamped), so every path issues the same number of loads */ \
+      const int np2 = p_begin + (g + 8) * 16 + r16;                                                               \
+      const unsigned idx_nn = (unsigned)v.pair_in[np2 < p_end ? np2 : p_begin];                                                \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(nb + j * 16);        \
+      const float* wb = s_w + (c * 16 * 64) * 4;                                                                  \
+      f32x4 bq[2][4];                                                                                             \
+      _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                            \
+        bq[0][cb] = *reinterpret_cast<const f32x4*>(wb + (q * 64 + cb * 16 + r16) * 4);                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+        if (j < 3) {                                                                                              \
+          _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                        \
+            bq[(j + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(wb + (((j + 1) * 4 + q) * 64 + cb * 16 + r16) * 4); \
+          __builtin_amdgcn_sched_barrier(0); /* B fragments of j + 1 are in flight under the 16 MFMAs of j */    \
+        }                                                                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                             \
+          _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                        \
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[j & 1][cb][t], cur[j][t], acc[cb], 0, 0, 0);        \
+      }                                                                                                           \
+      if (last) {                                                                                                 \
+        /* D^T: lane (r16 = pair, q) holds channels cb*16 + 4q .. +3 of its pair */                               \
+        /* lanes past the unit's end gathered the row of pair p_begin, so they hold exactly ITS product row (each   \
+           MFMA output row depends on its own input row only): they store those same bits there, which keeps     \
+           the stores unconditional (counted vmcnt waits, no exposed store acknowledgement) */                    \
+        float* dst = prod + (int64_t)(my_p < p_end ? my_p : p_begin) * cout + col0 + q * 4;                       \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) /* written once, read once by k_ws_reduce */             \
+          __builtin_nontemporal_store(acc[cb], reinterpret_cast<f32x4*>(dst + cb * 16));                          \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};                   \
+        g += 4;                                                                                                   \
+        my_p += 64;                                                                                               \
+        abase = nb;                                                                                               \
+        idx_n = idx_nn;                                                                                           \
+        c = 0;                                                                                                    \
+      } else {                                                                                                    \
+        ++c;                                                                                                      \
+      }                                                                                                           \
     }
+
+    int s = 0;
+    for (; s + 2 <= nsteps; s += 2) {
+      APR_WS_STEP(bufA, bufB)
+      APR_WS_STEP(bufB, bufA)
+    }
+    if (s < nsteps) APR_WS_STEP(bufA, bufB)
+#undef APR_WS_STEP
     __syncthreads();   // the slice is re-staged by the next unit
   }
 }
@@ -289,6 +326,7 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* count
   APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 27, "apr_spconv_ws_fwd: bad n_out / K");
   APR_CHECK_ARG(cin % 64 == 0 && cin <= 512 && cout % 64 == 0,
                 "apr_spconv_ws_fwd: needs cin %% 64 == 0, cin <= 512 and cout %% 64 == 0");
+  APR_CHECK_ARG(ldi > 0 && ldi < (1ll << 31), "apr_spconv_ws_fwd: ldi out of range");
   APR_CHECK_ARG(ldi % 4 == 0 && ldo % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out) | ((uintptr_t)prod_scratch)) & 15) == 0,
                 "apr_spconv_ws_fwd: 16-byte aligned rows required");
   APR_CHECK_ARG(!residual || (ldr % 4 == 0 && (((uintptr_t)residual) & 15) == 0), "apr_spconv_ws_fwd: residual alignment");
@@ -309,10 +347,14 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* count
   const unsigned units = (unsigned)gx;
   static bool s_attr = false;
   if (!s_attr) {
-    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     s_attr = true;
   }
-  hipLaunchKernelGGL(k_ws_gemm, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,
+  auto kern = cin == 64 ? k_ws_gemm<1> : cin == 128 ? k_ws_gemm<2> : cin == 256 ? k_ws_gemm<4> : k_ws_gemm<0>;
+  hipLaunchKernelGGL(kern, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,
                      prod_scratch, (int)n_out, (int)target);
   const dim3 rgrid((unsigned)cdiv64(n_out * (cout / 4), 256));
   if (K <= 8)

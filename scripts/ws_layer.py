@@ -8,9 +8,12 @@ dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "b2tr"
 cfg = {"b2tr": (1, 1, 64, 64, False), "b4": (8, 8, 256, 256, False), "c4tr": (8, 4, 256, 128, True),
        "b3": (4, 4, 128, 128, False), "c3tr": (4, 2, 256, 64, True), "b2": (2, 2, 64, 64, False)}[which]
-xyz0, xyz1, _ = synth.make_pair(0)
+NF = int(os.environ.get("FRAMES", "2"))          # frames per encoder call (bench default: 12)
+frames = []
+for s in range((NF + 1) // 2):
+    xyz0, xyz1, _ = synth.make_pair(s); frames += [xyz0, xyz1]
 maps = []
-for b, xyz in enumerate((xyz0, xyz1)):
+for b, xyz in enumerate(frames[:NF]):
     c = ops.voxelize(torch.from_numpy(xyz).to(dev), 0.3, b); maps.append(ops.build_map(c))
 ops.finalize_maps(maps)
 cm = CoordinateManager(torch.cat([m.coords for m in maps]))
