@@ -64,16 +64,23 @@ def build_model(name, n_out, dev):
     return m.to(dev).eval()
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC run of this same command
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 fetch correction): the
-    counters cannot be collected from inside the process, so bench.py reports the profiled value."""
+def pmc_traffic(path):
+    """HBM bytes per launch of the dominant kernel (`path` = "tile" | "ws") from the committed PMC run of this same
+    command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 fetch correction; produced by
+    scripts/profile_round.sh): the counters cannot be collected from inside the process, so bench.py reports the
+    profiled value."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spconv_summary.json")))
     if not files:
         return None
     with open(files[-1]) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
+        ks = json.load(f).get("kernels", {})
+    try:
+        if path == "tile":
+            return ks["k_spconv_pairs"]["hbm_bytes_per_launch"]
+        return ks["k_ws_gemm"]["hbm_bytes_per_launch"] + ks["k_ws_reduce"]["hbm_bytes_per_launch"]
+    except KeyError:
+        return None
 
 
 def cpu_baseline(state_dict, name, n_out, pair, ransac_iters):
@@ -279,7 +286,7 @@ def main():
             "kernel": f"{names[dom]} ({what[dom]}); {dl['launches_per_encode']} of the {s['launches'] // nprof} "
                       f"MFMA conv layers of one encode",
             **roof,
-            "traffic": pmc_traffic(),
+            "traffic": pmc_traffic(dom),
             "launches_per_encode": dl["launches_per_encode"],
             "algorithmic_bytes_per_launch": dl["algorithmic_bytes_per_launch"],
             "algorithmic_flops_per_launch": dd["flops"] / dd["launches"],

@@ -1,0 +1,26 @@
+"""Copy the judged artefacts of a scripts/profile_round.sh run from gpurun_out/profile_<tag>/ into profiles/ as r01_*.
+usage: python scripts/collect_profiles.py <tag> [prefix=r01]"""
+import csv, os, shutil, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r01"
+src = os.path.join(root, "gpurun_out", f"profile_{tag}")
+dst = os.path.join(root, "profiles")
+pairs = [("bench.json", f"{prefix}_bench.json"), ("bench_s1.json", f"{prefix}_bench_streams1.json"),
+         ("stats/b_kernel_stats.csv", f"{prefix}_bench_kernel_stats.csv"),
+         ("stats1/b_kernel_stats.csv", f"{prefix}_bench_streams1_kernel_stats.csv"),
+         ("pmc_spconv_summary.json", f"{prefix}_pmc_spconv_summary.json")]
+for a, b in pairs:
+    shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
+    print("copied", b)
+cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name",
+        "Counter_Value"]
+for c, name in (("FETCH_SIZE", "fetch_size"), ("WRITE_SIZE", "write_size")):
+    rows = list(csv.DictReader(open(os.path.join(src, f"pmc_{c}", "p_counter_collection.csv"))))
+    keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_spconv", "k_ws_"))]   # the sparse-conv kernels
+    with open(os.path.join(dst, f"{prefix}_pmc_{name}_spconv.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(cols)
+        for r in keep:
+            w.writerow([r[k][:60] if k == "Kernel_Name" else r[k] for k in cols])
+    print("wrote", f"{prefix}_pmc_{name}_spconv.csv", len(keep), "rows")
