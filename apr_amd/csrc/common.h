@@ -43,6 +43,12 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int apr_internal_nn_brute(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,
                           const unsigned* run_if, void* stream);
 
+// dense.hip: [M, cin] x [cin, cout] with the sparse conv's epilogue (identity kernel map); _ok = shape is supported
+bool apr_internal_dense_ok(int64_t M, int32_t cin, int32_t cout);
+int apr_internal_dense_gemm(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const float* wp,
+                            const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
+                            float* out, int64_t ldo, hipStream_t st);
+
 #ifdef __HIPCC__
 // Inclusive prefix sum over the 64 lanes with DPP adds only (no ds_bpermute round trips, ~6 VALU instead of 6
 // LDS-crossbar shuffles): 4 shifts inside each row of 16 lanes, then the row totals are broadcast into the

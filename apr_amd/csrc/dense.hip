@@ -1,0 +1,153 @@
+// Dense [M, cin] x [cin, cout] contraction with the sparse conv's fused epilogue (SURVEY 8(a) rows P4 step 2, P5 and
+// the K = 1 layers of F5): the unary / bottleneck Linear layers of KPFCNN (`Predator_APR/models/blocks.py:499-504,
+// 653-681`), KPConv's second step `[N, 15*Cin] @ [15*Cin, Cout]` (`blocks.py:347-374`) and the K = 1
+// MinkowskiConvolutions (`FCGF_APR/model/resunet.py:126-140`).  Reached through apr_spconv_fwd with an identity map
+// (nbr == NULL, K == 1): same packed weights Wp[cin/4][cout][4], same out = act(acc * scale + shift + residual).
+//
+// The pair-compacted tile kernel treats these as a sparse conv with one offset: every 16-row group re-reads its
+// 16 KB weight piece through the L1 (20 KB of vector-memory traffic per 64 MFMAs, ~60 % of a CU's L1 rate) and
+// the partial sums take a trip through LDS.  Here a workgroup owns 64*G rows x 64 columns and walks cin in
+// 64-channel chunks: the chunk's weight slice (16 KB) is staged ONCE per workgroup in LDS (double-buffered, the
+// next chunk's global loads are issued before the current chunk's MFMAs), every wave keeps the accumulators of its
+// G 16-row groups in registers for the whole K loop (B fragments from LDS are shared by the G groups), A rows
+// stream straight from global memory into MFMA operand registers one chunk ahead, and the epilogue stores 16-B
+// row pieces.  Exact fp32 (v_mfma_f32_16x16x4_f32, D^T form: a lane ends with 4 consecutive channels of one row).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int G>
+__global__ __launch_bounds__(256) void k_dense_gemm(const float* __restrict__ in, int64_t ldi, int M, int cin,
+                                                    int cout, const float* __restrict__ wp,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const float* __restrict__ residual, int64_t ldr, int relu,
+                                                    float* __restrict__ out, int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) float s_w[2][16 * 64 * 4];   // [buf][g = k/4][col 64][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q = lane >> 4;
+  const int ncol = cout >> 6;
+  const int tile_m = blockIdx.x / ncol, tile_n = blockIdx.x - tile_m * ncol;   // neighbours share the A rows in L2
+  const int row0 = tile_m * (64 * G) + wave * (16 * G);
+  const int col0 = tile_n * 64;
+  const int nchunk = cin >> 6;
+
+  // this lane's A row of each group (clamped: rows past M are computed and dropped)
+  const float* arow[G];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int r = row0 + gi * 16 + r16;
+    arow[gi] = in + (int64_t)(r < M ? r : M - 1) * ldi + q * 4;
+  }
+  // weight staging: thread t copies 4 x 16 B of the chunk: g = (t >> 6) + 4u, lane-contiguous 1 KB rows
+  const float* wsrc = wp + ((int64_t)wave * cout + col0) * 4 + lane * 4;
+  const int64_t wstep_g = (int64_t)4 * cout * 4;      // 4 g-rows further
+  const int64_t wstep_chunk = (int64_t)16 * cout * 4;   // next 64-channel chunk
+  f32x4 wreg[4];
+  f32x4 abuf[2][G][4];
+  f32x4 acc[G][4];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[gi][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int u = 0; u < 4; ++u) wreg[u] = *reinterpret_cast<const f32x4*>(wsrc + u * wstep_g);
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) abuf[0][gi][j] = *reinterpret_cast<const f32x4*>(arow[gi] + j * 16);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(&s_w[0][((wave + 4 * u) * 64 + lane) * 4]) = wreg[u];
+  __syncthreads();
+
+#define APR_DENSE_CHUNK(cur, nxt, c)                                                                              \
+  {                                                                                                               \
+    const bool more = (c) + 1 < nchunk;                                                                           \
+    if (more) {                                                                                                   \
+      const float* ws = wsrc + ((c) + 1) * wstep_chunk;                                                           \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) wreg[u] = *reinterpret_cast<const f32x4*>(ws + u * wstep_g);  \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+          abuf[nxt][gi][j] = *reinterpret_cast<const f32x4*>(arow[gi] + ((c) + 1) * 64 + j * 16);                \
+    }                                                                                                             \
+    const float* wb = &s_w[(c) & 1][0];                                                                           \
+    f32x4 bq[2][4];                                                                                               \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                              \
+      bq[0][cb] = *reinterpret_cast<const f32x4*>(wb + (q * 64 + cb * 16 + r16) * 4);                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+      if (j < 3) {                                                                                                \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                          \
+          bq[(j + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(wb + (((j + 1) * 4 + q) * 64 + cb * 16 + r16) * 4); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+      }                                                                                                           \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                            \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                             \
+          _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                        \
+            acc[gi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[j & 1][cb][t], abuf[cur][gi][j][t],             \
+                                                               acc[gi][cb], 0, 0, 0);                             \
+    }                                                                                                             \
+    if (more) {                                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                               \
+        *reinterpret_cast<f32x4*>(&s_w[((c) + 1) & 1][((wave + 4 * u) * 64 + lane) * 4]) = wreg[u];               \
+    }                                                                                                             \
+    __syncthreads();                                                                                              \
+  }
+
+  int c = 0;
+  for (; c + 2 <= nchunk; c += 2) {
+    APR_DENSE_CHUNK(0, 1, c)
+    APR_DENSE_CHUNK(1, 0, c + 1)
+  }
+  if (c < nchunk) APR_DENSE_CHUNK(0, 1, c)
+#undef APR_DENSE_CHUNK
+
+  // epilogue: lane (r16 = row, q) holds channels col0 + cb*16 + 4q .. +3 of its row
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int r = row0 + gi * 16 + r16;
+    if (r >= M) continue;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = col0 + cb * 16 + q * 4;
+      f32x4 v = acc[gi][cb];
+      if (scale) v *= *reinterpret_cast<const f32x4*>(scale + col);
+      if (shift) v += *reinterpret_cast<const f32x4*>(shift + col);
+      if (residual) v += *reinterpret_cast<const f32x4*>(residual + (int64_t)r * ldr + col);
+      if (relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(out + (int64_t)r * ldo + col) = v;
+    }
+  }
+}
+
+}  // namespace
+
+// true if the dense kernel takes this shape (the caller has checked the 16-B alignment of in / out / residual rows)
+bool apr_internal_dense_ok(int64_t M, int32_t cin, int32_t cout) {
+  static const int s_on = env_int("APR_DENSE_GEMM", 1);   // A/B switch: 0 = identity maps stay on the tile kernel
+  // One workgroup walks the whole of cin for its 64 rows x 64 columns: below ~144 workgroups (deep levels: 1-4 k rows
+  // against cin = 1920 ... 3840) the chip is underfilled and the tile kernel, which deals the cin chunks of a tile to
+  // its 4 waves, is faster (measured: 116 workgroups 47 vs 27 us, 160 workgroups 26 vs 33 us).
+  return s_on && M > 0 && M < (1ll << 31) && cin % 64 == 0 && cout % 64 == 0 && cdiv64(M, 64) * (cout / 64) >= 144;
+}
+
+int apr_internal_dense_gemm(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const float* wp,
+                            const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
+                            float* out, int64_t ldo, hipStream_t st) {
+  // 128-row tiles halve the weight staging per row but need enough workgroups to fill 256 CUs (>= 2 per CU)
+  const int64_t ncol = cout / 64;
+  const bool big = cdiv64(M, 128) * ncol >= 512;
+  if (big)
+    hipLaunchKernelGGL(k_dense_gemm<2>, dim3((unsigned)(cdiv64(M, 128) * ncol)), dim3(256), 0, st, in, ldi, (int)M, cin,
+                       cout, wp, scale, shift, residual, ldr, relu, out, ldo);
+  else
+    hipLaunchKernelGGL(k_dense_gemm<1>, dim3((unsigned)(cdiv64(M, 64) * ncol)), dim3(256), 0, st, in, ldi, (int)M, cin,
+                       cout, wp, scale, shift, residual, ldr, relu, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}

@@ -541,6 +541,10 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
   const bool vec_ok = (ldi % 4) == 0 && (((uintptr_t)in) & 15) == 0 && (ldo % 4) == 0 &&
                       (((uintptr_t)out) & 15) == 0 &&
                       (!residual || ((ldr % 4) == 0 && (((uintptr_t)residual) & 15) == 0));
+  // identity map (dense layer: K = 1 convolutions, Predator's Linear layers and KPConv's second step): dense.hip
+  if (nbr == nullptr && K == 1 && vec_ok && apr_internal_dense_ok(n_out, cin, cout) &&
+      ((((uintptr_t)scale) | ((uintptr_t)shift) | ((uintptr_t)w_packed)) & 15) == 0)
+    return apr_internal_dense_gemm(in, ldi, n_out, cin, cout, w_packed, scale, shift, residual, ldr, relu, out, ldo, st);
   if (s_impl == 2 && use_mfma(K, cin, cout) && K <= kKMax && vec_ok) {
 #define APR_PAIRS(TM_, CN_, CK_)                                                                      \
   return launch_pairs<TM_, CN_, CK_, 4>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift,    \

@@ -111,6 +111,32 @@ def test_spconv_fused_epilogue_and_slices(dev):
     assert float(wide_out[:, :64].abs().max()) == 0.0   # nothing written outside the slice
 
 
+@pytest.mark.parametrize("m,cin,cout", [
+    (4001, 64, 64), (27674, 960, 64), (129, 128, 256), (1246, 1920, 128), (64, 512, 512), (1, 64, 64),
+    (10187, 192, 128), (33000, 64, 128),
+])
+def test_dense_gemm_identity_map(dev, m, cin, cout):
+    """K = 1 with an identity map (Linear layers, KPConv step 2, K = 1 convolutions) runs on k_dense_gemm: column
+    slices as input / output / residual, fused scale + shift + residual + ReLU, ragged last tile."""
+    rng = np.random.default_rng(m + cin + cout)
+    wide_in = torch.from_numpy(rng.standard_normal((m, cin + 32)).astype(np.float32)).to(dev)
+    x = wide_in[:, 32:]
+    W = torch.from_numpy((rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    res_wide = torch.from_numpy(rng.standard_normal((m, cout + 4)).astype(np.float32)).to(dev)
+    res = res_wide[:, 4:]
+    wp = ops.pack_weights(W.to(dev))
+    plain = ops.spconv(x, None, 1, cin, cout, wp, n_out=m)
+    assert rel_l2(plain.cpu(), x.cpu().double() @ W.double()) < 2e-6
+    wide_out = torch.zeros((m, cout + 64), device=dev)
+    ops.spconv(x, None, 1, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=res, relu=True,
+               out=wide_out[:, 64:], n_out=m)
+    ref = torch.relu((x.cpu().double() @ W.double()) * scale.double() + shift.double() + res.cpu().double())
+    assert rel_l2(wide_out[:, 64:].cpu(), ref) < 2e-6
+    assert float(wide_out[:, :64].abs().max()) == 0.0
+
+
 def test_all_empty_offsets(dev):
     n, c = 100, 32
     nbr = torch.full((n, 27), -1, dtype=torch.int32, device=dev)
