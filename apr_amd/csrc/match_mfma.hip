@@ -8,10 +8,14 @@
 //           term) accumulates a.b ~ lo.hi + hi.lo + hi.hi in fp32, so approx(i,j) = |a|^2 + |b|^2 - 2 a.b obeys the
 //           RIGOROUS bound
 //               |approx - d| <= eps(i,j) = 1e-4 |a||b| + 5e-5 (|a|^2 + |b|^2)   (used with |b| <= max_j |b_j|)
-//           (|a - hi - lo| <= 2^-18 |a| and the dropped lo.lo term <= 2^-18 |a||b|: by Cauchy-Schwarz the dot
-//           product is off by <= 3 * 2^-18 |a||b|, doubled by the factor 2 = 2.3e-5, plus <= 1.2e-5 for three
-//           K=32 fp32 accumulations: 3.5e-5, bounded by 1e-4 with ~3x head-room; fp32 norm sums and the direct
-//           form's own rounding stay under the 5e-5 term for C <= 128).  A single-bf16 bound (eps 0.008) is not
+//           Derivation (worst case, every rounding at its bound): bf16 keeps 8 significant bits, so RNE gives
+//           |x - bf16(x)| <= 2^-8 |x|, hence |lo| <= 2^-8 |a| and |a - hi - lo| <= 2^-16 |a| (vector norms).  The three
+//           products drop lo.lo (<= 2^-16 |a||b|) and carry the two residuals (<= 2 * 2^-16 |a||b|): by Cauchy-Schwarz
+//           the dot product is off by <= 3 * 2^-16 |a||b|, doubled by the factor 2 = 9.2e-5, plus <= 1.2e-5 for three
+//           K=32 fp32 accumulations: 1.04e-4 |a||b|.  fp32 norm sums and the direct form's own rounding take
+//           <= 3e-5 (|a|^2 + |b|^2) at C = 128 (less for smaller C); what is left of the second term,
+//           2e-5 (|a|^2 + |b|^2) >= 4e-5 |a||b|, tops the first up to 1.4e-4 |a||b| >= 1.04e-4 |a||b|: the bound
+//           holds with every error at its worst case at once (typical errors are ~10x smaller).  A single-bf16 bound (eps 0.008) is not
 //           enough: untrained / weakly discriminative features put hundreds of targets inside that window.
 //           Per query U_i = min_j (approx + eps) is an upper bound of the true minimum;
 //   refine  the same MFMA pass again; only pairs with approx - eps <= U_i can be the arg-min (or tie with it): for
@@ -27,7 +31,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr float kEpsRel = 1e-4f;     // >= 3.5e-5 derived above, ~3x head-room (MFMA-internal rounding, sqrt, products)
+constexpr float kEpsRel = 1e-4f;     // with kEpsAbs: >= the 1.04e-4 |a||b| worst case derived above
 constexpr float kEpsAbs = 5e-5f;    // fp32 norm sums, fp32 accumulation and the direct form's own rounding, C <= 128
 
 __device__ inline unsigned short to_bf16_rne(float x) {
