@@ -137,7 +137,7 @@ class CoordinateManager:
         if pl is None:
             nbr = self.kernel_map(ts_in, ts_out, kernel_size, transpose)
             if self._plist_counters is None:      # one fill clears the counters of every map of this manager
-                self._plist_counters = torch.zeros((16, 32), dtype=torch.int32, device=nbr.device)
+                self._plist_counters = torch.zeros((16, ops.pair_counter_ints()), dtype=torch.int32, device=nbr.device)
             slot = len(self._plists)
             pl = ops.build_pairlist(nbr, lazy=True,
                                     counters=self._plist_counters[slot] if slot < 16 else None)

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "apr_spconv_packed_size": (_i64, [_i32, _i32, _i32]),
     "apr_spconv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "apr_spconv_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "apr_pairlist_counter_ints": (_i32, []),
     "apr_pairlist_bytes": (_sz, [_i64, _i32]),
     "apr_pairlist_build": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
     "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),

@@ -25,8 +25,13 @@ constexpr int kRows = 512;   // rows per block in the pair-list build (fewer, la
 constexpr int kBuildWaves = 8;
 constexpr int kMaxG = 64;  // <= 4096 pairs per unit (12 frames per call: 1.3 M pairs over 768 resident units need 27)
 
-struct PairHeader {   // the caller's 32 counters (zero before apr_pairlist_build)
-  int cnt[32];        // pairs of offset k; they sit at pair_in[k * n_out .. k * n_out + cnt[k])
+// The caller's counters (zero before apr_pairlist_build): the count of offset k lives at cnt[k * kCntStride], one
+// counter per 256 B.  Packed into one 128-B line, the K x (#blocks) range reservations of a build all queue on ONE
+// L2 channel (~10 ns each: 10 k atomics = the whole 103 us of a 189 k-row build); spread out, they proceed on K
+// channels in parallel.  pairs of offset k sit at pair_in[k * n_out .. k * n_out + cnt)
+constexpr int kCntStride = APR_PAIR_COUNTER_STRIDE;
+struct PairHeader {
+  int cnt[32 * kCntStride];
 };
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void k_pairs_build(const int* __r
         const int r = c * 64 + lane;
         cnt += __popcll(__ballot(r < rows && s_nbr[r * K + k] >= 0));
       }
-      if (lane == 0 && cnt) base[s] = atomicAdd(&v.hdr->cnt[k], cnt);
+      if (lane == 0 && cnt) base[s] = atomicAdd(&v.hdr->cnt[k * kCntStride], cnt);
     }
   }
   // phase 2: ranks -> positions
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
   const int cinG = cin >> 2;
   const int nchunk = NCH ? NCH : cin >> 6;   // cin % 64 == 0 on this path
   // unit table in registers: every wave redoes the 32-entry scan (no LDS, no barrier)
-  const int cnt_l = (lane < K) ? v.hdr->cnt[lane] : 0;
+  const int cnt_l = (lane < K) ? v.hdr->cnt[lane * kCntStride] : 0;
   int P = cnt_l;
   for (int d = 16; d >= 1; d >>= 1) P += __shfl_xor(P, d);
   P = __shfl(P, 0);   // lanes >= 32 hold no offsets
@@ -298,6 +303,8 @@ __global__ __launch_bounds__(256) void k_ws_reduce(const float* __restrict__ pro
 }
 
 }  // namespace
+
+APR_API int32_t apr_pairlist_counter_ints(void) { return 32 * kCntStride; }
 
 APR_API size_t apr_pairlist_bytes(int64_t n_out, int32_t K) {
   return 2 * align256((size_t)(n_out > 0 ? n_out : 1) * K * 4) + 256;

@@ -28,11 +28,13 @@ from .residual_block import get_block
 
 
 # stages of the fused plan that take the weight-stationary conv path (few pairs per tile, large Cin*Cout); chosen from
-# per-layer timings (scripts/layer_bench.py) AND whole-pipeline throughput with two steps in flight: at the finest
-# level (conv2_tr, block2_tr, 64 channels x >100 k rows per call) the path is faster in isolation but streams its
-# product rows through HBM and costs the concurrently running kernels more than it saves (-4 % pairs/s), so those
-# two stay on the tile kernel.  Override with APR_WS_STAGES="conv3,block4,..." / "none".
-WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", "block3_tr")
+# per-layer timings (scripts/layer_bench.py: tile vs gemm + reduce + pair-list build) and the single-stream step time
+# (scripts/host_vs_gpu.py).  With 12 frames per call: conv3 79 -> 53 + 13 us, conv4 94 -> 56 + 13 us, conv2_tr
+# 204 -> 119 + 19 us; block2_tr (64 channels x 190 k rows, two convs on one pair list) is a draw (2 x 221 vs
+# 2 x 218 + 21 us: its product rows make a round trip through HBM) and stays on the tile kernel, as does the
+# 32-channel level.  Override with APR_WS_STAGES="conv3,block4,..." / "none".
+WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", "block3_tr", "conv3", "conv4",
+             "conv2_tr")
 
 
 def _ws_stages():

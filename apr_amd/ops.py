@@ -215,7 +215,7 @@ PROFILE = None  # set to a SpconvProfile to time launches
 
 
 class PairList:
-    """Per-offset pair lists of one kernel map (apr_pairlist_build): 32 zeroed counters + a device blob.
+    """Per-offset pair lists of one kernel map (apr_pairlist_build): a zeroed counter block (32 counters, one per 256 B) + a device blob.
 
     `built` False: only allocated; the first launch of a SpconvBatch that uses it builds it inside the same
     library call (no extra host round trip)."""
@@ -237,18 +237,27 @@ class PairList:
 
     def counts(self):
         """Pairs per offset (host sync; tests / diagnostics)."""
-        return self.build().counters[:self.K].cpu().numpy()
+        return self.build().counters[::pair_counter_stride()][:self.K].cpu().numpy()
+
+
+def pair_counter_ints() -> int:
+    """Length of the int32 counter block of one pair list (32 counters, one per 256 B: apr_pairlist_counter_ints)."""
+    return int(_lib_().apr_pairlist_counter_ints())
+
+
+def pair_counter_stride() -> int:
+    return pair_counter_ints() // 32
 
 
 def build_pairlist(nbr, lazy=False, counters=None):
-    """nbr int32 [n_out, K] -> PairList.  `counters`: an all-zero int32[32] slice to use (a coordinate manager
-    clears the counters of all its maps with one fill); default: a fresh torch.zeros(32)."""
+    """nbr int32 [n_out, K] -> PairList.  `counters`: an all-zero int32[pair_counter_ints()] block to use (a coordinate
+    manager clears the counters of all its maps with one fill); default: a fresh zero block."""
     if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2:
         raise _lib.AprHipError("build_pairlist: nbr must be a contiguous int32 [n_out, K] tensor")
     n_out, K = nbr.shape
     nb = int(_lib_().apr_pairlist_bytes(n_out, K))
     if counters is None:
-        counters = torch.zeros(32, dtype=torch.int32, device=nbr.device)
+        counters = torch.zeros(pair_counter_ints(), dtype=torch.int32, device=nbr.device)
     pl = PairList(counters, torch.empty(nb, dtype=torch.uint8, device=nbr.device), nbr, False)
     return pl if lazy else pl.build()
 

@@ -137,9 +137,13 @@ int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_o
  * (offset, 64 pairs, 64 channels) work unit stages its weight piece once, writes per-pair products to
  * prod_scratch, and a second kernel sums them per output row in fixed offset order
  * with the same fused epilogue as apr_spconv_fwd.  Needs cin % 64 == 0, cin <= 512, cout % 64 == 0, K <= 27.
- * counters: int32[32] per-offset pair counts, ZERO before apr_pairlist_build (the caller clears them: one fill
- * can clear the counters of all maps of a forward pass); plist: apr_pairlist_bytes(n_out, K) bytes.
+ * counters: int32[apr_pairlist_counter_ints()] = 32 counters APR_PAIR_COUNTER_STRIDE ints apart (the pair count of
+ * offset k at counters[k * APR_PAIR_COUNTER_STRIDE]: one counter per 256 B, so the build's range reservations spread
+ * over the L2 channels), ZERO before apr_pairlist_build (the caller clears them: one fill can clear the counters of
+ * all maps of a forward pass); plist: apr_pairlist_bytes(n_out, K) bytes.
  * prod_scratch holds n_out*K rows of cout floats (offset k owns rows [k*n_out, (k+1)*n_out), sparsely used). */
+#define APR_PAIR_COUNTER_STRIDE 64
+int32_t apr_pairlist_counter_ints(void);
 size_t apr_pairlist_bytes(int64_t n_out, int32_t K);
 int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* counters, void* plist,
                        size_t plist_bytes, void* stream);
