@@ -49,6 +49,7 @@ PROTOTYPES = {
     "apr_kernel_map_transpose": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     "apr_voxelize_segments": (C.c_int, [_p, _i64, C.c_float, _p, _i32, _p, _p]),
     "apr_segment_counts": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
+    "apr_kernel_map_same": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
     "apr_kernel_map": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
     "apr_spconv_packed_size": (_i64, [_i32, _i32, _i32]),
     "apr_spconv_pack_weights": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),

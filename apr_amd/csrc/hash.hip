@@ -235,6 +235,41 @@ __global__ void k_kernel_map(const int4* __restrict__ out_coords, int64_t n_out,
   }
 }
 
+// Same-level map (the input map IS the output map, scale = its tensor stride): the relation is symmetric,
+// nbr[j][o] = i  <=>  nbr[i][K-1-o] = j, and the centre offset is the voxel itself.  Only the offsets below the
+// centre are probed; a hit also stores its mirror entry (unique writer: row i never probes offset K-1-o), the misses of
+// the upper half were pre-filled with -1 (k_fill_upper).  Half the hash probes of k_kernel_map.
+__global__ void k_kernel_map_sym(const int4* __restrict__ coords, int64_t n, const unsigned long long* __restrict__ keys,
+                                 const int* __restrict__ vals, uint32_t mask, int ks, int scale,
+                                 int* __restrict__ nbr) {
+  const int K = ks * ks * ks, h = ks / 2, half = K / 2;   // offsets 0 .. half-1 probed, `half` = the centre
+  const int64_t total = n * (half + 1);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / (half + 1);
+    const int o = (int)(t - j * (half + 1));
+    if (o == half) {
+      nbr[j * K + o] = (int)j;
+      continue;
+    }
+    const int ox = o % ks - h, oy = (o / ks) % ks - h, oz = o / (ks * ks) - h;
+    const int4 c = coords[j];
+    const int x = c.y + ox * scale, y = c.z + oy * scale, z = c.w + oz * scale;
+    int r = -1;
+    if (apr_key_in_range(c.x, x, y, z)) r = table_lookup(keys, vals, mask, apr_pack_key(c.x, x, y, z));
+    nbr[j * K + o] = r;
+    if (r >= 0) nbr[(int64_t)r * K + (K - 1 - o)] = (int)j;
+  }
+}
+
+__global__ void k_fill_upper(int* __restrict__ nbr, int64_t n, int K, int half) {
+  const int64_t total = n * half;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / half;
+    nbr[j * K + half + 1 + (int)(t - j * half)] = -1;
+  }
+}
+
 // nbrT[i][k] = j  for every entry nbr[j][k] = i >= 0 (each (i, k) has at most one source: plain stores)
 __global__ void k_map_transpose(const int* __restrict__ nbr, int64_t total, int K, int* __restrict__ nbr_t) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,6 +370,27 @@ APR_API int apr_segment_counts(const int64_t* first, const int32_t* n_dev, const
   if (nseg == 0) return APR_OK;
   hipLaunchKernelGGL(k_segment_counts, dim3((unsigned)cdiv64(nseg, 64)), dim3(64), 0, (hipStream_t)stream,
                      (const long long*)first, n_dev, (const long long*)offsets, nseg, counts);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_kernel_map_same(const int32_t* coords, int64_t n, const uint64_t* keys, const int32_t* vals, int64_t cap,
+                                int32_t kernel_size, int32_t scale, int32_t* nbr, void* stream) {
+  APR_CHECK_ARG(kernel_size >= 3 && (kernel_size & 1) && kernel_size <= 7,
+                "apr_kernel_map_same: kernel_size=%d must be odd, 3 ... 7", kernel_size);
+  APR_CHECK_ARG((cap & (cap - 1)) == 0 && cap > 0, "apr_kernel_map_same: cap must be a power of two");
+  APR_CHECK_ARG(n >= 0 && n < (1ll << 31), "apr_kernel_map_same: bad n");
+  if (n == 0) return APR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int K = kernel_size * kernel_size * kernel_size, half = K / 2;
+  // -1 in the upper half of every row (offsets above the centre): hits are scattered into it by the kernel
+  int64_t fblk = cdiv64(n * half, kBlock);
+  if (fblk > 16384) fblk = 16384;
+  hipLaunchKernelGGL(k_fill_upper, dim3((unsigned)fblk), dim3(kBlock), 0, st, nbr, n, K, half);
+  int64_t nblk = cdiv64(n * (half + 1), kBlock);
+  if (nblk > 65536) nblk = 65536;
+  hipLaunchKernelGGL(k_kernel_map_sym, dim3((unsigned)nblk), dim3(kBlock), 0, st, (const int4*)coords, n,
+                     (const unsigned long long*)keys, vals, (uint32_t)(cap - 1), kernel_size, scale, nbr);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -155,6 +155,12 @@ def kernel_map(out_map: CoordMap, in_map: CoordMap, kernel_size: int, scale: int
     K = kernel_size ** 3
     n_out = out_map.n
     nbr = torch.empty((n_out, K), dtype=torch.int32, device=out_map.coords.device)
+    if out_map is in_map and kernel_size >= 5 and kernel_size % 2 == 1 and scale > 0:
+        # same-level map: symmetric relation, half the probes (apr_kernel_map_same).  Pays for the 5^3 map of conv1
+        # (190 k rows: 186 -> 124 us incl. the -1 fill); on 3^3 maps the extra fill launch eats the gain.
+        check(lib.apr_kernel_map_same(ptr(out_map.coords), n_out, ptr(in_map.keys), ptr(in_map.vals), in_map.cap,
+                                      int(kernel_size), int(scale), ptr(nbr), stream()))
+        return nbr
     check(lib.apr_kernel_map(ptr(out_map.coords), n_out, None, ptr(in_map.keys), ptr(in_map.vals), in_map.cap,
                              int(kernel_size), int(scale), ptr(nbr), stream()))
     return nbr

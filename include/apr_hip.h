@@ -106,6 +106,11 @@ int apr_segment_counts(const int64_t* out_first, const int32_t* n_dev, const int
  *   replaces ME's kernel-map generation behind MinkowskiConvolution /
  *   MinkowskiConvolutionTranspose (FCGF_APR/model/resunet.py:31-140).
  */
+/* The same table for a SAME-LEVEL map (input map == output map, scale = its tensor stride; the maps of every
+ * stride-1 convolution of the network): nbr[j][o] = i <=> nbr[i][K-1-o] = j and the centre is the voxel itself, so
+ * only the offsets below the centre are probed and each hit also stores its mirror entry — half the hash probes. */
+int apr_kernel_map_same(const int32_t* coords, int64_t n, const uint64_t* keys, const int32_t* vals, int64_t cap,
+                        int32_t kernel_size, int32_t scale, int32_t* nbr, void* stream);
 int apr_kernel_map(const int32_t* out_coords, int64_t n_out, const int32_t* n_out_dev,
                    const uint64_t* in_keys, const int32_t* in_vals, int64_t cap,
                    int32_t kernel_size, int32_t scale, int32_t* nbr, void* stream);

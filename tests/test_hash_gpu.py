@@ -74,6 +74,15 @@ def test_pyramid_and_kernel_maps(dev):
     for (ti, to, k) in [(1, 1, 3), (1, 1, 5), (1, 2, 3), (2, 2, 3), (2, 4, 3), (4, 4, 3), (4, 8, 3), (8, 8, 3)]:
         nbr = cm.kernel_map(ti, to, k).cpu().numpy()
         assert np.array_equal(nbr, ocm.get_map(ti, to, k)), (ti, to, k)
+    # same-level maps take the symmetric half-probe kernel; a copy of the map object forces the generic probe kernel
+    import copy
+    for ts, k in [(1, 3), (1, 5), (2, 3), (8, 3)]:
+        m = cm.get_map(ts)
+        sym = torch.empty((m.n, k ** 3), dtype=torch.int32, device=dev)
+        ops.check(ops._lib_().apr_kernel_map_same(ops.ptr(m.coords), m.n, ops.ptr(m.keys), ops.ptr(m.vals), m.cap, k, ts,
+                                                  ops.ptr(sym), ops.stream()))
+        gen = ops.kernel_map(m, copy.copy(m), k, ts)
+        assert torch.equal(sym, gen), (ts, k)
     # transposed maps = forward strided map with in/out swapped
     for (tc, tf) in [(8, 4), (4, 2), (2, 1)]:
         nbr = cm.kernel_map(tc, tf, 3, True).cpu().numpy()

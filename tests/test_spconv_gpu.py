@@ -137,6 +137,29 @@ def test_dense_gemm_identity_map(dev, m, cin, cout):
     assert float(wide_out[:, :64].abs().max()) == 0.0
 
 
+def test_weight_stationary_many_rounds(dev):
+    """More units than resident workgroups (APR_WS_TARGET=4 is read once per process, hence the child process): every
+    workgroup walks several units, re-staging its weight slice, and the result must not change."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, torch, sys\n"
+        "from apr_amd import ops\n"
+        "rng = np.random.default_rng(5)\n"
+        "n, cin, cout, K = 6000, 128, 64, 27\n"
+        "x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()\n"
+        "W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / 30).astype(np.float32)).cuda()\n"
+        "nbr = rng.integers(0, n, size=(n, K)).astype(np.int32); nbr[rng.random((n, K)) > 0.3] = -1\n"
+        "nbr = torch.from_numpy(nbr).cuda()\n"
+        "wp = ops.pack_weights(W)\n"
+        "tile = ops.spconv(x, nbr, K, cin, cout, wp)\n"
+        "ws = ops.spconv(x, nbr, K, cin, cout, wp, plist=ops.build_pairlist(nbr))\n"
+        "err = float((ws - tile).norm() / tile.norm())\n"
+        "print('REL', err); sys.exit(0 if err < 1e-6 else 1)\n")
+    env = dict(os.environ, APR_WS_TARGET="4", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_all_empty_offsets(dev):
     n, c = 100, 32
     nbr = torch.full((n, 27), -1, dtype=torch.int32, device=dev)
