@@ -29,6 +29,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kEpsRel = 1e-4f;     // with kEpsAbs: >= the 1.04e-4 |a||b| worst case derived above
@@ -52,9 +53,10 @@ __global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scal
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t / LPR;
   const int g = (int)(t - row * LPR);
-  if (t == 0 && zero_me) {   // overflow flag, shared-list counter
+  if (t == 0 && zero_me) {   // overflow flag, shared-list counter, dense-list counter
     zero_me[0] = 0u;
     zero_me[1] = 0u;
+    zero_me[2] = 0u;   // dense-block list length
   }
   float s = 0.f;
   if (row < n) {
@@ -334,105 +336,116 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
   }
 }
 
-// Dense blocks: the refine pass left one flag byte per wave-tile (64 queries x 16 targets).  A wave reads 64 flags at
-// a time (interleaved so that clustered flags spread over all waves) and evaluates every flagged block:
-// lane = query with its row in registers, the 16 target rows wave-uniform (scalar loads), the oracle's direct form
-// for all 1024 pairs, a running strict-< minimum per lane (ascending j: ties keep the smaller index), ONE atomicMin
-// per query and block.
-template <int C>
-__global__ __launch_bounds__(256) void k_nn_dense(const unsigned char* __restrict__ dense_flag, int chunk,
-                                                  unsigned qwaves, unsigned nchunk, const float* __restrict__ f0,
-                                                  int64_t n0, const float* __restrict__ f1, int64_t n1,
-                                                  unsigned long long* __restrict__ best) {
+// Dense blocks: the refine pass left one flag byte per wave-tile (64 queries x 16 targets).  k_nn_dense_compact turns
+// the flags into a list of block ids (16 flags per thread, wave-aggregated append: ~200 atomics in all); the waves of
+// k_nn_dense_list then take the listed blocks in turn (grid stride), so a cluster of flagged blocks is spread over the
+// whole chip instead of being walked by the one wave that owns their 64 flags.  Per block: lane = query with its row
+// in registers; the 16 target rows go through LDS ONCE (one vector load per lane instead of 16 dependent scalar
+// fetches, ~0.5 us each) and are read back as broadcasts; the oracle's direct form for all 1024 pairs, a running
+// strict-< minimum per lane (ascending j: ties keep the smaller index), ONE atomicMin per query and block.
+constexpr unsigned kDenseListCap = 1u << 20;
+
+__global__ __launch_bounds__(256) void k_nn_dense_compact(const unsigned char* __restrict__ dense_flag, int chunk,
+                                                          unsigned qwaves, unsigned nchunk, int64_t n0, int64_t n1,
+                                                          unsigned* __restrict__ list, unsigned* __restrict__ count,
+                                                          unsigned* __restrict__ overflow) {
   const int lane = threadIdx.x & 63;
-  const unsigned tpc = (unsigned)chunk >> 4;                        // tiles per chunk
+  const unsigned tpc = (unsigned)chunk >> 4;                        // tiles per chunk (a multiple of 4: chunk % 64 == 0)
   const unsigned nflag = qwaves * nchunk * tpc;                     // < 2^32 (checked on the host)
-  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-  // group g, lane l looks at flag l * ngroups + g: the (up to chunk/16) dense tiles of one clustered refine wave are
-  // consecutive flags, this interleaving hands them to different waves here
-  const unsigned ngroups = (nflag + 63) / 64;
-  for (unsigned g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < ngroups; g += nwaves) {
-    const unsigned f = (unsigned)lane * ngroups + g;
-    bool flagged = false;
-    if (f < nflag) {
-      const unsigned wave_id = f / tpc, tile = f % tpc;
-      const int64_t q0 = (int64_t)(wave_id % qwaves) * 64;
-      const int64_t t0 = (int64_t)(wave_id / qwaves) * chunk;
-      const int64_t j0 = t0 + (int64_t)tile * 16;
-      // only slots the refine pass wrote: live query wave, tile inside its chunk
-      if (q0 < n0 && j0 < min((long long)(t0 + chunk), (long long)n1)) flagged = dense_flag[f] != 0;
+  const unsigned f0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+  unsigned mask = 0;   // bit b: flag f0 + b is set and belongs to a slot the refine pass wrote
+  if (f0 < nflag) {
+    const uint4 v = *reinterpret_cast<const uint4*>(dense_flag + f0);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const unsigned f = f0 + b;
+      if (f < nflag && ((w[b >> 2] >> ((b & 3) * 8)) & 0xffu)) {
+        const unsigned wave_id = f / tpc, tile = f % tpc;
+        const int64_t q0 = (int64_t)(wave_id % qwaves) * 64;
+        const int64_t t0 = (int64_t)(wave_id / qwaves) * chunk;
+        const int64_t j0 = t0 + (int64_t)tile * 16;
+        if (q0 < n0 && j0 < min((long long)(t0 + chunk), (long long)n1)) mask |= 1u << b;
+      }
     }
-    unsigned long long m = __ballot(flagged);
-    while (m) {
-      const int src = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const unsigned fb = (unsigned)src * ngroups + g;              // wave-uniform
-      const unsigned wave_id = fb / tpc, tile = fb % tpc;
-      const unsigned dq = __builtin_amdgcn_readfirstlane((wave_id % qwaves) * 64u);
-      const unsigned t0 = __builtin_amdgcn_readfirstlane((wave_id / qwaves) * (unsigned)chunk);
-      const unsigned ju = __builtin_amdgcn_readfirstlane(t0 + tile * 16u);   // uniform: rows via scalar loads
-      const int64_t q = (int64_t)dq + lane;
-      const int64_t j0 = (int64_t)ju;
-      const int64_t j1 = min(min((long long)(j0 + 16), (long long)((int64_t)t0 + chunk)), (long long)n1);
-      const float* x = f0 + (q < n0 ? q : n0 - 1) * C;
-      f32x4 xv[C / 4];
+  }
+  const int c = __popc(mask);
+  const int incl = apr_wave_incl_scan(c);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  if (total == 0) return;
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(count, (unsigned)total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  unsigned pos = base + (unsigned)(incl - c);
+  while (mask) {
+    const int b = __ffs((int)mask) - 1;
+    mask &= mask - 1;
+    if (pos < kDenseListCap) list[pos] = f0 + (unsigned)b; else overflow[0] = 1u;   // brute force redoes the search
+    ++pos;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_nn_dense_list(const unsigned* __restrict__ list,
+                                                       const unsigned* __restrict__ count, int chunk, unsigned qwaves,
+                                                       const float* __restrict__ f0, int64_t n0,
+                                                       const float* __restrict__ f1, int64_t n1,
+                                                       unsigned long long* __restrict__ best) {
+  __shared__ __attribute__((aligned(16))) float s_t[4][16 * C];   // per wave: the block's 16 target rows
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* my_t = s_t[wave];
+  const unsigned tpc = (unsigned)chunk >> 4;
+  const unsigned n = min(*count, kDenseListCap);
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (unsigned e = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; e < n; e += nwaves) {
+    const unsigned fb = __builtin_amdgcn_readfirstlane(list[e]);
+    const unsigned wave_id = fb / tpc, tile = fb % tpc;
+    const unsigned dq = (wave_id % qwaves) * 64u;
+    const unsigned t0 = (wave_id / qwaves) * (unsigned)chunk;
+    const int64_t q = (int64_t)dq + lane;
+    const int64_t j0 = (int64_t)t0 + (int64_t)tile * 16;
+    const int64_t j1 = min(min((long long)(j0 + 16), (long long)((int64_t)t0 + chunk)), (long long)n1);
+    // targets -> LDS (rows past j1 repeat row j1 - 1: a re-read never wins the strict <)
+    constexpr int VPR = C / 4;   // 16-B vectors per row
 #pragma unroll
-      for (int g = 0; g < C / 4; ++g) xv[g] = *reinterpret_cast<const f32x4*>(x + g * 4);
-      float bd = __builtin_inff();
-      int bj = 0x7fffffff;
-      auto consume = [&](const float (&y)[C], int64_t j) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int v = lane; v < 16 * VPR; v += 64) {
+      const int r = v / VPR, g = v - r * VPR;
+      const int64_t row = (j0 + r < j1) ? j0 + r : j1 - 1;
+      *reinterpret_cast<f32x4*>(my_t + r * C + g * 4) = *reinterpret_cast<const f32x4*>(f1 + row * C + g * 4);
+    }
+    const float* x = f0 + (q < n0 ? q : n0 - 1) * C;
+    f32x4 xv[C / 4];
 #pragma unroll
-        for (int g = 0; g < C / 4; ++g) {
-          const float d0 = xv[g][0] - y[4 * g], d1 = xv[g][1] - y[4 * g + 1];
-          const float d2 = xv[g][2] - y[4 * g + 2], d3 = xv[g][3] - y[4 * g + 3];
-          s0 = fmaf(d0, d0, s0);
-          s1 = fmaf(d1, d1, s1);
-          s2 = fmaf(d2, d2, s2);
-          s3 = fmaf(d3, d3, s3);
-        }
-        const float dd = (s0 + s1) + (s2 + s3);
-        if (dd < bd) {
-          bd = dd;
-          bj = (int)j;
-        }
-      };
-      auto row_of = [&](int jj) { return (j0 + jj < j1) ? j0 + jj : j1 - 1; };   // clamped re-reads never win (strict <)
-      if constexpr (C <= 32) {
-        // two SGPR row sets ping-pong (as in k_feature_nn): row jj+1 is in flight while row jj is consumed; scalar
-        // loads return out of order, so the previous fetch is drained before the next one is issued
-        float ra[C], rb[C];
-        auto fetch = [&](float (&dst)[C], int jj) {
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_sched_barrier(0);
-          const float* __restrict__ y = f1 + row_of(jj) * C;
-#pragma unroll
-          for (int c = 0; c < C; ++c) dst[c] = y[c];
-          __builtin_amdgcn_sched_barrier(0);
-        };
-        fetch(ra, 0);
-#pragma unroll 1
-        for (int jj = 0; jj < 16; jj += 2) {
-          fetch(rb, jj + 1);
-          consume(ra, row_of(jj));
-          fetch(ra, jj + 2 < 16 ? jj + 2 : 15);
-          consume(rb, row_of(jj + 1));
-        }
-      } else {
+    for (int g = 0; g < C / 4; ++g) xv[g] = *reinterpret_cast<const f32x4*>(x + g * 4);
+    float bd = __builtin_inff();
+    int bj = 0x7fffffff;
+    // the wave's own LDS writes are visible to its reads in program order (one wave, LDS ops complete in order)
 #pragma unroll 2
-        for (int jj = 0; jj < 16; ++jj) {
-          const int64_t j = row_of(jj);
-          const float* __restrict__ yp = f1 + j * C;
-          float y[C];
+    for (int jj = 0; jj < 16; ++jj) {
+      // plain v_sub_f32 + (compiler-packed) fma: packed adds (y + (-x)) measured SLOWER here (23 -> 30 us), packed
+      // fp32 issues at the same lane rate and the pairing costs registers
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-          for (int c = 0; c < C; ++c) y[c] = yp[c];
-          consume(y, j);
-        }
+      for (int g = 0; g < C / 4; ++g) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(my_t + jj * C + g * 4);   // broadcast read
+        const float d0 = xv[g][0] - yv[0], d1 = xv[g][1] - yv[1];
+        const float d2 = xv[g][2] - yv[2], d3 = xv[g][3] - yv[3];
+        s0 = fmaf(d0, d0, s0);
+        s1 = fmaf(d1, d1, s1);
+        s2 = fmaf(d2, d2, s2);
+        s3 = fmaf(d3, d3, s3);
       }
-      if (q < n0 && bj != 0x7fffffff) {
-        const unsigned long long mine = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
-        if (mine < __builtin_nontemporal_load(&best[q])) atomicMin(&best[q], mine);
+      const float dd = (s0 + s1) + (s2 + s3);
+      const int64_t j = (j0 + jj < j1) ? j0 + jj : j1 - 1;
+      if (dd < bd) {
+        bd = dd;
+        bj = (int)j;
       }
+    }
+    if (q < n0 && bj != 0x7fffffff) {
+      const unsigned long long mine = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
+      if (mine < __builtin_nontemporal_load(&best[q])) atomicMin(&best[q], mine);
     }
   }
 }
@@ -499,6 +512,12 @@ void nn_grid(int64_t n0, int64_t n1, int64_t* qblocks, int64_t* chunk, int64_t* 
   *nchunk = cdiv64(n1, c);
 }
 
+size_t dense_list_bytes(int64_t qblocks, int64_t nchunk, int64_t chunk) {
+  uint64_t nflag = (uint64_t)(qblocks * 4) * (uint64_t)nchunk * (uint64_t)(chunk / 16);
+  if (nflag > kDenseListCap) nflag = kDenseListCap;
+  return al256((size_t)nflag * 4 + 64);
+}
+
 template <int C>
 int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best, char* p,
              hipStream_t st) {
@@ -517,6 +536,8 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
   unsigned long long* cand = (unsigned long long*)p;   p += al256((size_t)nwaves * kCandWave * 8);
   unsigned long long* shared_list = (unsigned long long*)p;   p += al256((size_t)shared_capacity(n0) * 8);
   unsigned char* dense_flag = (unsigned char*)p;              // one byte per (64 queries x 16 targets) wave-tile
+  p += al256((size_t)(qblocks * 4) * (size_t)nchunk * (size_t)(chunk / 16) + 64);
+  unsigned* dense_list = (unsigned*)p;                        // ids of the flagged blocks (k_nn_dense_compact)
   const unsigned shared_cap = (unsigned)shared_capacity(n0);
   constexpr int LPR = C / 4;
   hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n0 * LPR, 256)), dim3(256), 0, st, f0, n0, kEpsRel, -2.0f, qb,
@@ -536,8 +557,14 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
     apr_set_error("apr_feature_nn_fast: problem too large for the dense-block flags");
     return APR_EINVAL;
   }
-  hipLaunchKernelGGL((k_nn_dense<C>), dim3(1024), dim3(256), 0, st, dense_flag, (int)chunk, (unsigned)(qblocks * 4),
-                     (unsigned)nchunk, f0, n0, f1, n1, best);
+  {
+    const unsigned qwaves = (unsigned)(qblocks * 4);
+    const uint64_t nflag = (uint64_t)qwaves * (uint64_t)nchunk * (uint64_t)(chunk / 16);
+    hipLaunchKernelGGL(k_nn_dense_compact, dim3((unsigned)cdiv64((int64_t)cdiv64((int64_t)nflag, 16), 256)), dim3(256), 0, st,
+                       dense_flag, (int)chunk, qwaves, (unsigned)nchunk, n0, n1, dense_list, overflow + 2, overflow);
+    hipLaunchKernelGGL((k_nn_dense_list<C>), dim3(1024), dim3(256), 0, st, dense_list, overflow + 2, (int)chunk, qwaves, f0,
+                       n0, f1, n1, best);
+  }
   // exact for ANY input: if the lists overflowed, the brute-force kernel (a no-op launch otherwise) redoes the search
   int rc = apr_internal_nn_brute(f0, n0, f1, n1, C, (uint64_t*)best, overflow, st);
   if (rc != APR_OK) return rc;
@@ -554,7 +581,8 @@ APR_API size_t apr_feature_nn_fast_scratch_bytes(int64_t n0, int64_t n1, int32_t
   const size_t nwaves = (size_t)(qblocks * nchunk * 4);
   return 2 * al256((size_t)n0 * c * 2) + 2 * al256((size_t)n1 * c * 2) + al256((size_t)n0 * 16) + al256((size_t)n1 * 16) +
          al256((size_t)n0 * 4) + 256 + al256(nwaves * 4) + al256(nwaves * kCandWave * 8) +
-         al256((size_t)shared_capacity(n0) * 8) + al256((size_t)(qblocks * 4) * (size_t)nchunk * (size_t)(chunk / 16) + 64) + 512;
+         al256((size_t)shared_capacity(n0) * 8) + al256((size_t)(qblocks * 4) * (size_t)nchunk * (size_t)(chunk / 16) + 64) + dense_list_bytes(qblocks, nchunk, chunk) +
+         512;
 }
 
 APR_API int apr_feature_nn_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,
