@@ -114,3 +114,38 @@ def test_decomposed_and_autograd_switch(dev):
     assert len(coords) == 2 and sum(len(c) for c in coords) == len(C)
     assert np.array_equal(coords[1].cpu().numpy(), C[C[:, 0] == 1][:, 1:])
     assert len(out) == len(C)
+
+
+def test_full_size_properties_translation_and_batch_order(dev):
+    """Size-independent properties at BASELINE's full frame size (2 x ~118 k points, where the oracle is too slow to be
+    the checker): (1) shifting every coordinate by a multiple of the coarsest tensor stride (8 voxels: the strided maps snap to
+    floor(c / 2ts) * 2ts) changes the hash layout but not a single kernel-map row, so the features must be BIT-identical; (2) two encodes of the same input are bit-identical although
+    the weight-stationary pair lists are laid out by atomics (positions vary run to run, results must not);
+    (3) swapping the two frames of the batch permutes the rows; a row's partial sums are then grouped differently (the
+    tile kernel deals the ACTIVE offsets of a 64-row tile to its 4 waves), so this one holds to summation-order
+    rounding, not bit for bit."""
+    from apr_amd import ops, synth
+    _, hm = model_pair("ResUNetBN2C", 32)
+    hm.eval()
+    xyz0, xyz1, _ = synth.make_pair(0)
+    frames = []
+    for b, xyz in enumerate((xyz0, xyz1)):
+        m = ops.build_map(ops.voxelize(torch.from_numpy(xyz).to(dev), 0.3, b))
+        ops.finalize_maps([m])
+        frames.append(m.coords.clone())
+    assert min(len(f) for f in frames) > 10000
+
+    def encode(C):
+        with torch.no_grad():
+            return hm(ME.SparseTensor(torch.ones((len(C), 1), device=dev), coordinates=C)).F
+
+    C = torch.cat(frames)
+    base = encode(C)
+    assert torch.equal(base, encode(C))                                   # (2)
+    shift = torch.tensor([0, 40, -512, 8], dtype=torch.int32, device=dev)
+    assert torch.equal(base, encode(C + shift))                           # (1)
+    f0, f1 = frames[0].clone(), frames[1].clone()
+    f0[:, 0], f1[:, 0] = 1, 0
+    swapped = encode(torch.cat([f1, f0]))                                 # (3)
+    n0, n1 = len(frames[0]), len(frames[1])
+    assert rel_l2(swapped[:n1].cpu(), base[n0:].cpu()) < 1e-6 and rel_l2(swapped[n1:].cpu(), base[:n0].cpu()) < 1e-6
