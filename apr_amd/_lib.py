@@ -83,6 +83,7 @@ PROTOTYPES = {
     "apr_grid_subsample_scratch_bytes": (_sz, [_i64]),
     "apr_grid_subsample": (C.c_int, [_p, _i64, _p, _i32, _f32, _p, _i32, _p, _p, _p, _p, _sz, _p]),
     "apr_radius_scratch_bytes": (_sz, [_i64, _i64]),
+    "apr_radius_neighbors_async": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "apr_radius_neighbors": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "apr_knn": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "apr_row_sums": (C.c_int, [_p, _i64, _i64, _i32, _p, _p]),

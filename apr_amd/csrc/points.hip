@@ -251,7 +251,7 @@ struct Grid {
   float cell;
 };
 
-// MODE 0: count only.  MODE 1: fill + sort.
+// MODE 0: count only.  MODE 1: fill + sort.  MODE 2: fill + sort, and the query's neighbour count to counts[].
 template <int MODE>
 __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int64_t nq, const int* __restrict__ qstarts,
                                                 const float* __restrict__ s, int nb, Grid g, float r2,
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
       hit = d2 < r2;
     }
     const unsigned long long m = __ballot(hit);
-    if (MODE == 1 && hit) {
+    if (MODE >= 1 && hit) {
       const int pos = nhit + __popcll(m & ((1ull << lane) - 1ull));
       if (pos < kHitCap) {
         s_d[wave][pos] = d2;
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
     if (lane == 0) counts[qi] = nhit;
     return;
   }
+  if (MODE == 2 && lane == 0) counts[qi] = nhit;
   if (nhit > kHitCap) {
     if (lane == 0) *status = 1;
     nhit = kHitCap;
@@ -450,14 +451,24 @@ GridWork carve(void* scratch, int64_t n) {
   return w;
 }
 
+// Batch start offsets reach the device as a kernel argument, not by hipMemcpyAsync from a stack array: the
+// synchronisation-free entry point returns before its stream work runs.
+struct BatchStarts {
+  int v[kMaxBatch + 1];
+};
+__global__ void k_set_starts(int* __restrict__ dst, BatchStarts s, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = s.v[threadIdx.x];
+}
+
 // points -> cells -> buckets.  mode as in k_cell_coords.
 int build_grid(const float* pts, int64_t n, const int32_t* lengths_host, int nb, float cell, int mode, GridWork& w,
                hipStream_t st) {
-  int starts[kMaxBatch + 1];
+  BatchStarts bs;
+  int* starts = bs.v;
   starts[0] = 0;
   for (int b = 0; b < nb; ++b) starts[b + 1] = starts[b] + lengths_host[b];
   APR_CHECK_ARG(starts[nb] == n, "batch lengths sum to %d, expected %lld points", starts[nb], (long long)n);
-  APR_HIP(hipMemcpyAsync(w.starts_dev, starts, (nb + 1) * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_set_starts, dim3(1), dim3(128), 0, st, w.starts_dev, bs, nb + 1);
   hipLaunchKernelGGL(k_cloud_min, dim3(nb), dim3(kBlock), 0, st, pts, w.starts_dev, nb, w.mins);
   const unsigned nblk = (unsigned)cdiv64(n, kBlock);
   hipLaunchKernelGGL(k_cell_coords, dim3(nblk), dim3(kBlock), 0, st, pts, n, w.starts_dev, nb, w.mins, cell, mode,
@@ -580,6 +591,44 @@ APR_API int apr_radius_neighbors(const float* queries, int64_t nq, const float* 
     apr_set_error("apr_radius_neighbors: a query has more than %d neighbours within the radius", kHitCap);
     return APR_ERANGE;
   }
+  return APR_OK;
+}
+
+// Host-synchronisation-free variant for callers that know the column limit (KPConv's calibrated neighbourhood limits):
+// one fill pass writes limit columns per query (sorted by distance, padded with ns) AND the query's full neighbour
+// count; flags_dev[0] = max count over all queries, flags_dev[1] != 0 if a query overflowed the candidate buffer.
+// The reference's width is min(max count, limit): a caller that needs it reads flags_dev when convenient (one
+// synchronisation for a whole pyramid of tables) and drops the all-padding columns [max count, limit) if any.
+APR_API int apr_radius_neighbors_async(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                                       const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb,
+                                       float radius, int32_t limit, int32_t* out, int64_t out_ld, int32_t* flags_dev,
+                                       void* scratch, size_t scratch_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(nq > 0 && ns > 0 && nq < (1ll << 31) && ns < (1ll << 31) && nb > 0 && nb <= kMaxBatch && radius > 0.f,
+                "apr_radius_neighbors_async: bad arguments");
+  APR_CHECK_ARG(limit > 0 && out != nullptr && out_ld >= limit && flags_dev != nullptr,
+                "apr_radius_neighbors_async: needs limit > 0, an output of >= limit columns and the flag words");
+  APR_CHECK_ARG(scratch_bytes >= apr_radius_scratch_bytes(nq, ns), "apr_radius_neighbors_async: scratch too small");
+  GridWork w = carve(scratch, ns);
+  char* p = (char*)scratch + grid_work_bytes(ns);
+  int* counts = (int*)p;
+  p += align256(nq * 4);
+  int* qstarts = (int*)p;
+  int rc = build_grid(supports, ns, s_lengths_host, nb, radius, 1, w, st);
+  if (rc != APR_OK) return rc;
+  BatchStarts qb;
+  int* qs = qb.v;
+  qs[0] = 0;
+  for (int b = 0; b < nb; ++b) qs[b + 1] = qs[b] + q_lengths_host[b];
+  APR_CHECK_ARG(qs[nb] == nq, "apr_radius_neighbors_async: query batch lengths sum to %d, expected %lld", qs[nb],
+                (long long)nq);
+  hipLaunchKernelGGL(k_set_starts, dim3(1), dim3(128), 0, st, qstarts, qb, nb + 1);
+  Grid g{w.keys, w.vals, (uint32_t)(w.cap - 1), w.start, w.sorted, w.mins, radius};
+  APR_HIP(hipMemsetAsync(flags_dev, 0, 8, st));
+  hipLaunchKernelGGL(k_radius<2>, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, st, queries, nq, qstarts, supports, nb, g,
+                     radius * radius, counts, out, (int)limit, out_ld, (int)ns, flags_dev + 1);
+  hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, st, counts, nq, flags_dev);
+  APR_LAUNCH_CHECK();
   return APR_OK;
 }
 

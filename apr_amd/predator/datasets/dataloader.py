@@ -46,6 +46,21 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits):
     layer_blocks, layer = [], 0
     input_points, input_neighbors, input_pools, input_upsamples, input_batches_len = [], [], [], [], []
     empty_i = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+    # With calibrated limits the neighbour tables are built without host synchronisations (the reference's table width
+    # min(max count, limit) is only needed to drop all-padding columns): their (max count, overflow) words are read
+    # in ONE copy after the loop.  Same tensors as `batch_neighbors_kpconv` returns, 1 sync instead of 2 per table.
+    deferred, slots = [], []
+    flags_all = torch.empty((16, 2), dtype=torch.int32, device=dev)
+
+    def neighbors(queries, supports, q_b, s_b, radius, limit, where):
+        if limit is None or int(limit) <= 0 or len(deferred) >= flags_all.shape[0]:
+            return batch_neighbors_kpconv(queries, supports, q_b, s_b, radius, limit)
+        t = point_ops.radius_neighbors_async(queries, supports, np.asarray(q_b), np.asarray(s_b), radius, int(limit),
+                                             flags_all[len(deferred)])
+        deferred.append(t)
+        slots.append(where)
+        return t
+
     for block_i, block in enumerate(config.architecture):
         if 'global' in block or 'upsample' in block:
             break
@@ -56,18 +71,18 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits):
         if layer_blocks:
             r = r_normal * config.deform_radius / config.conv_radius \
                 if np.any(['deformable' in blck for blck in layer_blocks[:-1]]) else r_normal
-            conv_i = batch_neighbors_kpconv(batched_points, batched_points, batched_lengths, batched_lengths, r,
-                                            neighborhood_limits[layer])
+            conv_i = neighbors(batched_points, batched_points, batched_lengths, batched_lengths, r,
+                               neighborhood_limits[layer], (input_neighbors, len(input_neighbors)))
         else:
             conv_i = empty_i
         if 'pool' in block or 'strided' in block:
             dl = 2 * r_normal / config.conv_radius
             pool_p, pool_b = batch_grid_subsampling_kpconv(batched_points, batched_lengths, sampleDl=dl)
             r = r_normal * config.deform_radius / config.conv_radius if 'deformable' in block else r_normal
-            pool_i = batch_neighbors_kpconv(pool_p, batched_points, pool_b, batched_lengths, r,
-                                            neighborhood_limits[layer])
-            up_i = batch_neighbors_kpconv(batched_points, pool_p, batched_lengths, pool_b, 2 * r,
-                                          neighborhood_limits[layer])
+            pool_i = neighbors(pool_p, batched_points, pool_b, batched_lengths, r, neighborhood_limits[layer],
+                               (input_pools, len(input_pools)))
+            up_i = neighbors(batched_points, pool_p, batched_lengths, pool_b, 2 * r, neighborhood_limits[layer],
+                             (input_upsamples, len(input_upsamples)))
         else:
             pool_i, up_i = empty_i, empty_i
             pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
@@ -81,6 +96,9 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits):
         r_normal *= 2
         layer += 1
         layer_blocks = []
+    if deferred:
+        for (lst, i), t in zip(slots, point_ops.finish_radius_tables(deferred, flags_all)):
+            lst[i] = t
     out = {'points': input_points, 'neighbors': input_neighbors, 'pools': input_pools, 'upsamples': input_upsamples,
            'features': batched_features, 'stack_lengths': input_batches_len}
     for key, val in zip(('rot', 'trans', 'correspondences', 'src_pcd_raw', 'tgt_pcd_raw', 'src_nghb', 'tgt_nghb',

@@ -69,6 +69,41 @@ def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, limit=0):
     return out if w == cap else out[:, :w].contiguous()
 
 
+def radius_neighbors_async(queries, supports, q_lengths, s_lengths, radius, limit, flags):
+    """`radius_neighbors(..., limit)` without a host synchronisation: int32 [Nq, limit] (nearest first, padded with
+    len(supports)); `flags` (int32[2] on the device) receives the largest neighbour count and the overflow flag —
+    the caller reads them when convenient (`finish_radius_tables`)."""
+    lib = _lib.load()
+    queries, supports = _pts(queries, "radius.queries"), _pts(supports, "radius.supports")
+    nq, ns = queries.shape[0], supports.shape[0]
+    qa, qp = _lens(q_lengths)
+    sa, sp = _lens(s_lengths)
+    if len(qa) != len(sa):
+        raise _lib.AprHipError("radius_neighbors: query / support batch counts differ")
+    if limit <= 0 or flags.dtype != torch.int32 or flags.numel() < 2 or not flags.is_contiguous():
+        raise _lib.AprHipError("radius_neighbors_async: needs limit > 0 and a contiguous int32[2] flag tensor")
+    sb = int(lib.apr_radius_scratch_bytes(nq, ns))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=queries.device)
+    out = torch.empty((nq, int(limit)), dtype=torch.int32, device=queries.device)
+    check(lib.apr_radius_neighbors_async(ptr(queries), nq, ptr(supports), ns, qp, sp, len(qa), float(radius), int(limit),
+                                         ptr(out), int(limit), ptr(flags), ptr(scratch), sb, stream()))
+    return out
+
+
+def finish_radius_tables(tables, flags_all):
+    """One synchronisation for a whole pyramid of `radius_neighbors_async` tables: flags_all int32 [n, 2] on the
+    device.  Returns the tables cut to the reference's width min(max count, limit) (columns beyond the largest
+    neighbour count hold padding only); raises like `radius_neighbors` if a query overflowed the candidate buffer."""
+    host = flags_all[:len(tables)].cpu().numpy()
+    done = []
+    for t, (maxc, status) in zip(tables, host):
+        if status != 0:
+            raise _lib.AprHipError("apr_radius_neighbors: a query has more neighbours within the radius than the "
+                                   "kernel's candidate buffer holds")
+        done.append(t if maxc >= t.shape[1] else t[:, :int(maxc)].contiguous())
+    return done
+
+
 def knn(points, k, skip_first=True):
     """int32 [N,k] nearest neighbours inside one cloud (the point itself dropped when skip_first)."""
     lib = _lib.load()

@@ -333,6 +333,16 @@ int apr_radius_neighbors(const float* queries, int64_t nq, const float* supports
                          int32_t limit, int32_t* out, int64_t out_ld, int32_t* width_host,
                          void* scratch, size_t scratch_bytes, void* stream);
 
+/* The same table without a host synchronisation, for callers that know the column limit (KPConv's calibrated
+ * neighbourhood limits, collate_fn_descriptor :121-180): out i32[nq, >= limit] gets the `limit` nearest neighbours per
+ * query (sorted by distance, padded with ns); flags_dev i32[2] on the device: [0] = largest neighbour count of any
+ * query (the reference's table width is min([0], limit); columns [that, limit) are all padding), [1] != 0 if a query
+ * had more neighbours within the radius than the kernel's candidate buffer holds (error). */
+int apr_radius_neighbors_async(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                               const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb, float radius,
+                               int32_t limit, int32_t* out, int64_t out_ld, int32_t* flags_dev,
+                               void* scratch, size_t scratch_bytes, void* stream);
+
 /* k nearest neighbours inside one cloud (brute force, k + skip_first <= 16); replaces the dense
  * square_distance + topk(k+1)[..., 1:] of Predator_APR/models/gcn.py:19-23.  out i32[n,k]. */
 int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t* out, void* stream);
