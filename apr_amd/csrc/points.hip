@@ -28,22 +28,37 @@ constexpr int kHitCap = 1024;  // max neighbours per query the radius kernels ca
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // ---- per-cloud bounding-box minimum -------------------------------------------------------
-__global__ void k_cloud_min(const float* __restrict__ pts, const int* __restrict__ starts, int nb,
-                            float* __restrict__ mins /*[nb,3]*/) {
-  __shared__ float s[3][kBlock];
+constexpr int kMinThreads = 1024;   // one workgroup per cloud: 1024 threads x 4 independent points in flight
+__global__ __launch_bounds__(kMinThreads) void k_cloud_min(const float* __restrict__ pts, const int* __restrict__ starts,
+                                                           int nb, float* __restrict__ mins /*[nb,3]*/) {
+  __shared__ float s[3][kMinThreads / 64];
   const int b = blockIdx.x;
   const int lo = starts[b], hi = starts[b + 1];
   float m[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-  for (int i = lo + threadIdx.x; i < hi; i += kBlock)
-    for (int d = 0; d < 3; ++d) m[d] = fminf(m[d], pts[3 * (int64_t)i + d]);
-  for (int d = 0; d < 3; ++d) s[d][threadIdx.x] = m[d];
-  __syncthreads();
-  for (int st = kBlock / 2; st >= 1; st >>= 1) {
-    if (threadIdx.x < st)
-      for (int d = 0; d < 3; ++d) s[d][threadIdx.x] = fminf(s[d][threadIdx.x], s[d][threadIdx.x + st]);
-    __syncthreads();
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * kMinThreads) {
+    float v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kMinThreads;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v[u][d] = (i < hi) ? pts[3 * (int64_t)i + d] : __builtin_inff();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) m[d] = fminf(m[d], v[u][d]);
   }
-  if (threadIdx.x < 3) mins[3 * b + threadIdx.x] = s[threadIdx.x][0];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    for (int o = 32; o >= 1; o >>= 1) m[d] = fminf(m[d], __shfl_xor(m[d], o));
+  if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 3; ++d) s[d][threadIdx.x >> 6] = m[d];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float r = s[threadIdx.x][0];
+    for (int w = 1; w < kMinThreads / 64; ++w) r = fminf(r, s[threadIdx.x][w]);
+    mins[3 * b + threadIdx.x] = r;
+  }
 }
 
 __device__ inline int batch_of(const int* __restrict__ starts, int nb, int i) {
@@ -469,7 +484,7 @@ int build_grid(const float* pts, int64_t n, const int32_t* lengths_host, int nb,
   for (int b = 0; b < nb; ++b) starts[b + 1] = starts[b] + lengths_host[b];
   APR_CHECK_ARG(starts[nb] == n, "batch lengths sum to %d, expected %lld points", starts[nb], (long long)n);
   hipLaunchKernelGGL(k_set_starts, dim3(1), dim3(128), 0, st, w.starts_dev, bs, nb + 1);
-  hipLaunchKernelGGL(k_cloud_min, dim3(nb), dim3(kBlock), 0, st, pts, w.starts_dev, nb, w.mins);
+  hipLaunchKernelGGL(k_cloud_min, dim3(nb), dim3(kMinThreads), 0, st, pts, w.starts_dev, nb, w.mins);
   const unsigned nblk = (unsigned)cdiv64(n, kBlock);
   hipLaunchKernelGGL(k_cell_coords, dim3(nblk), dim3(kBlock), 0, st, pts, n, w.starts_dev, nb, w.mins, cell, mode,
                      w.coords);
