@@ -9,6 +9,5 @@ for f in sys.argv[2:]:
         print(f, "unreadable:", e); continue
     for r in rows:
         if pat in r["Name"]:
-            name = r["Name"].split("(")[1] if r["Name"].startswith("void (") else r["Name"]
-            name = r["Name"].replace("void (anonymous namespace)::", "").split("(")[0]
+            name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             print(f"{f.split('/')[-2]:18s} {name:24s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.1f} us  min {float(r['MinNs'])/1e3:8.1f} us")
