@@ -254,8 +254,9 @@ __global__ __launch_bounds__(256) void k_fit_check(const float4* __restrict__ re
   }
 }
 
-constexpr int kScoreThreads = 1024;   // 14 k correspondences = 14 records per thread: 4 dependent L2 round trips
-                                      // per hypothesis instead of 14 with 256 threads (k_score 20 -> 9 us)
+constexpr int kScoreThreads = 256;   // 1024 threads per hypothesis cut the kernel from 14 to 12 us in isolation (4 instead of
+                                     // 14 dependent L2 round trips per thread) but cost 2.4 % pairs/s with three steps in
+                                     // flight: a 16-wave workgroup waits for a whole CU's worth of free slots
 // A workgroup per hypothesis (grid-stride; every workgroup reaches the exit): only a few hundred hypotheses survive
 // the checkers, so one WAVE per hypothesis would leave the chip idle behind ~220 serial iterations per wave.
 // The per-thread partial sums are combined in a fixed order (lane tree, then the waves in order): bitwise reproducible.
