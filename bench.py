@@ -148,13 +148,17 @@ def main():
     model = build_model(args.model, args.n_out, dev)
     pipe = PairRegistration(model, voxel_size=0.3, ransac_iters=args.ransac_iters)
 
-    # synthetic pairs of this rank (seeds 64*rank + i); upload before timing.  The pool
-    # is capped at the warm-up count so every distinct input shape has been seen once (allocator
-    # growth, lazy module init) before the timed region starts.
-    npool = max(1, min(args.pool, args.warmup if args.warmup > 0 else 1))
+    # synthetic pairs of this rank (seeds 64*rank + i); upload before timing.  The pool size does NOT
+    # depend on --warmup: every distinct batch composition is run on every worker stream during the untimed setup
+    # below, whatever the driver passes.
+    npool = max(1, args.pool)
     host_pairs = [synth.make_pair(s)[:2] for s in shard.rank_seeds(rank, npool)]
     pairs = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in host_pairs]
     n_pts = float(np.mean([len(a) + len(b) for a, b in host_pairs])) / 2
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     # one-off allocator warm-up (setup, not a step): cache a large HBM segment so the timed region
     # never falls into hipMalloc when a pair's voxel counts differ from the previous pair's
@@ -166,13 +170,6 @@ def main():
     for _ in range(2000):
         ops.affine_act(_tiny, relu=True, out=_tiny)
     torch.cuda.synchronize()
-    # ... and every code path once on a SMALL (16-beam) pair that is not part of the workload
-    _s0, _s1, _ = synth.make_pair(977, n_beams=16, n_azimuth=625)
-    _s0, _s1 = torch.from_numpy(_s0).to(dev), torch.from_numpy(_s1).to(dev)
-    _small = PairRegistration(model, voxel_size=0.3, ransac_iters=args.ransac_iters)
-    for i in range(12):
-        _small(_s0, _s1, seed=i)
-    torch.cuda.synchronize()
 
     B = max(1, args.pairs_per_step)
 
@@ -183,33 +180,59 @@ def main():
         batch = [pairs[(i * B + j) % len(pairs)] for j in range(B)]
         return pipe.register_batch(batch, seeds=[i * B + j for j in range(B)])[-1]
 
-    # S independent pairs in flight: worker w owns HIP stream w and runs steps w, w+S, w+2S, ...
+    # S independent steps in flight: worker w owns HIP stream w and runs steps w, w+S, w+2S, ...  The worker threads
+    # are PERSISTENT (created once, here in the setup): no thread, stream, HSA queue or allocator pool is first touched
+    # inside the timed region.
+    import threading
     if os.environ.get("APR_BENCH_SWITCH"):
         sys.setswitchinterval(float(os.environ["APR_BENCH_SWITCH"]))
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     results = {}
+    step_log = []      # (step, worker, host start, host end) of every step
+    job = {"first": 0, "last": 0, "stop": False, "err": None}
+    go = threading.Barrier(nstreams + 1)
+    done = threading.Barrier(nstreams + 1)
 
-    def worker(w, first, last):
+    def worker(w):
         torch.cuda.set_device(dev)
         with torch.cuda.stream(streams[w]):
-            for i in range(first + w, last, nstreams):
-                results[i] = step(i)
-            streams[w].synchronize()
+            while True:
+                go.wait()
+                if job["stop"]:
+                    return
+                try:
+                    for i in range(job["first"] + w, job["last"], nstreams):
+                        ta = time.perf_counter()
+                        results[i] = step(i)
+                        step_log.append((i, w, ta, time.perf_counter()))
+                    streams[w].synchronize()
+                except BaseException as e:      # surface worker failures instead of hanging the barrier
+                    job["err"] = e
+                done.wait()
+
+    threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(nstreams)]
+    [t.start() for t in threads]
 
     def run_steps(first, last):
-        if nstreams == 1:
-            worker(0, first, last)
-            return
-        import threading
-        ts = [threading.Thread(target=worker, args=(w, first, last)) for w in range(nstreams)]
-        [t.start() for t in ts]
-        [t.join() for t in ts]
+        job["first"], job["last"] = first, last
+        go.wait()
+        done.wait()
+        if job["err"] is not None:
+            raise job["err"]
 
-    for i in range(min(args.warmup, npool)):     # lazily built caches (packed weights, folded BN): one thread
-        step(i)
+    # untimed setup, independent of --warmup: lazily built caches (packed weights, folded BN) on one thread, then every
+    # distinct batch composition (the pool repeats with period `ncomp` steps) at least twice on EVERY worker stream
+    step(0)
     torch.cuda.synchronize()
-    run_steps(min(args.warmup, npool), args.warmup)
+    ncomp = max(1, npool // int(np.gcd(B, npool)))
+    nprime = 2 * nstreams * ncomp
+    tp = time.perf_counter()
+    run_steps(0, nprime)
+    log(f"setup: {nprime} priming steps on {nstreams} worker stream(s) in {time.perf_counter() - tp:.3f}s")
+    # ... then the W warm-up steps the contract asks for
+    run_steps(nprime, nprime + args.warmup)
+    step_log.clear()
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,20 +240,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    first = nprime + args.warmup
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.warmup + args.steps)     # EXACTLY `steps` pairs, `streams` in flight
-    T, info = results[args.warmup + args.steps - 1]
+    run_steps(first, first + args.steps)     # EXACTLY `steps` steps, `streams` in flight
+    T, info = results[first + args.steps - 1]
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dev if backend == "nccl" else torch.device("cpu"))   # all-reduce(MAX)
-
-    def log(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed_local, dev if backend == "nccl" else torch.device("cpu"))   # all-reduce(MAX)
+    job["stop"] = True
+    go.wait()
 
     log(f"timed loop: {args.steps} steps in {elapsed:.3f}s with {nstreams} stream(s)")
+    # steady state: median interval between step completions (each completion = one step of B pairs), next to the
+    # mean over the whole timed region that `ms_per_step` reports
+    ends = sorted(tb for _, _, _, tb in step_log)
+    gaps = np.diff(np.array([t0] + ends))
+    steady_ms = 1e3 * float(np.median(gaps)) if len(gaps) else float("nan")
+    if os.environ.get("APR_BENCH_STEPLOG"):
+        for i, w, ta, tb in sorted(step_log):
+            log(f"  step {i - first:4d} worker {w} start {1e3 * (ta - t0):8.2f} ms  host {1e3 * (tb - ta):7.2f} ms")
+    log(f"steady state: median step-completion interval {steady_ms:.3f} ms vs mean {1e3 * elapsed / args.steps:.3f} ms")
+    # end-of-run stats of every rank: one all_gather of a few floats
+    stats = shard.gather_stats([args.steps * B, elapsed_local, float(info["n_valid"])],
+                               dev if backend == "nccl" else torch.device("cpu"))
     out = {
         "metric": "point-cloud pairs/sec (120k-pt KITTI frame, FCGF encode+match+SVD)",
         "value": world * args.steps * B / elapsed,
@@ -239,6 +273,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
+        "steady_ms_per_step": steady_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -248,7 +283,9 @@ def main():
                                f"per step share one batched encoder call (2x{B} frames), then NN + RANSAC per pair",
                    "encoder": args.model, "feature_dim": args.n_out, "points_per_frame": int(n_pts),
                    "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
-                   "pairs_per_step": B, "streams_per_gpu": nstreams, "sharding": f"{world} ranks x independent pairs"},
+                   "pairs_per_step": B, "streams_per_gpu": nstreams, "sharding": f"{world} ranks x independent pairs",
+                   "pool_pairs": npool, "ransac_valid_hypotheses_last_pair": int(info["n_valid"]),
+                   "per_rank_pairs_per_s": [float(r[0] / r[1]) for r in stats.tolist()]},
     }
 
     if rank == 0 and not args.no_roofline:
