@@ -69,8 +69,9 @@ __device__ inline int apr_wave_incl_scan(int x) {
 #define APR_AXIS_BIAS (1 << 17)
 #define APR_AXIS_RANGE (1 << 18)
 
+// batch index 1023 is reserved: (1023, max, max, max) would pack to APR_KEY_EMPTY
 __host__ __device__ static inline bool apr_key_in_range(int b, int x, int y, int z) {
-  return (unsigned)b < 1024u && (unsigned)(x + APR_AXIS_BIAS) < (unsigned)APR_AXIS_RANGE &&
+  return (unsigned)b < 1023u && (unsigned)(x + APR_AXIS_BIAS) < (unsigned)APR_AXIS_RANGE &&
          (unsigned)(y + APR_AXIS_BIAS) < (unsigned)APR_AXIS_RANGE &&
          (unsigned)(z + APR_AXIS_BIAS) < (unsigned)APR_AXIS_RANGE;
 }

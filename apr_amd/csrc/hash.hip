@@ -296,7 +296,7 @@ APR_API size_t apr_map_scratch_bytes(int64_t n) {
 APR_API int apr_voxelize(const float* xyz, int64_t n, float voxel_size, int32_t batch,
                          int32_t* coords, void* stream) {
   APR_CHECK_ARG(n >= 0 && voxel_size > 0.f, "apr_voxelize: bad n=%lld or voxel_size", (long long)n);
-  APR_CHECK_ARG(batch >= 0 && batch < 1024, "apr_voxelize: batch index %d outside [0,1024)", batch);
+  APR_CHECK_ARG(batch >= 0 && batch < 1023, "apr_voxelize: batch index %d outside [0,1023)", batch);
   if (n == 0) return APR_OK;
   hipLaunchKernelGGL(k_voxelize, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                      xyz, n, voxel_size, batch, (int4*)coords);
@@ -356,7 +356,7 @@ APR_API int apr_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t 
 
 APR_API int apr_voxelize_segments(const float* xyz, int64_t n, float voxel_size, const int64_t* offsets, int32_t nseg,
                                   int32_t* coords, void* stream) {
-  APR_CHECK_ARG(n >= 0 && voxel_size > 0.f && nseg >= 1 && nseg <= 1024 && offsets, "apr_voxelize_segments: bad arguments");
+  APR_CHECK_ARG(n >= 0 && voxel_size > 0.f && nseg >= 1 && nseg <= 1023 && offsets, "apr_voxelize_segments: bad arguments");
   if (n == 0) return APR_OK;
   hipLaunchKernelGGL(k_voxelize_segments, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, xyz, n,
                      voxel_size, (const long long*)offsets, nseg, (int4*)coords);

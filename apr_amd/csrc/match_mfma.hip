@@ -580,15 +580,22 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
 
 }  // namespace
 
+// An upper bound of what run_fast carves, MONOTONE in n0 and in n1: a caller that sizes one buffer for a batch of
+// pairs from the largest n0 and the largest n1 (apr_match_pose_batch) must be covered for every pair of the batch,
+// and the exact need is not monotone (the refine grid trades query blocks against target chunks: a smaller n0 can
+// mean more chunks).  Bounds: qblocks * nchunk <= 768 + qblocks (nchunk <= want = ceil(768 / qblocks));
+// nchunk * chunk <= 2 * n1 + 320 (chunk <= max(256, n1 / want + 64)).
 APR_API size_t apr_feature_nn_fast_scratch_bytes(int64_t n0, int64_t n1, int32_t c) {
   if (n0 < 0 || n1 < 0 || c <= 0) return 0;
-  int64_t qblocks, chunk, nchunk;
-  nn_grid(n0 > 0 ? n0 : 1, n1 > 0 ? n1 : 1, &qblocks, &chunk, &nchunk);
-  const size_t nwaves = (size_t)(qblocks * nchunk * 4);
+  if (n0 < 1) n0 = 1;
+  if (n1 < 1) n1 = 1;
+  const size_t qblocks = (size_t)cdiv64(n0, 256);
+  const size_t nwaves = 4 * (768 + qblocks);
+  const size_t nflag = qblocks * 4 * ((2 * (size_t)n1 + 320) / 16 + 1);
+  const size_t nlist = nflag > kDenseListCap ? (size_t)kDenseListCap : nflag;
   return 2 * al256((size_t)n0 * c * 2) + 2 * al256((size_t)n1 * c * 2) + al256((size_t)n0 * 16) + al256((size_t)n1 * 16) +
          al256((size_t)n0 * 4) + 256 + al256(nwaves * 4) + al256(nwaves * kCandWave * 8) +
-         al256((size_t)shared_capacity(n0) * 8) + al256((size_t)(qblocks * 4) * (size_t)nchunk * (size_t)(chunk / 16) + 64) + dense_list_bytes(qblocks, nchunk, chunk) +
-         512;
+         al256((size_t)shared_capacity(n0) * 8) + al256(nflag + 64) + al256(nlist * 4 + 64) + 512;
 }
 
 APR_API int apr_feature_nn_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,

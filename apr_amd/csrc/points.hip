@@ -337,8 +337,65 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
   }
   if (MODE == 2 && lane == 0) counts[qi] = nhit;
   if (nhit > kHitCap) {
-    if (lane == 0) *status = 1;
-    nhit = kHitCap;
+    // More neighbours than the rank buffer holds (a scan taken a few centimetres from a wall).  Only the `width`
+    // nearest are wanted: when they fit, select them exactly — bisection on the bit pattern of d2 (non-negative
+    // floats order like their bits) for the smallest T with at least `width` candidates at d2 <= T, all candidates
+    // below T plus the smallest-index ones AT T (a second bisection) make up exactly `width` entries — and rank
+    // those.  A few dozen extra sweeps over the candidates, for the rare query that needs them.
+    if (width > kHitCap) {
+      if (lane == 0) *status = 1;       // cannot rank more columns than the buffer holds
+      nhit = kHitCap;
+    } else {
+      auto sweep = [&](auto&& f) {       // f(d2, index) for every in-radius candidate of this query
+        for (int base = 0; base < total; base += 64) {
+          const int t = base + lane;
+          bool hit = false;
+          float d2 = 0.f;
+          int sidx = -1;
+          if (t < total) {
+            int L = 0;
+            while (s_incl[wave][L] <= t) ++L;
+            const int before = L ? s_incl[wave][L - 1] : 0;
+            sidx = g.sorted[s_lo[wave][L] + (t - before)];
+            const float dx = __fsub_rn(qx, s[3 * (int64_t)sidx]), dy = __fsub_rn(qy, s[3 * (int64_t)sidx + 1]),
+                        dz = __fsub_rn(qz, s[3 * (int64_t)sidx + 2]);
+            d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            hit = d2 < r2;
+          }
+          f(hit, d2, sidx);
+        }
+      };
+      unsigned lo = 0u, hi = __float_as_uint(r2);
+      while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        sweep([&](bool hit, float d2, int) { c += __popcll(__ballot(hit && __float_as_uint(d2) <= mid)); });
+        if (c >= width) hi = mid; else lo = mid + 1;
+      }
+      int below = 0;
+      sweep([&](bool hit, float d2, int) { below += __popcll(__ballot(hit && __float_as_uint(d2) < lo)); });
+      const int need = width - below;    // >= 1 entries to take at d2 == T, smallest indices first
+      int ilo = 0, ihi = 0x7fffffff;
+      while (ilo < ihi) {
+        const int mid = ilo + ((ihi - ilo) >> 1);
+        int c = 0;
+        sweep([&](bool hit, float d2, int id) { c += __popcll(__ballot(hit && __float_as_uint(d2) == lo && id <= mid)); });
+        if (c >= need) ihi = mid; else ilo = mid + 1;
+      }
+      int got = 0;
+      sweep([&](bool hit, float d2, int id) {
+        const unsigned bits = __float_as_uint(d2);
+        const bool take = hit && (bits < lo || (bits == lo && id <= ilo));
+        const unsigned long long m = __ballot(take);
+        if (take) {
+          const int pos = got + __popcll(m & ((1ull << lane) - 1ull));
+          s_d[wave][pos] = d2;
+          s_i[wave][pos] = id;
+        }
+        got += __popcll(m);
+      });
+      nhit = got;                         // == width
+    }
   }
   // rank sort by (d2, index); wave-private LDS rows, so no barrier is needed
   for (int e = lane; e < nhit; e += 64) {

@@ -15,6 +15,8 @@
 //      D^T form) and stores prod[p, :] with 16-B stores;
 //   2. k_ws_reduce: out[j,:] = act((sum_k prod[pair_id[j,k],:]) * scale + shift + residual) in fixed k order.
 // No float atomics, bitwise reproducible.  Extra HBM traffic: the product rows, written and read once.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -352,13 +354,21 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* count
   const int64_t need = cdiv64(n_out * (int64_t)K, 64) + K;
   if (gx > need) gx = need;
   const unsigned units = (unsigned)gx;
-  static bool s_attr = false;
-  if (!s_attr) {
-    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    s_attr = true;
+  // this entry point is called from several host threads (one per stream): the 128 KB dynamic-LDS opt-in is set
+  // once per device, under a lock
+  {
+    static std::mutex s_mu;
+    static bool s_attr[64] = {};
+    int dev = 0;
+    APR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(s_mu);
+    if (dev >= 0 && dev < 64 && !s_attr[dev]) {
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      s_attr[dev] = true;
+    }
   }
   auto kern = cin == 64 ? k_ws_gemm<1> : cin == 128 ? k_ws_gemm<2> : cin == 256 ? k_ws_gemm<4> : k_ws_gemm<0>;
   hipLaunchKernelGGL(kern, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,

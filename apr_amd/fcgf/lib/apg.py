@@ -134,19 +134,28 @@ class GenerativeMLP_54(GenerativeMLP):
     CHANNELS = [None, 32, 16, None]
 
 
+def npr_regulariser(generated, reg_type='L2', alpha=0.1):
+    """Length penalty on the generated offsets [N, 3*ratio] (complement_trainer.py:432-440)."""
+    sq = (generated.reshape(-1, 3) ** 2).sum(-1)
+    if reg_type == 'L2':
+        return sq.mean()
+    if reg_type == 'RepelL2':
+        return sq.mean() + (1.0 / (sq + alpha)).mean()
+    if reg_type == 'RepelL1':
+        return ((torch.pow(sq + 1e-5, 0.25) - 1) ** 2).mean()
+    raise ValueError(reg_type)
+
+
+def npr_points(generated, enc_coords, voxel_size, ratio):
+    """Generated offsets + their voxel's corner -> [N*ratio, 3] points (complement_trainer.py:441-442)."""
+    return (generated + voxel_size * enc_coords.to(generated.dtype).repeat(1, ratio)).reshape(-1, 3)
+
+
 @torch.no_grad()
 def npr_reconstruction_loss(generator, enc_feats, enc_coords, pcd_nghb, voxel_size, ratio, reg_strength=0.01,
                             reg_type='L2', alpha=0.1):
     """chamfer(generated + voxel centres, APG cloud) + reg * regulariser for one cloud (complement_trainer.py:424-448)."""
     generated = generator(enc_feats) * voxel_size                                       # [N, 3*ratio]
-    sq = (generated.reshape(-1, 3) ** 2).sum(-1)
-    if reg_type == 'L2':
-        reg = sq.mean()
-    elif reg_type == 'RepelL2':
-        reg = sq.mean() + (1.0 / (sq + alpha)).mean()
-    elif reg_type == 'RepelL1':
-        reg = ((torch.pow(sq + 1e-5, 0.25) - 1) ** 2).mean()
-    else:
-        raise ValueError(reg_type)
-    mod = (generated + voxel_size * enc_coords.to(generated.dtype).repeat(1, ratio)).reshape(-1, 3)
+    reg = npr_regulariser(generated, reg_type, alpha)
+    mod = npr_points(generated, enc_coords, voxel_size, ratio)
     return chamfer_distance(mod, pcd_nghb).float() + reg * reg_strength

@@ -7,13 +7,15 @@ fused HIP arg-min (`lib.eval.find_nn_gpu`).
 import torch
 
 
+def _rigid(T, pts):
+    return pts @ T[:3, :3].t() + T[:3, 3]
+
+
 def corr_dist(est, gth, xyz0, xyz1, weight=None, max_dist=1):
-    xyz0_est = xyz0 @ est[:3, :3].t() + est[:3, 3]
-    xyz0_gth = xyz0 @ gth[:3, :3].t() + gth[:3, 3]
-    dists = torch.clamp(torch.sqrt(((xyz0_est - xyz0_gth).pow(2)).sum(1)), max=max_dist)
-    if weight is not None:
-        dists = weight * dists
-    return dists.mean()
+    """Mean (optionally weighted) distance, capped at `max_dist`, between the source points moved by the estimated
+    and by the ground-truth transform (FCGF_APR/lib/metrics.py:13-19; `xyz1` is unused there too)."""
+    gap = torch.linalg.vector_norm(_rigid(est, xyz0) - _rigid(gth, xyz0), dim=1).clamp(max=max_dist)
+    return (gap if weight is None else weight * gap).mean()
 
 
 def pdist(A, B, dist_type='L2'):

@@ -55,8 +55,8 @@ class PairRegistration:
         in the key; rows come out in first-occurrence order = frame order), that map is adopted as the stride-1
         coordinate map, the three coarser maps are chained behind it with device-side row counts, and a single
         host sync fetches every size (12 + 4 builds and 2 syncs per step become 4 builds and 1 sync)."""
-        if len(clouds) > 1024:
-            raise ValueError("at most 1024 frames per batch (10-bit batch index in the voxel key)")
+        if len(clouds) > 1023:
+            raise ValueError("at most 1023 frames per batch (10-bit batch index in the voxel key; 1023 is reserved for the empty-slot key)")
         dev = clouds[0].device
         npts = [int(c.shape[0]) for c in clouds]
         offs = [0]

@@ -142,7 +142,7 @@ def _apply_finalize(pend, host):
     for i, m in enumerate(pend):
         if host[2 * i + 1] != 0:
             raise _lib.AprHipError(
-                "coordinate outside the packed voxel-key range (|xyz| < 2^17 voxels, batch < 1024)")
+                "coordinate outside the packed voxel-key range (|xyz| < 2^17 voxels, batch < 1023)")
         m.n = int(host[2 * i])
         m.coords = m.coords[: m.n]
         if m.first is not None:

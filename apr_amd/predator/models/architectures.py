@@ -16,61 +16,72 @@ from .blocks import block_decider
 from .gcn import GCN, _Packed, conv1x1
 
 
+def _is_level_change(name):
+    return 'pool' in name or 'strided' in name
+
+
+def plan_architecture(config):
+    """Walk `config.architecture` once -> (encoder rows, decoder rows, skip block ids, skip widths, bottleneck width).
+
+    A row is (block name, radius, in width, out width, pyramid level) = the arguments of `block_decider`.  The schedule
+    is the reference's (Predator_APR/models/architectures.py:11-123): the radius starts at first_subsampling_dl *
+    conv_radius and doubles at every pooling / strided block together with the width, a 'simple' block hands on half
+    of its width, the encoder stops at the first 'upsample' block; the decoder then undoes the doubling level by level
+    and a block that FOLLOWS an upsampling one takes that level's skip features as extra input channels."""
+    names = list(config.architecture)
+    first_up = next((i for i, n in enumerate(names) if 'upsample' in n), len(names))
+    radius = config.first_subsampling_dl * config.conv_radius
+    width_in, width_out, level = config.in_feats_dim, config.first_feats_dim, 0
+    enc, skips, skip_widths = [], [], []
+    for i, name in enumerate(names[:first_up + 1]):
+        if 'equivariant' in name and width_out % 3 != 0:
+            raise ValueError('Equivariant block but features dimension is not a factor of 3')
+        if _is_level_change(name) or 'upsample' in name or 'global' in name:
+            skips.append(i)
+            skip_widths.append(width_in)
+        if i == first_up:
+            break
+        enc.append((name, radius, width_in, width_out, level))
+        width_in = width_out // 2 if 'simple' in name else width_out
+        if _is_level_change(name):
+            level, radius, width_out = level + 1, radius * 2, width_out * 2
+    bottleneck = width_in
+    # decoder: its first block is the parameter-free upsampling one, so the width handed to it (the encoder's last,
+    # as in the reference) does not matter; from there on every block emits the conditioned width
+    width_out = config.gnn_feats_dim + (2 if config.add_cross_score else 1)
+    dec, concats = [], []
+    tail = names[first_up:]
+    for j, name in enumerate(tail):
+        if j > 0 and 'upsample' in tail[j - 1]:
+            width_in += skip_widths[level]
+            concats.append(j)
+        dec.append((name, radius, width_in, width_out, level))
+        width_in = width_out
+        if 'upsample' in name:
+            level, radius, width_out = level - 1, radius * 0.5, width_out // 2
+    return enc, dec, skips, skip_widths, concats, bottleneck
+
+
 class KPFCNN(nn.Module):
     def __init__(self, config):
         super().__init__()
-        layer = 0
-        r = config.first_subsampling_dl * config.conv_radius
-        in_dim = config.in_feats_dim
-        out_dim = config.first_feats_dim
+        enc, dec, skips, skip_widths, concats, bottleneck = plan_architecture(config)
         self.final_feats_dim = config.final_feats_dim
         self.K = config.num_kernel_points
         self.epsilon = torch.nn.Parameter(torch.tensor(-5.0))
         self.condition = config.condition_feature
         self.add_cross_overlap = config.add_cross_score
-
-        self.encoder_blocks = nn.ModuleList()
-        self.encoder_skip_dims = []
-        self.encoder_skips = []
-        for block_i, block in enumerate(config.architecture):
-            if ('equivariant' in block) and (not out_dim % 3 == 0):
-                raise ValueError('Equivariant block but features dimension is not a factor of 3')
-            if np.any([tmp in block for tmp in ['pool', 'strided', 'upsample', 'global']]):
-                self.encoder_skips.append(block_i)
-                self.encoder_skip_dims.append(in_dim)
-            if 'upsample' in block:
-                break
-            self.encoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
-            in_dim = out_dim // 2 if 'simple' in block else out_dim
-            if 'pool' in block or 'strided' in block:
-                layer += 1
-                r *= 2
-                out_dim *= 2
-
-        gnn_feats_dim = config.gnn_feats_dim
-        self.bottle = nn.Conv1d(in_dim, gnn_feats_dim, kernel_size=1, bias=True)
-        self.gnn = GCN(config.num_head, gnn_feats_dim, config.dgcnn_k, config.nets)
-        self.proj_gnn = nn.Conv1d(gnn_feats_dim, gnn_feats_dim, kernel_size=1, bias=True)
-        self.proj_score = nn.Conv1d(gnn_feats_dim, 1, kernel_size=1, bias=True)
-
-        out_dim = gnn_feats_dim + 2 if self.add_cross_overlap else gnn_feats_dim + 1
-        self.decoder_blocks = nn.ModuleList()
-        self.decoder_concats = []
-        start_i = 0
-        for block_i, block in enumerate(config.architecture):
-            if 'upsample' in block:
-                start_i = block_i
-                break
-        for block_i, block in enumerate(config.architecture[start_i:]):
-            if block_i > 0 and 'upsample' in config.architecture[start_i + block_i - 1]:
-                in_dim += self.encoder_skip_dims[layer]
-                self.decoder_concats.append(block_i)
-            self.decoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
-            in_dim = out_dim
-            if 'upsample' in block:
-                layer -= 1
-                r *= 0.5
-                out_dim = out_dim // 2
+        # attribute order = the reference's, so that module registration (and with it RNG consumption at
+        # construction and state_dict order) is the same
+        self.encoder_blocks = nn.ModuleList(block_decider(*row, config) for row in enc)
+        self.encoder_skip_dims, self.encoder_skips = skip_widths, skips
+        g = config.gnn_feats_dim
+        self.bottle = nn.Conv1d(bottleneck, g, kernel_size=1, bias=True)
+        self.gnn = GCN(config.num_head, g, config.dgcnn_k, config.nets)
+        self.proj_gnn = nn.Conv1d(g, g, kernel_size=1, bias=True)
+        self.proj_score = nn.Conv1d(g, 1, kernel_size=1, bias=True)
+        self.decoder_blocks = nn.ModuleList(block_decider(*row, config) for row in dec)
+        self.decoder_concats = concats
         self._c = [_Packed(), _Packed(), _Packed()]
 
     def regular_score(self, score):

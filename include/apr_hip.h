@@ -87,7 +87,7 @@ int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_dev, int
 int apr_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t, void* stream);
 
 /* apr_voxelize for the concatenated frames of a batch: point i gets batch index b with offsets[b] <= i < offsets[b+1]
- * (offsets i64[nseg+1] on the device, nseg <= 1024). */
+ * (offsets i64[nseg+1] on the device, nseg <= 1023: batch index 1023 is reserved, its largest key is the empty-slot sentinel). */
 int apr_voxelize_segments(const float* xyz, int64_t n, float voxel_size, const int64_t* offsets, int32_t nseg,
                           int32_t* coords, void* stream);
 

@@ -1,0 +1,142 @@
+"""Round-2 closes: calibrate_neighbors, hit ratio, subsampled find_corr, corr_dist, the reserved batch index,
+and the library driven from several host threads / streams at once."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from apr_amd import ops, synth
+from apr_amd._lib import AprHipError
+from apr_amd.fcgf.lib import eval as EV
+from apr_amd.fcgf.lib import metrics as MT
+from apr_amd.predator.configs.models import kitti_config
+from apr_amd.predator.datasets.dataloader import calibrate_neighbors, collate_fn_descriptor
+from oracle import kpfcnn_oracle as KO
+from tests.helpers import model_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_calibrate_neighbors_matches_reference_rule(dev):
+    """Predator_APR/datasets/dataloader.py:200-232 on a 10-pair synthetic dataset: histogram of neighbour counts per
+    layer from an UN-capped collate, caps = number of histogram bins below the 80th percentile.  The expected caps come
+    from the reference's own C++ neighbour search (oracle/_ref) run through the same rule."""
+    cfg = kitti_config()
+    data = []
+    for s in range(10):
+        a, b, _ = synth.make_pair(100 + s, n_beams=16, n_azimuth=400)
+        data.append((a, b, np.ones((len(a), 1), np.float32), np.ones((len(b), 1), np.float32)))
+    got = calibrate_neighbors(data, cfg, collate_fn=collate_fn_descriptor, keep_ratio=0.8, samples_threshold=2000)
+    hist_n = int(np.ceil(4 / 3 * np.pi * (cfg.deform_radius + 1) ** 3))
+    hists = np.zeros((cfg.num_layers, hist_n), np.int64)
+    for a, b, _, _ in data:
+        ref = KO.collate(a, b, cfg, [hist_n] * 5)
+        for l, m in enumerate(ref["neighbors"]):
+            c = (m < m.shape[0]).sum(1).numpy()
+            hists[l] += np.bincount(c, minlength=hist_n)[:hist_n]
+        if hists.sum(1).min() > 2000:
+            break
+    cum = np.cumsum(hists.T, axis=0)
+    want = (cum < 0.8 * cum[hist_n - 1]).sum(0)
+    assert got.shape == want.shape == (cfg.num_layers,)
+    # levels >= 2 are built from barycentres summed in a different row order (last-bit differences): +-1 bin
+    assert np.all(np.abs(got.astype(np.int64) - want) <= 1), (got, want)
+    assert np.array_equal(got[:2], want[:2])
+
+
+def test_hit_ratio_and_corr_dist(dev):
+    rng = np.random.default_rng(3)
+    xyz0 = rng.uniform(-20, 20, (4000, 3)).astype(np.float32)
+    a = np.deg2rad(7.0)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+    T[:3, 3] = [1.0, -2.0, 0.5]
+    xyz1 = xyz0 @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.06, xyz0.shape).astype(np.float32)
+    # FCGF_APR/lib/trainer.py:392-395, restated in numpy
+    d = np.sqrt((((xyz0 @ T[:3, :3].T + T[:3, 3]) - xyz1) ** 2).sum(1) + 1e-6)
+    want = float((d < 0.1).mean())
+    got = EV.evaluate_hit_ratio(torch.from_numpy(xyz0).to(dev), torch.from_numpy(xyz1).to(dev), torch.from_numpy(T), 0.1)
+    assert abs(got - want) < 1e-3
+    # FCGF_APR/lib/metrics.py:13-19
+    est = torch.from_numpy(T).clone()
+    est[:3, 3] += torch.tensor([0.3, 0.0, -0.2])
+    x0 = torch.from_numpy(xyz0)
+    w = torch.from_numpy(rng.random(len(xyz0)).astype(np.float32))
+    ref = torch.clamp(torch.sqrt((((x0 @ est[:3, :3].t() + est[:3, 3]) - (x0 @ torch.from_numpy(T)[:3, :3].t()
+                                  + torch.from_numpy(T)[:3, 3])) ** 2).sum(1)), max=0.25)
+    assert torch.allclose(MT.corr_dist(est, torch.from_numpy(T), x0, None, max_dist=0.25), ref.mean(), atol=1e-6)
+    assert torch.allclose(MT.corr_dist(est, torch.from_numpy(T), x0, None, weight=w, max_dist=0.25), (w * ref).mean(),
+                          atol=1e-6)
+
+
+def test_find_corr_subsample_follows_reference_draws(dev):
+    """scripts/test_apr.py:43-57 with subsample_size=5000: the same two np.random.choice draws, NN on the subsample."""
+    rng = np.random.default_rng(5)
+    F0 = torch.from_numpy(rng.standard_normal((7000, 32)).astype(np.float32)).to(dev)
+    F1 = torch.from_numpy(rng.standard_normal((6500, 32)).astype(np.float32)).to(dev)
+    xyz0 = rng.uniform(-5, 5, (7000, 3)).astype(np.float32)
+    xyz1 = rng.uniform(-5, 5, (6500, 3)).astype(np.float32)
+    np.random.seed(11)
+    a0, a1 = EV.find_corr(xyz0, xyz1, F0, F1, subsample_size=5000)
+    np.random.seed(11)
+    i0 = np.random.choice(7000, 5000, replace=False)
+    i1 = np.random.choice(6500, 5000, replace=False)
+    d = torch.cdist(F0[torch.as_tensor(i0, device=dev)].double(), F1[torch.as_tensor(i1, device=dev)].double())
+    nn = d.argmin(1).cpu().numpy()
+    assert a0.shape == (5000, 3) and np.array_equal(a0, xyz0[i0]) and np.array_equal(a1, xyz1[i1[nn]])
+    # no subsampling when the clouds are smaller than the cap (or the cap is -1)
+    b0, b1 = EV.find_corr(xyz0[:300], xyz1[:400], F0[:300], F1[:400], subsample_size=5000)
+    assert b0.shape == (300, 3) and b1.shape == (300, 3)
+
+
+def test_batch_index_1023_is_reserved(dev):
+    """(1023, max, max, max) would pack to the empty-slot key: the library rejects batch index 1023 instead of
+    silently corrupting the table."""
+    xyz = torch.tensor([[39321.3, 39321.3, 39321.3], [0.1, 0.2, 0.3]], device=dev)   # 131071 voxels at 0.3 m
+    c = ops.voxelize(xyz, 0.3, 1022)
+    m = ops.build_map(c)
+    ops.finalize_maps([m])
+    assert m.n == 2
+    with pytest.raises(AprHipError):
+        ops.voxelize(xyz, 0.3, 1023)
+    coords = torch.tensor([[1023, 131071, 131071, 131071], [1023, 0, 0, 0]], dtype=torch.int32, device=dev)
+    with pytest.raises(AprHipError):
+        ops.finalize_maps([ops.build_map(coords)])
+
+
+def test_three_threads_three_streams_match_single_stream(dev):
+    """The bench drives register_batch from 3 host threads on 3 HIP streams: poses and features must be bit-identical
+    to the single-stream result (also exercises the per-device one-time kernel attribute set-up under contention)."""
+    from apr_amd.fcgf.pipeline import PairRegistration
+    _, hm = model_pair("ResUNetBN2C")
+    hm = hm.eval()
+    pipe = PairRegistration(hm, 0.3, ransac_iters=200000)
+    pairs = []
+    for s in range(4):
+        a, b, _ = synth.make_pair(40 + s, n_beams=32, n_azimuth=900)
+        pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    batches = [[pairs[0], pairs[1]], [pairs[2], pairs[3]], [pairs[1], pairs[2]]]
+    want = [pipe.register_batch(b, seeds=[7, 8]) for b in batches]
+    torch.cuda.synchronize()
+    got = [None] * 3
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    errs = []
+
+    def work(w):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[w]):
+                for _ in range(3):
+                    got[w] = pipe.register_batch(batches[w], seeds=[7, 8])
+                streams[w].synchronize()
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(w,)) for w in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for w in range(3):
+        for (Ta, ia), (Tb, ib) in zip(want[w], got[w]):
+            assert np.array_equal(Ta, Tb) and ia == ib

@@ -89,3 +89,17 @@ def test_rte_rre():
     T = np.eye(4); T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]; T[:3, 3] = [1, 2, 2]
     rte, rre = rte_rre(T, np.eye(4))
     assert abs(rte - 3.0) < 1e-12 and abs(rre - 3.0) < 1e-9
+
+
+def test_nn_scratch_size_is_monotone(lib):
+    """apr_match_pose_batch sizes ONE feature-NN scratch for a batch from (max n0, max n1): the size function must
+    not shrink when either count grows (it once did: a batch of unequal pairs failed with 'scratch too small')."""
+    for c in (32, 64, 128):
+        for n0 in (300, 5000, 14000, 41000):
+            col = [lib.apr_feature_nn_fast_scratch_bytes(n0, n1, c) for n1 in range(200, 60000, 1499)]
+            assert col == sorted(col)
+        for n1 in (300, 5000, 14000, 41000):
+            row = [lib.apr_feature_nn_fast_scratch_bytes(n0, n1, c) for n0 in range(200, 60000, 1499)]
+            assert row == sorted(row)
+    big = lib.apr_match_pose_batch_scratch_bytes(3, 9000, 9500, 32, 200000)
+    assert big > lib.apr_feature_nn_fast_scratch_bytes(6000, 9500, 32)

@@ -120,3 +120,35 @@ def test_knn_matches_dense_topk(dev):
     assert got.shape == (700, 10)
     assert (got == ref).float().mean() > 0.999
     assert torch.equal(got.sort(1)[0], ref.sort(1)[0]) or (got.sort(1)[0] == ref.sort(1)[0]).float().mean() > 0.999
+
+
+def test_radius_neighbors_beyond_the_rank_buffer(dev):
+    """A clump with more than 1024 points inside the radius (a scan taken next to a wall): the `limit` nearest are
+    still selected exactly (bisection on the distance, ties by index), like the reference's nanoflann search followed
+    by the dataloader's truncation (Predator_APR/cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-333,
+    datasets/dataloader.py:66-68); duplicates of one point make a run of exact ties."""
+    rng = np.random.default_rng(9)
+    clump = rng.normal(0, 0.25, (2600, 3)).astype(np.float32)
+    clump[100:160] = clump[100]                                    # 60 exact duplicates: ties at one distance
+    far = rng.uniform(-30, 30, (4000, 3)).astype(np.float32)
+    pts = np.concatenate([clump, far]).astype(np.float32)
+    lens = np.array([len(pts)], np.int32)
+    t = torch.from_numpy(pts).to(dev)
+    r, lim = 1.0, 48
+    got = point_ops.radius_neighbors(t, t, lens, lens, r, limit=lim).cpu().numpy()
+    ref = REF.batch_query(pts, pts, lens, lens, radius=r)[:, :lim]
+    assert got.shape == ref.shape == (len(pts), lim)
+    d_ref = ((pts[np.minimum(ref, len(pts) - 1)] - pts[:, None]) ** 2).sum(-1)
+    d_got = ((pts[np.minimum(got, len(pts) - 1)] - pts[:, None]) ** 2).sum(-1)
+    pad_ref, pad_got = ref == len(pts), got == len(pts)
+    assert np.array_equal(pad_ref, pad_got)
+    assert np.allclose(np.where(pad_ref, 0, d_ref), np.where(pad_got, 0, d_got), rtol=1e-5, atol=1e-7)
+    assert (got == ref).mean() > 0.97                              # positions differ only inside runs of equal distance
+    # the asynchronous table (collate path) takes the same route
+    flags = torch.empty(2, dtype=torch.int32, device=dev)
+    tab = point_ops.finish_radius_tables([point_ops.radius_neighbors_async(t, t, lens, lens, r, lim, flags)],
+                                         flags.view(1, 2))[0]
+    assert torch.equal(tab.cpu(), torch.from_numpy(got))
+    # without a limit the full width cannot be ranked: loud error, not a truncated table
+    with pytest.raises(Exception):
+        point_ops.radius_neighbors(t, t, lens, lens, r)
