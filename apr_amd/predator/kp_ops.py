@@ -7,6 +7,22 @@ from .. import _lib, ops
 from .._lib import check, ptr, stream
 
 
+PROFILE = None   # set to a list to collect (N, H, cin, cout, K, start event, end event) per KPConv layer
+
+
+def kpconv_profile_summary(records):
+    """Algorithmic bytes / FLOP (bytes = 4*N*H*(3+cin) + 8*N*H + 4*N*cout; FLOP = 2*N*H*K*(3+cin) +
+    2*N*K*cin*cout) and summed HIP-event time of the recorded KPConv layers."""
+    torch.cuda.synchronize()
+    tot = dict(launches=0, bytes=0.0, flops=0.0, ms=0.0)
+    for (n, h, cin, cout, k, e0, e1) in records:
+        tot["launches"] += 1
+        tot["bytes"] += 4.0 * n * h * (3 + cin) + 8.0 * n * h + 4.0 * n * cout
+        tot["flops"] += 2.0 * n * h * k * (3 + cin) + 2.0 * n * k * cin * cout
+        tot["ms"] += e0.elapsed_time(e1)
+    return tot
+
+
 def tracking(*tensors):
     """Autograd is recording and one of the tensors / parameters takes part: the modules then run differentiable torch
     ops (the reference's own formulation) instead of the forward-only HIP kernels."""

@@ -70,8 +70,16 @@ class KPConv(nn.Module):
     def forward(self, q_pts, s_pts, neighb_inds, x):
         if kp_ops.tracking(x, self.weights):
             return self._forward_autograd(q_pts, s_pts, neighb_inds, x)
+        prof = kp_ops.PROFILE
+        if prof is not None:      # bench.py roofline leg: HIP events on the launch stream around the layer's kernels
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         wf = kp_ops.kpconv_weighted(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.KP_extent)
-        return kp_ops.linear(wf, self._weight())
+        out = kp_ops.linear(wf, self._weight())
+        if prof is not None:
+            e1.record()
+            prof.append((q_pts.shape[0], neighb_inds.shape[1], self.in_channels, self.out_channels, self.K, e0, e1))
+        return out
 
     def _forward_autograd(self, q_pts, s_pts, inds, x):
         """blocks.py:229-374, rigid / linear influence / sum aggregation, with plain torch ops."""

@@ -45,6 +45,9 @@ def parse():
                          "cannot fill 256 CUs alone, so independent pairs overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the extra workloads block (Predator config 3, FatBN-128, config 5), measured after the "
+                         "headline loop")
     ap.add_argument("--pairs-per-step", type=int, default=1,
                     help="independent pairs batched into one encoder call per step (value counts pairs, not steps)")
     ap.set_defaults(pairs_per_step=6)
@@ -119,6 +122,138 @@ def cpu_baseline(state_dict, name, n_out, pairs, ransac_iters):
             "sample": (f"{n} pairs of the timed workload: voxelise+encode 2 frames {t_enc / n:.2f}s, feature NN "
                        f"{t_nn / n:.2f}s, RANSAC {iters} of {ransac_iters} iterations {t_rs / n:.2f}s scaled "
                        f"x{scale:.0f} (per pair; {t_enc + t_nn + t_rs:.1f}s of CPU work in all)")}
+
+PREDATOR_LIMITS = [58, 59, 58, 57]     # calibrate_neighbors (80th percentile) on this generator at full size
+
+
+def conv_roofline(s):
+    """Roofline entry of a SpconvProfile summary (all MFMA conv layers): the tighter of the two roofs."""
+    t_hbm = s["bytes"] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = s["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    sec = s["ms"] * 1e-3
+    gbs, tf = s["bytes"] / sec / 1e9, s["flops"] / sec / 1e12
+    if t_mfma > t_hbm:
+        r = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": tf / MFMA_F32_PEAK_TFLOPS}
+    else:
+        r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    r.update(traffic=None, hbm_gbs=gbs, mfma_tflops=tf, launches=s["launches"],
+             avg_launch_us=1000.0 * s["ms"] / max(s["launches"], 1))
+    return r
+
+
+def extra_workloads(dev, log):
+    """The other single-GPU configurations of BASELINE.json, measured AFTER the headline loop (they do not touch it):
+    config 3 (Predator_APR pair), APR's own encoder (ResUNetFatBN, 128 features) through the headline pipeline, and
+    config 5 (distant pair: APG aggregation + FatBN encode + NPR loss).  Each with the roofline of its dominant
+    kernel from HIP events on the launch stream."""
+    from apr_amd import MinkowskiEngine as ME
+    from apr_amd import ops, synth
+    from apr_amd.fcgf.lib import apg
+    from apr_amd.fcgf.pipeline import PairRegistration
+    from apr_amd.predator import kp_ops
+    from apr_amd.predator.configs.models import kitti_config
+    from apr_amd.predator.models.architectures import KPFCNN
+    from apr_amd.predator.pipeline import PredatorRegistration
+    out = {}
+
+    def sync():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    a, b, _ = synth.make_pair(0)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+
+    # ---- config 3: Predator_APR pair, one pair at a time (grid subsample -> collate -> KPFCNN -> sampling -> RANSAC)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    cfg = kitti_config()
+    pred = PredatorRegistration(KPFCNN(cfg).to(dev).eval(), cfg, PREDATOR_LIMITS)
+    for i in range(3):
+        pred(ta, tb, seed=i)
+    reps = 10
+    t0 = sync()
+    for i in range(reps):
+        T, info = pred(ta, tb, seed=i)
+    t1 = sync()
+    kp_ops.PROFILE = []
+    src, tgt, feats, ov, sal = pred.encode(ta, tb)
+    ks = kp_ops.kpconv_profile_summary(kp_ops.PROFILE)
+    kp_ops.PROFILE = None
+    kr = conv_roofline(ks)
+    kr["kernel"] = ("KPConv layer = k_row_sums + k_kpconv_weighted_mfma (kernel-point correlation) + k_dense_gemm "
+                    f"([N, 15*cin] x [15*cin, cout]); {ks['launches']} layers of one KPFCNN forward")
+    out["predator_config3"] = {
+        "workload": "Predator_APR KPConv encoder + overlap attention + score sampling + RANSAC(50000, 1000) on one "
+                    "2 x 118 k-point pair, one pair at a time",
+        "value": reps / (t1 - t0), "unit": "pairs/s", "ms_per_pair": 1e3 * (t1 - t0) / reps,
+        "points_after_0.3m_grid": [int(len(src)), int(len(tgt))], "neighbor_limits": PREDATOR_LIMITS,
+        "roofline": kr}
+    log(f"workloads: predator {out['predator_config3']['value']:.1f} pairs/s")
+
+    # ---- APR's encoder (FatBN, 128 features) through the headline pipeline: 6 pairs per call, single stream
+    torch.manual_seed(0)
+    fat = build_model("ResUNetFatBN", 128, dev)
+    pipe = PairRegistration(fat, voxel_size=0.3, ransac_iters=4000000)
+    pool = [(ta, tb)] + [tuple(torch.from_numpy(x).to(dev) for x in synth.make_pair(s)[:2]) for s in (1, 2)]
+    batch = [pool[j % len(pool)] for j in range(6)]
+    for i in range(3):
+        pipe.register_batch(batch, seeds=list(range(6)))
+    steps = 10
+    t0 = sync()
+    for i in range(steps):
+        pipe.register_batch(batch, seeds=[6 * i + j for j in range(6)])
+    t1 = sync()
+    prof = ops.SpconvProfile()
+    ops.PROFILE = prof
+    for i in range(3):
+        pipe.encode_batch(pipe.voxelize_batch([c for p in batch for c in p])[0])
+    ops.PROFILE = None
+    fr = conv_roofline(prof.summary())
+    fr["kernel"] = "all MFMA conv layers of the ResUNetFatBN encode (12 frames per call)"
+    out["fcgf_fatbn128"] = {
+        "workload": "FCGF_APR encode+match+SVD with APR's encoder (ResUNetFatBN, 128-d features, "
+                    "scripts/train_apr_kitti.sh:12-13), 6 pairs per step, one stream",
+        "value": steps * 6 / (t1 - t0), "unit": "pairs/s", "ms_per_step": 1e3 * (t1 - t0) / steps, "roofline": fr}
+    log(f"workloads: fatbn128 {out['fcgf_fatbn128']['value']:.1f} pairs/s")
+
+    # ---- config 5: distant pair (16-beam source vs 64-beam target, 40 m), APG over 10 complement frames + NPR loss
+    xyz0, _, _ = synth.make_pair(0, n_beams1=16, dist=40.0)
+    rng = np.random.default_rng(1000)
+    scene = synth.make_scene(0)
+    frames, poses = [], []
+    for j in list(range(-5, 0)) + list(range(1, 6)):
+        frames.append(torch.from_numpy(synth.raycast(scene, (6.0 * j, 0.0, 0.0), 0.0, rng, 16, 1875)).to(dev))
+        M = np.eye(4)
+        M[0, 3] = 6.0 * j
+        poses.append(M)
+    key = torch.from_numpy(xyz0).to(dev)
+    gen = apg.GenerativeMLP_98(in_channel=128, out_points=4).to(dev).eval()
+    rows = []
+    for rep in range(4):
+        t0 = sync()
+        nghb, sel = apg.aggregate_frames(key, frames, poses, 0.3)
+        cloud = nghb[sel]
+        t1 = sync()
+        m = ops.build_map(ops.voxelize(key, 0.3, 0), want_first=True)
+        ops.finalize_maps([m])
+        with torch.no_grad():
+            F = fat(ME.SparseTensor(torch.ones((m.n, 1), device=dev), coordinates=m.coords)).F
+        t2 = sync()
+        loss = apg.npr_reconstruction_loss(gen, F, m.coords[:, 1:], cloud, 0.3, 4)
+        t3 = sync()
+        if rep:
+            rows.append([t1 - t0, t2 - t1, t3 - t2])
+    r = np.array(rows).mean(0) * 1e3
+    out["config5_distant_pair"] = {
+        "workload": "LoNuScenes-shaped distant pair, source side: APG aggregation of 10 complement frames + FatBN-128 "
+                    "encode of the 16-beam key frame + NPR decoder (GenerativeMLP_98, ratio 4) reconstruction loss",
+        "value": float(r.sum()), "unit": "ms", "higher_is_better": False,
+        "stages_ms": {"apg_aggregate": float(r[0]), "voxelise+encode": float(r[1]), "npr_mlp+chamfer+reg": float(r[2])},
+        "key_points": int(len(xyz0)), "complement_points": int(sum(len(f) for f in frames)),
+        "apg_points": int(len(cloud)), "key_voxels": int(m.n), "loss": float(loss)}
+    log(f"workloads: config5 {r.sum():.2f} ms")
+    return out
 
 
 def main():
@@ -342,6 +477,8 @@ def main():
                                 "avg_launch_us": 1000.0 * s["ms"] / s["launches"]},
             "by_kernel": {names[k]: v for k, v in sorted(legs.items())},
         }
+    if rank == 0 and world == 1 and not args.no_workloads:
+        out["workloads"] = extra_workloads(dev, log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline (oracle on host cores) ...")
         out["cpu_baseline"] = cpu_baseline(model.state_dict(), args.model, args.n_out, host_pairs,
