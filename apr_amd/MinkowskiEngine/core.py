@@ -75,20 +75,44 @@ class CoordinateManager:
         fetched = []
         if pend or extras:
             fetched = ops.finalize_maps(pend, extras)
-            if self._dedup is not None and self._dedup.n > self._compact_rows:
-                # more voxels than the compact table was sized for: adopt the big table after all and rebuild
-                # whatever was chained behind the truncated one (second sync; never on LiDAR-density input)
-                strides = [ts for ts in self.maps if ts != 1]
-                self.maps = {1: self._dedup}
-                self._dedup = None
-                self._kmaps, self._plists = {}, {}
-                self.build_pyramid(strides)
-            m1 = self.maps[1]
-            if not self._adopted and m1.n != m1.n_in:
-                raise AprHipError(
-                    f"SparseTensor: {m1.n_in - m1.n} duplicate coordinates; quantize first "
-                    "(ME.utils.sparse_quantize)")
+            self._after_finalize()
         return fetched
+
+    def _after_finalize(self):
+        if self._dedup is not None and self._dedup.n > self._compact_rows:
+            # more voxels than the compact table was sized for: adopt the big table after all and rebuild
+            # whatever was chained behind the truncated one (second sync; never on LiDAR-density input)
+            strides = [ts for ts in self.maps if ts != 1]
+            self.maps = {1: self._dedup}
+            self._dedup = None
+            self._kmaps, self._plists = {}, {}
+            self.build_pyramid(strides)
+        m1 = self.maps[1]
+        if not self._adopted and m1.n != m1.n_in:
+            raise AprHipError(
+                f"SparseTensor: {m1.n_in - m1.n} duplicate coordinates; quantize first "
+                "(ME.utils.sparse_quantize)")
+
+    def build_pyramid_async(self, strides, extras=()):
+        """`build_pyramid` without the host synchronisation -> ops.PendingFetch; finish() returns the extras and leaves
+        the manager finalised (the rare oversize fallback inside synchronises)."""
+        for ts in sorted(strides):
+            if ts not in self.maps:
+                src = self.maps[ts // 2]
+                self.maps[ts] = ops.build_map(src.coords, floor_to=ts, n_in_dev=src.n_dev if src.n is None else None)
+        pend = [m for m in self.maps.values() if m.n is None]
+        if self._dedup is not None and self._dedup.n is None:
+            pend.append(self._dedup)
+        pf = ops.finalize_maps_async(pend, extras)
+        inner = pf._then
+
+        def then(host):
+            fetched = inner(host)
+            self._after_finalize()
+            return fetched
+
+        pf._then = then
+        return pf
 
     def build_pyramid(self, strides, extras=()):
         """Enqueue all missing strided maps back to back and sync ONCE (`extras`: small device int tensors fetched

@@ -78,6 +78,9 @@ PROTOTYPES = {
     "apr_irls_pose": (C.c_int, [_p, _p, _p, _i64, _p, _p, _sz, _p]),
     "apr_match_pose_batch_scratch_bytes": (_sz, [_i32, _i64, _i64, _i32, _i64]),
     "apr_match_pose_batch": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p]),
+    "apr_match_pose_batch_slot_bytes": (_sz, [_i32]),
+    "apr_match_pose_batch_enqueue": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p]),
+    "apr_match_pose_batch_finish": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p, _p]),
     "apr_irls_scratch_bytes": (_sz, [_i64]),
     "apr_contrastive_reduce": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _f32, _f32, _p, _p]),
     "apr_grid_subsample_scratch_bytes": (_sz, [_i64]),

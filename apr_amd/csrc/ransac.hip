@@ -795,11 +795,15 @@ APR_API size_t apr_match_pose_batch_scratch_bytes(int32_t B, int64_t n0_max, int
   return batch_layout(B, n0_max, n1_max, c, max_iter).total;
 }
 
-APR_API int apr_match_pose_batch(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist, double edge_ratio,
-                                 int64_t max_iter, void* scratch, size_t scratch_bytes, double* results_host,
-                                 void* stream) {
+APR_API size_t apr_match_pose_batch_slot_bytes(int32_t B) { return B > 0 ? (size_t)B * (sizeof(Hyp) + 64) : 0; }
+
+// Everything of apr_match_pose_batch up to the copy of the B result slots into slots_host (pinned memory of
+// apr_match_pose_batch_slot_bytes(B) bytes for the copy to be asynchronous): NO host synchronisation.
+APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist,
+                                         double edge_ratio, int64_t max_iter, void* scratch, size_t scratch_bytes,
+                                         void* slots_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  APR_CHECK_ARG(B > 0 && B <= 4096 && pairs && results_host, "apr_match_pose_batch: bad arguments");
+  APR_CHECK_ARG(B > 0 && B <= 4096 && pairs && slots_host, "apr_match_pose_batch: bad arguments");
   APR_CHECK_ARG(max_iter > 0 && max_iter < (1ll << 31) && max_dist > 0 && c > 0, "apr_match_pose_batch: bad parameters");
   int64_t n0_max = 0, n1_max = 0;
   for (int i = 0; i < B; ++i) {
@@ -839,20 +843,32 @@ APR_API int apr_match_pose_batch(const apr_pair_desc* pairs, int32_t B, int32_t 
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
   }
   APR_LAUNCH_CHECK();
-  // one round trip for all results
+  APR_HIP(hipMemcpyAsync(slots_host, slots, (size_t)B * (sizeof(Hyp) + 64), hipMemcpyDeviceToHost, st));
+  return APR_OK;
+}
+
+// Decode the slots once the stream work of the matching enqueue call has completed (the caller waited on the stream or
+// on an event recorded behind it); `pairs`, `scratch` and the parameters must be the ones given to the enqueue call.
+// A pair whose hypothesis list overflowed is redone through apr_ransac_pose (chunked rounds; synchronises).
+APR_API int apr_match_pose_batch_finish(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist,
+                                        double edge_ratio, int64_t max_iter, void* scratch, size_t scratch_bytes,
+                                        const void* slots_host, double* results_host, void* stream) {
+  APR_CHECK_ARG(B > 0 && B <= 4096 && pairs && slots_host && results_host, "apr_match_pose_batch: bad arguments");
+  int64_t n0_max = 0, n1_max = 0;
+  for (int i = 0; i < B; ++i) {
+    n0_max = pairs[i].n0 > n0_max ? pairs[i].n0 : n0_max;
+    n1_max = pairs[i].n1 > n1_max ? pairs[i].n1 : n1_max;
+  }
+  const BatchLayout L = batch_layout(B, n0_max, n1_max, c, max_iter);
+  APR_CHECK_ARG(scratch_bytes >= L.total, "apr_match_pose_batch: scratch too small");
+  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  p += L.nn_scratch + L.best;
+  void* ransac_scratch = p;
+  p += L.ransac + L.slots;
+  char* corr_base = p;
+  const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const size_t slot_bytes = sizeof(Hyp) + 64;
-  char* host = (char*)malloc((size_t)B * slot_bytes);
-  if (!host) {
-    apr_set_error("apr_match_pose_batch: out of host memory");
-    return APR_EINVAL;
-  }
-  hipError_t e = hipMemcpyAsync(host, slots, (size_t)B * slot_bytes, hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) {
-    free(host);
-    apr_set_error("apr_match_pose_batch: result fetch failed: %s", hipGetErrorString(e));
-    return APR_EHIP;
-  }
+  const char* host = (const char*)slots_host;
   int rc = APR_OK;
   for (int i = 0; i < B && rc == APR_OK; ++i) {
     Hyp hb;
@@ -873,6 +889,27 @@ APR_API int apr_match_pose_batch(const apr_pair_desc* pairs, int32_t B, int32_t 
     out[18] = (double)hb.it;
     out[19] = (double)tv;
   }
+  return rc;
+}
+
+APR_API int apr_match_pose_batch(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist, double edge_ratio,
+                                 int64_t max_iter, void* scratch, size_t scratch_bytes, double* results_host,
+                                 void* stream) {
+  APR_CHECK_ARG(B > 0 && B <= 4096 && pairs && results_host, "apr_match_pose_batch: bad arguments");
+  const size_t nb = apr_match_pose_batch_slot_bytes(B);
+  char* host = (char*)malloc(nb);
+  if (!host) {
+    apr_set_error("apr_match_pose_batch: out of host memory");
+    return APR_EINVAL;
+  }
+  int rc = apr_match_pose_batch_enqueue(pairs, B, c, max_dist, edge_ratio, max_iter, scratch, scratch_bytes, host, stream);
+  if (rc == APR_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    apr_set_error("apr_match_pose_batch: result fetch failed");
+    rc = APR_EHIP;
+  }
+  if (rc == APR_OK)
+    rc = apr_match_pose_batch_finish(pairs, B, c, max_dist, edge_ratio, max_iter, scratch, scratch_bytes, host,
+                                     results_host, stream);
   free(host);
   return rc;
 }

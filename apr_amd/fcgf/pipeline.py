@@ -75,6 +75,48 @@ class PairRegistration:
         return cm, [int(c) for c in counts], m.first, offs, pts_all
 
     @torch.no_grad()
+    def register_batch_phases(self, pairs, seeds=None):
+        """`register_batch` as a generator for a single-threaded scheduler (`run_pipelined`): it yields an
+        `ops.PendingFetch` wherever the synchronous version blocks the host (the map sizes, the poses), enqueues
+        everything else on the CURRENT stream, and returns the list of (T, info)."""
+        if seeds is None:
+            seeds = range(len(pairs))
+        clouds = [c for p in pairs for c in p]
+        if len(clouds) > 1023:
+            raise ValueError("at most 1023 frames per batch (10-bit batch index in the voxel key; 1023 is reserved "
+                             "for the empty-slot key)")
+        dev = clouds[0].device
+        offs = [0]
+        for c in clouds:
+            offs.append(offs[-1] + int(c.shape[0]))
+        xyz_all = torch.cat(clouds) if len(clouds) > 1 else clouds[0].contiguous()
+        offs_dev = torch.tensor(offs, dtype=torch.int64).to(dev, non_blocking=True)
+        coords_all = ops.voxelize_segments(xyz_all, self.voxel_size, offs_dev)
+        m = ops.build_map(coords_all, want_first=True)
+        counts_dev = ops.segment_counts(m, offs_dev)
+        cm = ME.CoordinateManager(base_map=m)
+        pending = cm.build_pyramid_async([2, 4, 8], extras=[counts_dev])
+        yield pending
+        (counts,) = pending.finish()
+        counts = [int(c) for c in counts]
+        pts_all = xyz_all[m.first]
+        F = self.encode_batch(cm)
+        o = [0]
+        for n in counts:
+            o.append(o[-1] + n)
+        pts = [pts_all[o[b]:o[b + 1]] for b in range(len(clouds))]
+        pending = ops.match_pose_batch_async([F[o[2 * i]:o[2 * i + 1]] for i in range(len(pairs))],
+                                             [F[o[2 * i + 1]:o[2 * i + 2]] for i in range(len(pairs))],
+                                             pts[0::2], pts[1::2], self.distance_threshold, self.edge_length,
+                                             self.ransac_iters, seeds=list(seeds))
+        yield pending
+        out = []
+        for i, (T, info) in enumerate(pending.finish()):
+            info.update(n0=counts[2 * i], n1=counts[2 * i + 1])
+            out.append((T, info))
+        return out
+
+    @torch.no_grad()
     def encode_batch(self, cm):
         n = cm.size(1)
         feats = torch.ones((n, 1), dtype=torch.float32, device=cm.device)
@@ -117,3 +159,52 @@ class PairRegistration:
                                   self.edge_length, self.ransac_iters, seed)
         info.update(n0=n0, n1=n1)
         return T, info
+
+
+def run_pipelined(make_step, indices, streams):
+    """ONE host thread, len(streams) steps in flight.  `make_step(i)` returns a generator that enqueues work on the
+    current stream and yields `ops.PendingFetch` objects where it needs bytes back on the host (see
+    `PairRegistration.register_batch_phases`).  Slot s runs its steps on streams[s]; whenever a slot's fetch has landed
+    its generator is resumed, otherwise the next slot gets the host; the host only blocks when no slot can move.
+    -> ({i: result}, [(i, completion time)]).
+
+    This replaces one Python thread per stream: the threads spent their time fighting over the GIL (3 threads: host
+    time per step 10 ms instead of 1.4 ms), and 8 ranks x 3 threads do not fit a 16-thread host share."""
+    import time
+    it = iter(indices)
+    slots = [None] * len(streams)          # (step index, generator, pending fetch)
+    results, done_at = {}, []
+    exhausted = False
+
+    def advance(s):
+        i, gen, _ = slots[s]
+        with torch.cuda.stream(streams[s]):
+            try:
+                slots[s] = (i, gen, next(gen))
+            except StopIteration as stop:
+                results[i] = stop.value
+                done_at.append((i, time.perf_counter()))
+                slots[s] = None
+
+    while True:
+        moved = False
+        for s in range(len(streams)):
+            if slots[s] is None:
+                if exhausted:
+                    continue
+                try:
+                    i = next(it)
+                except StopIteration:
+                    exhausted = True
+                    continue
+                slots[s] = (i, make_step(i), None)
+                advance(s)
+                moved = True
+            elif slots[s][2].event.query():
+                advance(s)
+                moved = True
+        live = [sl for sl in slots if sl is not None]
+        if not live and exhausted:
+            return results, done_at
+        if not moved and live:
+            min(live, key=lambda sl: sl[0])[2].event.synchronize()      # nothing ready: wait for the oldest step

@@ -138,6 +138,44 @@ def finalize_maps(maps, extras=()):
     return out
 
 
+class PendingFetch:
+    """A small device -> pinned-host copy in flight on the current stream: `event` completes when the bytes have
+    landed, `finish()` then runs the host-side continuation and returns its value.  Lets ONE host thread keep several
+    steps in flight (apr_amd.fcgf.pipeline.run_pipelined) instead of blocking in `.cpu()`."""
+
+    __slots__ = ("event", "_host", "_then", "_keep")
+
+    def __init__(self, dev_tensor, then, keep=()):
+        self._host = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True)
+        self._host.copy_(dev_tensor, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._then, self._keep = then, keep
+
+    def finish(self):
+        self.event.synchronize()
+        return self._then(self._host.numpy())
+
+
+def finalize_maps_async(maps, extras=()):
+    """`finalize_maps` without the host synchronisation -> PendingFetch whose finish() applies the counts and returns
+    the extras (numpy arrays)."""
+    pend = [m for m in maps if m.n is None]
+    parts = [torch.cat([m.n_dev, m.status]) for m in pend] + [e.reshape(-1).to(torch.int32) for e in extras]
+    if not parts:
+        parts = [torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))]
+
+    def then(host):
+        out, pos = [], 2 * len(pend)
+        for e in extras:
+            out.append(host[pos:pos + e.numel()].copy())
+            pos += e.numel()
+        _apply_finalize(pend, host)
+        return out
+
+    return PendingFetch(torch.cat(parts), then)
+
+
 def _apply_finalize(pend, host):
     for i, m in enumerate(pend):
         if host[2 * i + 1] != 0:
@@ -584,6 +622,57 @@ def match_pose_batch(feats0, feats1, pts0, pts1, max_dist, edge_ratio=0.9, max_i
                     dict(inliers=int(r[i, 16]), rmse=float(r[i, 17]), best_iteration=int(r[i, 18]),
                          n_valid=int(r[i, 19]), fitness=float(r[i, 16]) / max(n0, 1))))
     return out
+
+
+def match_pose_batch_async(feats0, feats1, pts0, pts1, max_dist, edge_ratio=0.9, max_iter=4000000, seeds=None):
+    """`match_pose_batch` in two halves (apr_match_pose_batch_enqueue / _finish): everything is enqueued on the current
+    stream, the B result slots travel to pinned host memory asynchronously -> PendingFetch whose finish() returns the
+    list of (T, info)."""
+    B = len(feats0)
+    if not (B == len(feats1) == len(pts0) == len(pts1)) or B == 0:
+        raise _lib.AprHipError("match_pose_batch: need the same (non-zero) number of entries in every list")
+    if seeds is None:
+        seeds = range(B)
+    lib = _lib_()
+    descs = (_lib.PairDesc * B)()
+    keep = []
+    c = feats0[0].shape[1]
+    n0m = n1m = 0
+    for i in range(B):
+        f0 = _f32(feats0[i], "match_pose_batch.feats0").contiguous()
+        f1 = _f32(feats1[i], "match_pose_batch.feats1").contiguous()
+        p0 = _f32(pts0[i], "match_pose_batch.pts0").contiguous()
+        p1 = _f32(pts1[i], "match_pose_batch.pts1").contiguous()
+        if f0.shape[1] != c or f1.shape[1] != c or p0.shape != (f0.shape[0], 3) or p1.shape != (f1.shape[0], 3):
+            raise _lib.AprHipError("match_pose_batch: inconsistent shapes in pair %d" % i)
+        keep += [f0, f1, p0, p1]
+        d = descs[i]
+        d.f0, d.n0, d.f1, d.n1 = f0.data_ptr(), f0.shape[0], f1.data_ptr(), f1.shape[0]
+        d.xyz0, d.xyz1, d.seed = p0.data_ptr(), p1.data_ptr(), int(seeds[i]) & 0xFFFFFFFFFFFFFFFF
+        n0m, n1m = max(n0m, f0.shape[0]), max(n1m, f1.shape[0])
+    sb = int(lib.apr_match_pose_batch_scratch_bytes(B, n0m, n1m, c, int(max_iter)))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=keep[0].device)
+    slots = torch.empty(int(lib.apr_match_pose_batch_slot_bytes(B)), dtype=torch.uint8, pin_memory=True)
+    st = stream()
+    check(lib.apr_match_pose_batch_enqueue(descs, B, c, float(max_dist), float(edge_ratio), int(max_iter), ptr(scratch),
+                                           sb, C.c_void_p(slots.data_ptr()), st))
+    pf = PendingFetch.__new__(PendingFetch)
+    pf._host = slots
+    pf.event = torch.cuda.Event()
+    pf.event.record()
+    pf._keep = (keep, scratch, descs)
+
+    def then(_):
+        res = (C.c_double * (20 * B))()
+        check(lib.apr_match_pose_batch_finish(descs, B, c, float(max_dist), float(edge_ratio), int(max_iter),
+                                              ptr(scratch), sb, C.c_void_p(slots.data_ptr()), res, st))
+        r = np.array(list(res), dtype=np.float64).reshape(B, 20)
+        return [(r[i, :16].reshape(4, 4).copy(),
+                 dict(inliers=int(r[i, 16]), rmse=float(r[i, 17]), best_iteration=int(r[i, 18]), n_valid=int(r[i, 19]),
+                      fitness=float(r[i, 16]) / max(descs[i].n0, 1))) for i in range(B)]
+
+    pf._then = then
+    return pf
 
 
 def ransac_pose_geometric(xyz0, xyz1, corr, max_dist, edge_ratio=0.9, max_iter=50000, max_validation=1000, seed=0):

@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="pairs in flight per GPU: each on its own HIP stream + host thread (a 28 k-voxel pair "
                          "cannot fill 256 CUs alone, so independent pairs overlap)")
+    ap.add_argument("--host", choices=["pipelined", "threads"], default="pipelined",
+                    help="how the --streams steps in flight are driven: ONE host thread resuming each step when its "
+                         "device->host fetch has landed (default), or one Python thread per stream (round 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true",
@@ -346,10 +349,24 @@ def main():
                     job["err"] = e
                 done.wait()
 
-    threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(nstreams)]
+    pipelined = args.host == "pipelined" and B > 1
+    threads = [] if pipelined else [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(nstreams)]
     [t.start() for t in threads]
 
+    def make_step(i):
+        batch = [pairs[(i * B + j) % len(pairs)] for j in range(B)]
+        return pipe.register_batch_phases(batch, seeds=[i * B + j for j in range(B)])
+
     def run_steps(first, last):
+        if pipelined:       # one host thread, `nstreams` steps in flight (apr_amd.fcgf.pipeline.run_pipelined)
+            from apr_amd.fcgf.pipeline import run_pipelined
+            res, done_at = run_pipelined(make_step, range(first, last), streams)
+            for i, r in res.items():
+                results[i] = r[-1]
+            step_log.extend((i, 0, t, t) for i, t in done_at)
+            for st in streams:
+                st.synchronize()
+            return
         job["first"], job["last"] = first, last
         go.wait()
         done.wait()
@@ -384,8 +401,9 @@ def main():
     barrier()
     elapsed_local = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed_local, dev if backend == "nccl" else torch.device("cpu"))   # all-reduce(MAX)
-    job["stop"] = True
-    go.wait()
+    if not pipelined:
+        job["stop"] = True
+        go.wait()
 
     log(f"timed loop: {args.steps} steps in {elapsed:.3f}s with {nstreams} stream(s)")
     # steady state: median interval between step completions (each completion = one step of B pairs), next to the
@@ -418,7 +436,9 @@ def main():
                                f"per step share one batched encoder call (2x{B} frames), then NN + RANSAC per pair",
                    "encoder": args.model, "feature_dim": args.n_out, "points_per_frame": int(n_pts),
                    "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
-                   "pairs_per_step": B, "streams_per_gpu": nstreams, "sharding": f"{world} ranks x independent pairs",
+                   "pairs_per_step": B, "streams_per_gpu": nstreams,
+                   "host": "one thread, steps resumed on fetch completion" if pipelined else f"{nstreams} threads",
+                   "sharding": f"{world} ranks x independent pairs",
                    "pool_pairs": npool, "ransac_valid_hypotheses_last_pair": int(info["n_valid"]),
                    "per_rank_pairs_per_s": [float(r[0] / r[1]) for r in stats.tolist()]},
     }

@@ -282,6 +282,17 @@ typedef struct {
 size_t apr_match_pose_batch_scratch_bytes(int32_t B, int64_t n0_max, int64_t n1_max, int32_t c, int64_t max_iter);
 int apr_match_pose_batch(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist, double edge_ratio,
                          int64_t max_iter, void* scratch, size_t scratch_bytes, double* results_host, void* stream);
+/* The same in two halves, for a host that keeps several batches in flight from ONE thread (bench.py): _enqueue
+ * launches everything and ends with an asynchronous copy of the B result slots into slots_host
+ * (apr_match_pose_batch_slot_bytes(B) bytes; pinned host memory makes the copy asynchronous) - no host
+ * synchronisation; _finish decodes the slots into results_host f64[B][20] once the caller has waited for that copy (an
+ * event recorded on `stream` behind the enqueue call).  Same pairs / parameters / scratch for both halves. */
+size_t apr_match_pose_batch_slot_bytes(int32_t B);
+int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist, double edge_ratio,
+                                 int64_t max_iter, void* scratch, size_t scratch_bytes, void* slots_host, void* stream);
+int apr_match_pose_batch_finish(const apr_pair_desc* pairs, int32_t B, int32_t c, double max_dist, double edge_ratio,
+                                int64_t max_iter, void* scratch, size_t scratch_bytes, const void* slots_host,
+                                double* results_host, void* stream);
 
 /* Robust linearised 6-DoF pose (20 IRLS iterations), replaces
  * est_quad_linear_robust (FCGF_APR/util/transform_estimation.py:89-116).

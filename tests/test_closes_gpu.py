@@ -140,3 +140,24 @@ def test_three_threads_three_streams_match_single_stream(dev):
     for w in range(3):
         for (Ta, ia), (Tb, ib) in zip(want[w], got[w]):
             assert np.array_equal(Ta, Tb) and ia == ib
+
+
+def test_single_thread_pipelined_steps_match_blocking_calls(dev):
+    """apr_amd.fcgf.pipeline.run_pipelined (one host thread, 3 steps in flight on 3 streams, resumed when their
+    device->host fetches land) returns exactly what the blocking register_batch returns, step by step."""
+    from apr_amd.fcgf.pipeline import PairRegistration, run_pipelined
+    _, hm = model_pair("ResUNetBN2C")
+    pipe = PairRegistration(hm.eval(), 0.3, ransac_iters=200000)
+    pairs = []
+    for s in range(4):
+        a, b, _ = synth.make_pair(60 + s, n_beams=32, n_azimuth=700)
+        pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    batches = [[pairs[i % 4], pairs[(i + 1) % 4]] for i in range(7)]
+    want = [pipe.register_batch(b, seeds=[3 * i, 3 * i + 1]) for i, b in enumerate(batches)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    got, done_at = run_pipelined(lambda i: pipe.register_batch_phases(batches[i], seeds=[3 * i, 3 * i + 1]),
+                                 range(len(batches)), streams)
+    assert sorted(got) == list(range(len(batches))) and len(done_at) == len(batches)
+    for i in range(len(batches)):
+        for (Ta, ia), (Tb, ib) in zip(want[i], got[i]):
+            assert np.array_equal(Ta, Tb) and ia == ib
