@@ -282,3 +282,18 @@ def test_match_pose_batch_equals_per_pair_calls(dev):
         T, info = ops.ransac_pose(g(xyz0), g(xyz1), corr, 0.3, 0.9, iters, seed)
         assert info == ib and np.array_equal(T, Tb)
     assert batch[3][1]["n_valid"] == iters and batch[3][1]["inliers"] == 260
+
+
+def test_batch_path_replays_overflow_at_full_reference_criteria(dev):
+    """KITTI-sized pair, 80 % true correspondences, the reference's 4 000 000 iterations, through the BATCH entry point
+    (apr_match_pose_batch) and without any test hook: ~1.6 M hypotheses survive both checkers, more than the 2^20-entry
+    list holds, so the pair is redone in rounds inside the call.  Same result as the per-pair entry point."""
+    xyz0, xyz1, F0, F1, T_gt = _synthetic_pair(21, n=14000, inlier=0.8)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    (T, info), = ops.match_pose_batch([t(F0)], [t(F1)], [t(xyz0)], [t(xyz1)], 0.3, 0.9, 4000000, seeds=[4])
+    assert info["n_valid"] > (1 << 20)
+    rte, rre = registration.rte_rre(T, T_gt)
+    assert rte < 0.1 and rre < 0.2 and info["inliers"] > 0.7 * 14000
+    corr = ops.feature_nn(t(F0), t(F1))
+    T2, info2 = ops.ransac_pose(t(xyz0), t(xyz1), corr, 0.3, 0.9, 4000000, 4)
+    assert info2 == {k: info[k] for k in info2} and np.array_equal(T, T2)
