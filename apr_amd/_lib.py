@@ -65,6 +65,7 @@ PROTOTYPES = {
     "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     "apr_norm_params": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _p, _p, _sz, _p]),
     "apr_bn_stats_scratch_bytes": (_sz, [_i64, _i32]),
+    "apr_instance_norm_act": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _sz, _p]),
     "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _p]),
     "apr_l2_normalize": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
     "apr_feature_nn": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p]),
@@ -87,10 +88,12 @@ PROTOTYPES = {
     "apr_grid_subsample": (C.c_int, [_p, _i64, _p, _i32, _f32, _p, _i32, _p, _p, _p, _p, _sz, _p]),
     "apr_radius_scratch_bytes": (_sz, [_i64, _i64]),
     "apr_radius_neighbors_async": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
+    "apr_radius_neighbors_regrid_async": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "apr_radius_neighbors": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "apr_knn": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "apr_row_sums": (C.c_int, [_p, _i64, _i64, _i32, _p, _p]),
     "apr_kpconv_weighted": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _p, _i32, _f32, _p, _p, _i64, _p]),
+    "apr_kpconv_dfeat": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _p, _i32, _f32, _p, _p, _i64, _p]),
     "apr_gather_pool": (C.c_int, [_p, _i64, _i64, _i32, _p, _i32, _i64, _i32, _p, _i64, _p]),
     "apr_edge_features": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "apr_group_max": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _f32, _p, _i64, _p]),

@@ -142,6 +142,67 @@ __global__ void k_kpconv_weighted_generic(const float* __restrict__ q_pts, const
   }
 }
 
+// Backward of step 1 with respect to the neighbour features (Predator side):
+//   dx[nbr[q,h], c] += (1 / num_q) * sum_k w[q,k,h] * dwf[q, k*cin + c]
+// (the neighbour count num_q and the influences w depend on the geometry and on the SIGN of the feature sums only:
+// piecewise constant in x, no gradient through them - the same graph torch builds for blocks.py:326-374).
+// One wave per query: the 15 x H influences go to LDS once, a lane keeps the 15 values dwf[q, :, c] of its channel
+// in registers and walks the neighbours; the sums leave through float atomics (a support point is the neighbour of
+// ~H queries: the transposed table is not available, and torch's own index backward adds atomically as well).
+template <int CPL>   // channels per lane: cin <= 64 * CPL
+__global__ __launch_bounds__(256) void k_kpconv_dfeat(
+    const float* __restrict__ q_pts, const float* __restrict__ s_pts, const int* __restrict__ nbr, int H,
+    const float* __restrict__ dwf, int64_t lddwf, int cin, const float* __restrict__ kp, float extent,
+    const float* __restrict__ rowsum, float* __restrict__ dx, int64_t lddx, int nq, int ns) {
+  __shared__ int s_idx[4][kMaxH];
+  __shared__ float s_w[4][kMaxH][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x * 4 + wave;
+  if (qi >= nq) return;
+  const float qx = q_pts[3 * (int64_t)qi], qy = q_pts[3 * (int64_t)qi + 1], qz = q_pts[3 * (int64_t)qi + 2];
+  const float inv_extent = 1.f / extent;
+  int cnt = 0;
+  for (int h = lane; h < H; h += 64) {
+    int idx = nbr[(int64_t)qi * H + h];
+    if (idx < 0 || idx >= ns) idx = -1;
+    s_idx[wave][h] = idx;
+    if (idx >= 0) {
+      cnt += rowsum[idx] > 0.f ? 1 : 0;
+      const float dx_ = s_pts[3 * (int64_t)idx] - qx, dy_ = s_pts[3 * (int64_t)idx + 1] - qy,
+                  dz_ = s_pts[3 * (int64_t)idx + 2] - qz;
+#pragma unroll
+      for (int k = 0; k < kKP; ++k)
+        s_w[wave][h][k] = kp_weight(dx_, dy_, dz_, kp[3 * k], kp[3 * k + 1], kp[3 * k + 2], inv_extent);
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+  const float inv_num = 1.f / (float)max(cnt, 1);
+  // (the wave's LDS writes are read back by other lanes of the same wave: in-order LDS queue, no barrier needed)
+  float g[CPL][kKP];
+#pragma unroll
+  for (int u = 0; u < CPL; ++u) {
+    const int c = lane + 64 * u;
+#pragma unroll
+    for (int k = 0; k < kKP; ++k)
+      g[u][k] = c < cin ? dwf[(int64_t)qi * lddwf + (int64_t)k * cin + c] * inv_num : 0.f;
+  }
+  for (int h = 0; h < H; ++h) {
+    const int idx = s_idx[wave][h];      // wave-uniform
+    if (idx < 0) continue;
+    float w[kKP];
+#pragma unroll
+    for (int k = 0; k < kKP; ++k) w[k] = s_w[wave][h][k];
+#pragma unroll
+    for (int u = 0; u < CPL; ++u) {
+      const int c = lane + 64 * u;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < kKP; ++k) acc = fmaf(w[k], g[u][k], acc);
+      if (c < cin) atomicAdd(dx + (int64_t)idx * lddx + c, acc);
+    }
+  }
+}
+
 // out[q,:] = max_h x_pad[inds[q,h],:]  (x_pad = x plus a zero shadow row; blocks.py:86-102)
 // mode 1: out[q,:] = x_pad[inds[q,0],:]  (closest_pool, blocks.py:71-83)
 __global__ void k_gather_pool(const float* __restrict__ x, int64_t ldx, int ns, int c, const int* __restrict__ inds,
@@ -405,6 +466,28 @@ APR_API int apr_kpconv_weighted(const float* q_pts, int64_t nq, const float* s_p
     hipLaunchKernelGGL(k_kpconv_weighted_generic, dim3((unsigned)cdiv64(nq * kKP, 256)), dim3(256), 0, st, q_pts, s_pts,
                        nbr, H, x, ldx, cin, kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
   }
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr, int32_t H,
+                             const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points, int32_t n_kp,
+                             float extent, const float* rowsum, float* dx, int64_t lddx, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n_kp == kKP, "apr_kpconv_dfeat: built for %d kernel points, got %d", kKP, n_kp);
+  APR_CHECK_ARG(nq >= 0 && ns > 0 && H > 0 && H <= kMaxH && cin > 0 && cin <= 512 && extent > 0.f,
+                "apr_kpconv_dfeat: bad arguments (H <= %d, cin <= 512)", kMaxH);
+  APR_CHECK_ARG(lddx >= cin && lddwf >= (int64_t)kKP * cin, "apr_kpconv_dfeat: leading dimension too small");
+  if (nq == 0) return APR_OK;
+  const unsigned grid = (unsigned)cdiv64(nq, 4);
+#define APR_DF(N)                                                                                                     \
+  hipLaunchKernelGGL(k_kpconv_dfeat<N>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, dwf, lddwf, cin, kernel_points, \
+                     extent, rowsum, dx, lddx, (int)nq, (int)ns)
+  if (cin <= 64) APR_DF(1);
+  else if (cin <= 128) APR_DF(2);
+  else if (cin <= 256) APR_DF(4);
+  else APR_DF(8);
+#undef APR_DF
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -113,6 +113,63 @@ __global__ void k_affine_act(const float* __restrict__ x, int64_t ldx, int64_t n
   }
 }
 
+// k_bn_finish + k_affine_act in one: a workgroup owns 64 columns x 64 rows; it first rebuilds the columns'
+// (scale, shift) from the block partials (every workgroup of a column repeats the same fixed-order sum: a few
+// hundred fp64 adds against a launch, a 4 KB round trip and a host-side call saved per normalisation), then
+// y = act(x * scale + shift (+ residual)).
+__global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                    const double* __restrict__ partial, int nblk, float eps,
+                                                    const float* __restrict__ residual, int64_t ldr, int relu,
+                                                    float slope, float* __restrict__ y, int64_t ldy) {
+  __shared__ double s_a[4][64], s_q[4][64];
+  __shared__ float s_scale[64], s_shift[64];
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + tx;
+  double s = 0.0, s2 = 0.0;
+  if (col < c) {
+    for (int b0 = grp; b0 < nblk; b0 += 32) {      // same order as k_bn_finish: bit-identical statistics
+      double a[8], q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 4 * u;
+        const bool ok = b < nblk;
+        a[u] = ok ? partial[((int64_t)b * 2 + 0) * c + col] : 0.0;
+        q[u] = ok ? partial[((int64_t)b * 2 + 1) * c + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += a[u];
+        s2 += q[u];
+      }
+    }
+  }
+  s_a[grp][tx] = s;
+  s_q[grp][tx] = s2;
+  __syncthreads();
+  if (grp == 0 && col < c) {
+    s = ((s_a[0][tx] + s_a[1][tx]) + s_a[2][tx]) + s_a[3][tx];
+    s2 = ((s_q[0][tx] + s_q[1][tx]) + s_q[2][tx]) + s_q[3][tx];
+    const double m = s / (double)n;
+    const double v = s2 / (double)n - m * m;
+    const float mf = (float)m, vf = (float)(v > 0.0 ? v : 0.0);
+    const float sc = 1.0f / sqrtf(vf + eps);
+    s_scale[tx] = sc;
+    s_shift[tx] = -mf * sc;
+  }
+  __syncthreads();
+  if (col >= c) return;
+  const float sc = s_scale[tx], sh = s_shift[tx];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int64_t r1 = min((long long)(r0 + 64), (long long)n);
+  for (int64_t r = r0 + grp; r < r1; r += 4) {
+    float v = x[r * ldx + col] * sc + sh;
+    if (residual) v += residual[r * ldr + col];
+    if (relu == 1) v = fmaxf(v, 0.f);
+    else if (relu == 2) v = v > 0.f ? v : v * slope;
+    y[r * ldy + col] = v;
+  }
+}
+
 // one wave per row; c <= 64 * 8
 __global__ void k_l2_normalize(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
                                float* __restrict__ y, int64_t ldy) {
@@ -157,6 +214,21 @@ APR_API int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, fl
                      (double*)scratch);
   hipLaunchKernelGGL(k_bn_finish, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const double*)scratch, nblk, n, c, (float*)nullptr, (float*)nullptr, eps, scale, shift);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_instance_norm_act(const float* x, int64_t ldx, int64_t n, int32_t c, float eps, const float* residual,
+                                  int64_t ldr, int32_t relu, float negative_slope, float* y, int64_t ldy, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(n > 0 && c > 0 && ldx >= c && ldy >= c && eps >= 0.f && x && y, "apr_instance_norm_act: bad arguments");
+  APR_CHECK_ARG(!residual || ldr >= c, "apr_instance_norm_act: ldr < c");
+  APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_instance_norm_act: scratch too small");
+  const int nblk = (int)cdiv64(n, kRowsPerBlock);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ldx, n, c,
+                     (double*)scratch);
+  hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(n, 64), (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x,
+                     ldx, n, c, (const double*)scratch, nblk, eps, residual, ldr, relu, negative_slope, y, ldy);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

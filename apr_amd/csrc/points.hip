@@ -671,10 +671,10 @@ APR_API int apr_radius_neighbors(const float* queries, int64_t nq, const float* 
 // count; flags_dev[0] = max count over all queries, flags_dev[1] != 0 if a query overflowed the candidate buffer.
 // The reference's width is min(max count, limit): a caller that needs it reads flags_dev when convenient (one
 // synchronisation for a whole pyramid of tables) and drops the all-padding columns [max count, limit) if any.
-APR_API int apr_radius_neighbors_async(const float* queries, int64_t nq, const float* supports, int64_t ns,
-                                       const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb,
-                                       float radius, int32_t limit, int32_t* out, int64_t out_ld, int32_t* flags_dev,
-                                       void* scratch, size_t scratch_bytes, void* stream) {
+static int radius_async(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                        const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb, float radius,
+                        int32_t limit, int32_t* out, int64_t out_ld, int32_t* flags_dev, void* scratch,
+                        size_t scratch_bytes, void* stream, bool reuse_grid) {
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(nq > 0 && ns > 0 && nq < (1ll << 31) && ns < (1ll << 31) && nb > 0 && nb <= kMaxBatch && radius > 0.f,
                 "apr_radius_neighbors_async: bad arguments");
@@ -686,8 +686,10 @@ APR_API int apr_radius_neighbors_async(const float* queries, int64_t nq, const f
   int* counts = (int*)p;
   p += align256(nq * 4);
   int* qstarts = (int*)p;
-  int rc = build_grid(supports, ns, s_lengths_host, nb, radius, 1, w, st);
-  if (rc != APR_OK) return rc;
+  if (!reuse_grid) {
+    int rc = build_grid(supports, ns, s_lengths_host, nb, radius, 1, w, st);
+    if (rc != APR_OK) return rc;
+  }
   BatchStarts qb;
   int* qs = qb.v;
   qs[0] = 0;
@@ -702,6 +704,25 @@ APR_API int apr_radius_neighbors_async(const float* queries, int64_t nq, const f
   hipLaunchKernelGGL(k_max_int, dim3(64), dim3(256), 0, st, counts, nq, flags_dev);
   APR_LAUNCH_CHECK();
   return APR_OK;
+}
+
+APR_API int apr_radius_neighbors_async(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                                       const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb,
+                                       float radius, int32_t limit, int32_t* out, int64_t out_ld, int32_t* flags_dev,
+                                       void* scratch, size_t scratch_bytes, void* stream) {
+  return radius_async(queries, nq, supports, ns, q_lengths_host, s_lengths_host, nb, radius, limit, out, out_ld,
+                      flags_dev, scratch, scratch_bytes, stream, false);
+}
+
+// Same, searching the grid the PREVIOUS apr_radius_neighbors_async call left in `scratch`: same supports, same
+// s_lengths, same radius, same stream (KPConv's collate queries every level's points twice with one radius: once from
+// the level itself, once from the pooled level: the ~15 launches of the second grid build are saved).
+APR_API int apr_radius_neighbors_regrid_async(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                                              const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb,
+                                              float radius, int32_t limit, int32_t* out, int64_t out_ld,
+                                              int32_t* flags_dev, void* scratch, size_t scratch_bytes, void* stream) {
+  return radius_async(queries, nq, supports, ns, q_lengths_host, s_lengths_host, nb, radius, limit, out, out_ld,
+                      flags_dev, scratch, scratch_bytes, stream, true);
 }
 
 APR_API int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t* out, void* stream) {

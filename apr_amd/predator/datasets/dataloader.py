@@ -52,11 +52,13 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits):
     deferred, slots = [], []
     flags_all = torch.empty((16, 2), dtype=torch.int32, device=dev)
 
+    level_grid = point_ops.SearchGrid()     # the level's own points bucketed at the conv radius: searched twice
+
     def neighbors(queries, supports, q_b, s_b, radius, limit, where):
         if limit is None or int(limit) <= 0 or len(deferred) >= flags_all.shape[0]:
             return batch_neighbors_kpconv(queries, supports, q_b, s_b, radius, limit)
         t = point_ops.radius_neighbors_async(queries, supports, np.asarray(q_b), np.asarray(s_b), radius, int(limit),
-                                             flags_all[len(deferred)])
+                                             flags_all[len(deferred)], keep_grid=level_grid, grid=level_grid)
         deferred.append(t)
         slots.append(where)
         return t

@@ -107,6 +107,48 @@ def kpconv_weighted(q_pts, s_pts, nbr, x, kernel_points, extent):
     return wf
 
 
+class KPConvFunction(torch.autograd.Function):
+    """Rigid KPConv (blocks.py:229-374) with forward AND both gradients on the HIP kernels:
+    forward   wf = step 1 (apr_kpconv_weighted), out = wf @ W (dense MFMA GEMM);
+    d W       = wf^T @ dout                       (apr_spconv_wgrad, identity map; wf is recomputed, not stored);
+    d x       = scatter of (dout @ W^T) through the influences (apr_kpconv_dfeat on the forward's neighbour table).
+    The points, the kernel points and the neighbour table get no gradient (rigid kernel)."""
+
+    @staticmethod
+    def forward(ctx, q_pts, s_pts, inds, x, weights, kernel_points, extent):
+        inds = _i32(inds, "kpconv.nbr")
+        x = x.contiguous()
+        K, cin, cout = weights.shape
+        wf = kpconv_weighted(q_pts, s_pts, inds, x, kernel_points, extent)
+        w2 = weights.detach().reshape(K * cin, cout)
+        if wf.shape[1] != K * cin:
+            w2 = torch.cat([w2, torch.zeros((wf.shape[1] - K * cin, cout), dtype=w2.dtype, device=w2.device)], 0)
+        out = linear(wf, pack_linear(w2))
+        ctx.save_for_backward(q_pts, s_pts, inds, x, weights, kernel_points)
+        ctx.extent = float(extent)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_pts, s_pts, inds, x, weights, kernel_points = ctx.saved_tensors
+        K, cin, cout = weights.shape
+        dout = dout.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[4]:
+            wf = kpconv_weighted(q_pts, s_pts, inds, x, kernel_points, ctx.extent)
+            dw = ops.spconv_wgrad(wf, dout, None, 1, wf.shape[1], cout)[0, :K * cin].reshape(K, cin, cout)
+        if ctx.needs_input_grad[3]:
+            dwf = linear(dout, pack_linear(weights.detach().reshape(K * cin, cout).t().contiguous()))   # [nq, K*cin]
+            dwf, lddwf = ops._rows(dwf, "kpconv.dwf")
+            dx = torch.zeros_like(x)
+            rs = row_sums(x)
+            check(_lib.load().apr_kpconv_dfeat(ptr(q_pts.contiguous()), q_pts.shape[0], ptr(s_pts.contiguous()),
+                                               s_pts.shape[0], ptr(inds), inds.shape[1], ptr(dwf), lddwf, cin,
+                                               ptr(kernel_points.contiguous()), kernel_points.shape[0], ctx.extent,
+                                               ptr(rs), ptr(dx), dx.stride(0), stream()))
+        return None, None, None, dx, dw, None, None
+
+
 def gather_pool(x, inds, mode):
     """mode 'max' -> max_pool(x, inds); 'closest' -> closest_pool(x, inds)."""
     inds = _i32(inds, "gather_pool.inds")
@@ -164,5 +206,18 @@ def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=No
     if tracking(x, residual):
         y = instance_norm_rows(x, eps)
         return _act(y if residual is None else y + residual, leaky, relu)
-    scale, shift = ops.norm_params(x, eps)
-    return ops.affine_act(x, scale=scale, shift=shift, residual=residual, relu=relu, leaky=leaky, out=out)
+    x, ldx = ops._rows(x, "instance_norm_act.x")
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    out, ldy = ops._rows(out, "instance_norm_act.out")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = ops._rows(residual, "instance_norm_act.residual")
+    lib = _lib.load()
+    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    mode = 2 if leaky is not None else int(bool(relu))
+    check(lib.apr_instance_norm_act(ptr(x), ldx, n, c, float(eps), ptr(residual), ldr, mode, float(leaky or 0.0),
+                                    ptr(out), ldy, ptr(scratch), sb, stream()))
+    return out

@@ -69,7 +69,11 @@ class KPConv(nn.Module):
 
     def forward(self, q_pts, s_pts, neighb_inds, x):
         if kp_ops.tracking(x, self.weights):
-            return self._forward_autograd(q_pts, s_pts, neighb_inds, x)
+            if self.in_channels % 64 == 0 and neighb_inds.shape[1] <= 128 and self.out_channels % 32 == 0:
+                # training: forward and both gradients on the HIP kernels
+                return kp_ops.KPConvFunction.apply(q_pts, s_pts, neighb_inds, x, self.weights, self.kernel_points,
+                                                   self.KP_extent)
+            return self._forward_autograd(q_pts, s_pts, neighb_inds, x)       # first layer (cin = 1): torch ops
         prof = kp_ops.PROFILE
         if prof is not None:      # bench.py roofline leg: HIP events on the launch stream around the layer's kernels
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -69,7 +69,17 @@ def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, limit=0):
     return out if w == cap else out[:, :w].contiguous()
 
 
-def radius_neighbors_async(queries, supports, q_lengths, s_lengths, radius, limit, flags):
+class SearchGrid:
+    """The scratch buffer of a radius_neighbors_async call, kept so that a second query set can search the same
+    support grid (apr_radius_neighbors_regrid_async)."""
+    __slots__ = ("scratch", "supports", "radius", "ns")
+
+    def __init__(self):
+        self.scratch = self.supports = self.radius = self.ns = None
+
+
+def radius_neighbors_async(queries, supports, q_lengths, s_lengths, radius, limit, flags, keep_grid=None,
+                           grid=None):
     """`radius_neighbors(..., limit)` without a host synchronisation: int32 [Nq, limit] (nearest first, padded with
     len(supports)); `flags` (int32[2] on the device) receives the largest neighbour count and the overflow flag —
     the caller reads them when convenient (`finish_radius_tables`)."""
@@ -82,11 +92,22 @@ def radius_neighbors_async(queries, supports, q_lengths, s_lengths, radius, limi
         raise _lib.AprHipError("radius_neighbors: query / support batch counts differ")
     if limit <= 0 or flags.dtype != torch.int32 or flags.numel() < 2 or not flags.is_contiguous():
         raise _lib.AprHipError("radius_neighbors_async: needs limit > 0 and a contiguous int32[2] flag tensor")
-    sb = int(lib.apr_radius_scratch_bytes(nq, ns))
-    scratch = torch.empty(sb, dtype=torch.uint8, device=queries.device)
     out = torch.empty((nq, int(limit)), dtype=torch.int32, device=queries.device)
+    sb = int(lib.apr_radius_scratch_bytes(nq, ns))
+    if (grid is not None and grid.supports is supports and grid.radius == float(radius) and grid.ns == ns
+            and grid.scratch.numel() >= sb):
+        # `keep_grid` of an earlier call on the same supports / radius: search its grid, no rebuild
+        check(lib.apr_radius_neighbors_regrid_async(ptr(queries), nq, ptr(supports), ns, qp, sp, len(qa), float(radius),
+                                                    int(limit), ptr(out), int(limit), ptr(flags), ptr(grid.scratch),
+                                                    grid.scratch.numel(), stream()))
+        return out
+    if keep_grid is not None:       # room for a later, possibly larger, query set on this grid
+        sb = max(sb, int(lib.apr_radius_scratch_bytes(max(nq, ns), ns)))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=queries.device)
     check(lib.apr_radius_neighbors_async(ptr(queries), nq, ptr(supports), ns, qp, sp, len(qa), float(radius), int(limit),
                                          ptr(out), int(limit), ptr(flags), ptr(scratch), sb, stream()))
+    if keep_grid is not None:
+        keep_grid.scratch, keep_grid.supports, keep_grid.radius, keep_grid.ns = scratch, supports, float(radius), ns
     return out
 
 

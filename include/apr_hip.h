@@ -204,6 +204,14 @@ size_t apr_bn_stats_scratch_bytes(int64_t n, int32_t c);
 int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, float eps, float* scale, float* shift,
                     void* scratch, size_t scratch_bytes, void* stream);
 
+/* apr_norm_params + apr_affine_act in one call and two launches (statistics, then rebuild-and-apply): y = act((x -
+ * mean) / sqrt(var + eps) (+ residual)) per channel over all rows: the InstanceNorm1d + LeakyReLU / residual that
+ * follows every Linear and KPConv of KPFCNN (Predator_APR/models/blocks.py:451-468,499-504,653-681).  51 of them per
+ * forward: the pair path is bound by the host cost of its ~600 launches.  Same scratch as apr_bn_stats. */
+int apr_instance_norm_act(const float* x, int64_t ldx, int64_t n, int32_t c, float eps, const float* residual,
+                          int64_t ldr, int32_t relu, float negative_slope, float* y, int64_t ldy, void* scratch,
+                          size_t scratch_bytes, void* stream);
+
 /* y = act(x * scale[c] + shift[c] (+ residual)); scale/shift/residual nullable.
  * relu: 0 none, 1 ReLU, 2 LeakyReLU(negative_slope) (Predator_APR/models/blocks.py:489,574). */
 int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c,
@@ -353,6 +361,12 @@ int apr_radius_neighbors_async(const float* queries, int64_t nq, const float* su
                                const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb, float radius,
                                int32_t limit, int32_t* out, int64_t out_ld, int32_t* flags_dev,
                                void* scratch, size_t scratch_bytes, void* stream);
+/* Same, searching the grid the PREVIOUS apr_radius_neighbors_async call left in `scratch` (same supports, lengths,
+ * radius and stream): skips the grid build. */
+int apr_radius_neighbors_regrid_async(const float* queries, int64_t nq, const float* supports, int64_t ns,
+                               const int32_t* q_lengths_host, const int32_t* s_lengths_host, int32_t nb, float radius,
+                               int32_t limit, int32_t* out, int64_t out_ld, int32_t* flags_dev,
+                               void* scratch, size_t scratch_bytes, void* stream);
 
 /* k nearest neighbours inside one cloud (brute force, k + skip_first <= 16); replaces the dense
  * square_distance + topk(k+1)[..., 1:] of Predator_APR/models/gcn.py:19-23.  out i32[n,k]. */
@@ -372,6 +386,14 @@ int apr_row_sums(const float* x, int64_t ld, int64_t n, int32_t c, float* out, v
 int apr_kpconv_weighted(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr,
                         int32_t H, const float* x, int64_t ldx, int32_t cin, const float* kernel_points,
                         int32_t n_kp, float extent, const float* rowsum, float* wf, int64_t ldwf, void* stream);
+/* Backward of apr_kpconv_weighted with respect to the neighbour features (training path, SURVEY 8(f) next-3;
+ * Predator_APR/models/blocks.py:326-374 through lib/trainer.py:142-280): dx[nbr[q,h], c] += (1 / num_q) * sum_k
+ * w[q,k,h] * dwf[q, k*cin + c] with float atomics (dx must be zero-initialised; f32 [ns, cin]).  The weight gradient of
+ * the layer is apr_spconv_wgrad on (wf, dout) with the identity map; d wf is a dense apr_spconv_fwd with the transposed
+ * weights.  rowsum: apr_row_sums of the forward's x. */
+int apr_kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr, int32_t H,
+                     const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points, int32_t n_kp,
+                     float extent, const float* rowsum, float* dx, int64_t lddx, void* stream);
 
 /* mode 0: max_pool(x, inds) (blocks.py:86-102); mode 1: closest_pool(x, inds) (blocks.py:71-83).
  * Index ns addresses an implicit all-zero shadow row. */

@@ -177,3 +177,29 @@ def test_kpfcnn_training_path_gradients(dev):
         checked += 1
     # fp32 through ~40 layers of KPConv + instance norms, GPU vs CPU reductions, neighbour order inside distance ties
     assert checked > 50 and worst < 2e-2, (checked, worst)
+
+
+def test_kpconv_backward_kernels_match_autograd_through_oracle(dev):
+    """SURVEY 8(f) next-3, Predator side: d features (apr_kpconv_dfeat, on the forward's neighbour table) and d weights
+    (apr_spconv_wgrad on the recomputed step-1 output) against torch autograd through the CPU oracle's KPConv
+    (= Predator_APR/models/blocks.py:229-374), relative L2 <= 1e-4."""
+    rng = np.random.default_rng(4)
+    for cin, cout, nq, ns, H in [(64, 64, 2500, 2500, 37), (128, 64, 1200, 3000, 40), (256, 256, 600, 600, 58)]:
+        s = torch.from_numpy(rng.uniform(-6, 6, (ns, 3)).astype(np.float32))
+        q = s[:nq].clone() if nq <= ns else torch.from_numpy(rng.uniform(-6, 6, (nq, 3)).astype(np.float32))
+        inds = torch.from_numpy(rng.integers(0, ns + 1, (nq, H)).astype(np.int64))     # ns == shadow
+        d = (s[inds.clamp(max=ns - 1)] - q[:, None]).norm(dim=-1)
+        inds[d > 2.0] = ns
+        x = torch.from_numpy(rng.standard_normal((ns, cin)).astype(np.float32))
+        x[rng.random(ns) < 0.2] *= -1
+        W = torch.from_numpy((rng.standard_normal((15, cin, cout)) / np.sqrt(15 * cin)).astype(np.float32))
+        kp = torch.from_numpy(rng.uniform(-1, 1, (15, 3)).astype(np.float32))
+        proj = torch.from_numpy(rng.standard_normal((nq, cout)).astype(np.float32))
+        xr, Wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        (KO.kpconv(q, s, inds, xr, Wr, kp, 1.2) * proj).sum().backward()
+        xg, Wg = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+        out = kp_ops.KPConvFunction.apply(q.to(dev), s.to(dev), inds.to(dev), xg, Wg, kp.to(dev), 1.2)
+        (out * proj.to(dev)).sum().backward()
+        assert rel_l2(out.detach().cpu(), KO.kpconv(q, s, inds, x, W, kp, 1.2)) < 5e-6
+        assert rel_l2(xg.grad.cpu(), xr.grad) < 1e-4, (cin, cout)
+        assert rel_l2(Wg.grad.cpu(), Wr.grad) < 1e-4, (cin, cout)
