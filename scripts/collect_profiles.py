@@ -3,13 +3,17 @@ usage: python scripts/collect_profiles.py <tag> [prefix=r01]"""
 import csv, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-prefix = sys.argv[2] if len(sys.argv) > 2 else "r01"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join(root, "gpurun_out", f"profile_{tag}")
 dst = os.path.join(root, "profiles")
 pairs = [("bench.json", f"{prefix}_bench.json"), ("bench_s1.json", f"{prefix}_bench_streams1.json"),
          ("stats/b_kernel_stats.csv", f"{prefix}_bench_kernel_stats.csv"),
          ("stats1/b_kernel_stats.csv", f"{prefix}_bench_streams1_kernel_stats.csv"),
-         ("pmc_spconv_summary.json", f"{prefix}_pmc_spconv_summary.json")]
+         ("pmc_spconv_summary.json", f"{prefix}_pmc_spconv_summary.json"),
+         ("pred_stats/p_kernel_stats.csv", f"{prefix}_predator_kernel_stats.csv"),
+         ("predator_profile.log", f"{prefix}_predator_host_profile.log")]
+pairs += [(f"driver_cmd_{i}.json", f"{prefix}_driver_cmd_{i}.json") for i in (1, 2, 3)]
+pairs += [(f"driver_cmd_{i}.log", f"{prefix}_driver_cmd_{i}.log") for i in (1, 2, 3)]
 for a, b in pairs:
     shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
     print("copied", b)
@@ -18,6 +22,8 @@ cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_
 for c, name in (("FETCH_SIZE", "fetch_size"), ("WRITE_SIZE", "write_size")):
     rows = list(csv.DictReader(open(os.path.join(src, f"pmc_{c}", "p_counter_collection.csv"))))
     keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_spconv", "k_ws_"))]   # the sparse-conv kernels
+    prows = list(csv.DictReader(open(os.path.join(src, f"pred_pmc_{c}", "p_counter_collection.csv"))))
+    keep += [r for r in prows if "k_kpconv" in r["Kernel_Name"]]
     with open(os.path.join(dst, f"{prefix}_pmc_{name}_spconv.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(cols)

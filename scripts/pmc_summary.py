@@ -1,39 +1,53 @@
 """Summarise the FETCH_SIZE / WRITE_SIZE passes of scripts/profile_round.sh into HBM bytes per launch of the sparse-conv
-kernels (gfx950 correction: FETCH_SIZE counts 64 B per 128-B request -> x2; WRITE_SIZE exact; both in KB)."""
+kernels (and of the KPConv kernel of the Predator pair).  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request ->
+x2; WRITE_SIZE exact; both in KB (MI355X_MICROARCH.md, HBM).
+
+Every encoder call of the profiled bench command runs the FULL-SIZE workload (12 frames per call): since round 2 the
+bench primes its streams with the timed workload itself, not with a small pair, so the per-launch averages are per
+full-size launch (round 1's figure was diluted 2.8x by 180 small priming launches)."""
 import csv, glob, json, os, sys
 out = sys.argv[1]
-KERNELS = ("k_spconv_pairs", "k_ws_gemm", "k_ws_reduce")
+KERNELS = ("k_spconv_pairs", "k_ws_gemm", "k_ws_reduce", "k_dense_gemm", "k_spconv_smallcin")
 
 
-def per_kernel(counter):
-    files = glob.glob(os.path.join(out, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
-    acc = {k: [0.0, 0] for k in KERNELS}
+def per_kernel(counter, sub, names):
+    files = glob.glob(os.path.join(out, sub.format(counter), "**", "*counter_collection.csv"), recursive=True)
+    acc = {k: [0.0, 0] for k in names}
     for f in files:
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            for k in KERNELS:
+            for k in names:
                 if k in r["Kernel_Name"]:
                     acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     return acc
 
 
-fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
+def table(sub, names):
+    fetch, write = per_kernel("FETCH_SIZE", sub, names), per_kernel("WRITE_SIZE", sub, names)
+    res = {}
+    for k in names:
+        nf, nw = fetch[k][1], write[k][1]
+        if not nf or not nw:
+            continue
+        f_kb, w_kb = fetch[k][0] / nf, write[k][0] / nw
+        res[k] = {"launches": nf, "FETCH_SIZE_avg_KB": f_kb, "WRITE_SIZE_avg_KB": w_kb,
+                  "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024}
+    return res
+
+
 res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 "
-                  "--warmup 2 --streams 1 --no-cpu-baseline --no-roofline   (6 pairs per encoder call, as in the timed "
-                  "run; averages include the priming calls on a small pair)",
+                  "--warmup 2 --streams 1 --no-cpu-baseline --no-roofline --no-workloads   (6 pairs = 12 frames per "
+                  "encoder call, every call full size)",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE "
                      "exact; units KB",
-       "kernels": {}}
-for k in KERNELS:
-    nf, nw = fetch[k][1], write[k][1]
-    if not nf or not nw:
-        continue
-    f_kb, w_kb = fetch[k][0] / nf, write[k][0] / nw
-    res["kernels"][k] = {"launches": nf, "FETCH_SIZE_avg_KB": f_kb, "WRITE_SIZE_avg_KB": w_kb,
-                         "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024}
+       "kernels": table("pmc_{}", KERNELS)}
 ks = res["kernels"]
 if "k_ws_gemm" in ks and "k_ws_reduce" in ks:
     res["kernel"] = "k_ws_gemm+k_ws_reduce (one weight-stationary conv layer = one launch of each)"
     res["hbm_bytes_per_launch"] = ks["k_ws_gemm"]["hbm_bytes_per_launch"] + ks["k_ws_reduce"]["hbm_bytes_per_launch"]
+pk = table("pred_pmc_{}", ("k_kpconv_weighted_mfma", "k_kpconv_weighted_generic"))
+if pk:
+    res["predator_kpconv"] = {"command": "same counters -- python3 scripts/kpconv_bench.py (KPConv step 1 per pyramid "
+                                         "level of one full-size pair, 13 launches per shape)", "kernels": pk}
 print(json.dumps(res, indent=1))

@@ -1,24 +1,36 @@
 #!/bin/bash
-# Round artefacts for profiles/: default bench line, rocprofv3 kernel stats of the default and the single-stream run,
-# and the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in SEPARATE runs, kernel-trace only).  Run on the GPU box:
-#   gpurun -- scripts/profile_round.sh r01        -> gpurun_out/profile_r01/*  (copy what is judged into profiles/)
+# Round artefacts for profiles/: the driver's exact command (3 runs, per-step log), the default bench line, rocprofv3
+# kernel stats of the default and the single-stream run, the HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in
+# SEPARATE runs, kernel-trace only), and the Predator pair (kernel stats + KPConv PMC).  Run on the GPU box:
+#   gpurun -- scripts/profile_round.sh r02        -> gpurun_out/profile_r02/*  (scripts/collect_profiles.py copies
+#   what is judged into profiles/)
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "[profile] default bench"; 
+for i in 1 2 3; do
+  echo "[profile] driver command, run $i"
+  APR_BENCH_STEPLOG=1 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-workloads > $OUT/driver_cmd_$i.json 2> $OUT/driver_cmd_$i.log </dev/null || { echo "driver cmd failed"; tail -5 $OUT/driver_cmd_$i.log; exit 1; }
+done
+echo "[profile] default bench"
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err </dev/null || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "[profile] rocprof stats, default run"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/bench_prof.err </dev/null || { echo "rocprof default failed"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $R/bench.py --no-cpu-baseline --no-workloads > $OUT/bench_prof.json 2> $OUT/bench_prof.err </dev/null || { echo "rocprof default failed"; exit 1; }
 echo "[profile] rocprof stats, single stream"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o b -- python3 $R/bench.py --streams 1 --steps 60 --no-cpu-baseline > $OUT/bench_s1.json 2> $OUT/bench_s1.err </dev/null || { echo "rocprof s1 failed"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o b -- python3 $R/bench.py --streams 1 --steps 60 --no-cpu-baseline --no-workloads > $OUT/bench_s1.json 2> $OUT/bench_s1.err </dev/null || { echo "rocprof s1 failed"; exit 1; }
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "[profile] pmc $C"
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $R/bench.py --steps 4 --warmup 2 --streams 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err </dev/null || { echo "pmc $C failed"; exit 1; }
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $R/bench.py --steps 4 --warmup 2 --streams 1 --no-cpu-baseline --no-roofline --no-workloads > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err </dev/null || { echo "pmc $C failed"; exit 1; }
 done
-python3 $R/scripts/pmc_summary.py $OUT > $OUT/pmc_spconv_summary.json && cat $OUT/pmc_spconv_summary.json | head -30
+echo "[profile] predator pair: kernel stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pred_stats -o p -- python3 $R/scripts/predator_profile.py > $OUT/predator_profile.log 2>&1 </dev/null || { echo "predator stats failed"; exit 1; }
+for C in FETCH_SIZE WRITE_SIZE; do
+  echo "[profile] predator kpconv pmc $C"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pred_pmc_$C -o p -- python3 $R/scripts/kpconv_bench.py > $OUT/pred_pmc_$C.log 2>&1 </dev/null || { echo "kpconv pmc $C failed"; exit 1; }
+done
+python3 $R/scripts/pmc_summary.py $OUT > $OUT/pmc_spconv_summary.json && head -40 $OUT/pmc_spconv_summary.json
 # keep the merge small: traces are large, the stats and counter tables are what is judged
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 echo "[profile] done"
