@@ -338,6 +338,18 @@ class _ConvBase(nn.Module):
             self._packed_key = k
         return self._packed
 
+    def packed_weight_bf3(self):
+        """3-way bf16 split of the kernel for the weight-stationary path (None if the shape is not covered or the
+        split path is switched off with APR_WS_BF3=0)."""
+        import os
+        if os.environ.get("APR_WS_BF3", "1") == "0" or self.kernel.dim() != 3:
+            return None
+        k = (self.kernel.data_ptr(), self.kernel._version, self.kernel.device)
+        if getattr(self, "_bf3_key", None) != k:
+            self._bf3 = ops.pack_weights_bf3(self.kernel)
+            self._bf3_key = k
+        return self._bf3
+
     def _maps(self, x: SparseTensor):
         """-> (nbr or None, out tensor stride)."""
         ts = x.coordinate_map_key.stride
@@ -362,7 +374,8 @@ class _ConvBase(nn.Module):
         fn = ops.spconv if batch is None else batch.add
         return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
                   self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
-                  relu=relu, out=out, n_out=n_out, plist=plist)
+                  relu=relu, out=out, n_out=n_out, plist=plist,
+                  w_bf3=self.packed_weight_bf3() if plist is not None else None)
 
     def _reverse_map(self, x: SparseTensor, nbr_fwd, ts_out):
         """Map of the input gradient: (table, mirrored offsets?)  (backward)."""

@@ -34,7 +34,7 @@ class SpconvDesc(C.Structure):
                 ("w_packed", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("counters", C.c_void_p), ("plist", C.c_void_p), ("prod_scratch", C.c_void_p),
-                ("plist_bytes", C.c_int64)]
+                ("plist_bytes", C.c_int64), ("w_bf3", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
@@ -58,6 +58,10 @@ PROTOTYPES = {
     "apr_pairlist_bytes": (_sz, [_i64, _i32]),
     "apr_pairlist_build": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
     "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
+    "apr_spconv_packed_bf3_bytes": (_i64, [_i32, _i32, _i32]),
+    "apr_spconv_pack_weights_bf3": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "apr_spconv_ws_fwd_bf3": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64,
+                                        _p, _p]),
     "apr_spconv_wgrad_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "apr_spconv_wgrad": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "apr_spconv_fwd_batch": (C.c_int, [_p, _i32, _p]),

@@ -640,8 +640,8 @@ static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e
       if (rcb != APR_OK) return rcb;
     }
     if (e0) APR_HIP(hipEventRecord(e0, st));
-    int rcw = apr_spconv_ws_fwd(d.in, d.ldi, d.counters, d.plist, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.scale, d.shift,
-                                d.residual, d.ldr, d.relu, d.out, d.ldo, d.prod_scratch, stream);
+    int rcw = apr_spconv_ws_fwd_bf3(d.in, d.ldi, d.counters, d.plist, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.w_bf3,
+                                    d.scale, d.shift, d.residual, d.ldr, d.relu, d.out, d.ldo, d.prod_scratch, stream);
     if (rcw != APR_OK) return rcw;
   } else {
     if (e0) APR_HIP(hipEventRecord(e0, st));

@@ -270,6 +270,199 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_ws_gemm_bf3: the same unit structure, with the contraction on the bf16 MFMA in a 3-way split that keeps fp32
+// accuracy.  Exact-fp32 MFMA runs at 1/16 of the bf16 rate on gfx950 and k_ws_gemm sits at 57-68 % of that roof: the
+// remaining lever is fewer MFMA cycles, not better scheduling.  x = hi + mid + lo with three round-to-nearest bf16
+// pieces (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); the subtractions are exact in fp32) carries all 24
+// mantissa bits; of the 9 cross terms of (a_h + a_m + a_l)(w_h + w_m + w_l) the three of order 2^-24 and below
+// (a_m w_l, a_l w_m, a_l w_l) are dropped, the other six run as v_mfma_f32_16x16x32_bf16 (K = 32 per instruction, 16
+// cycles), small terms first, fp32 accumulate.  Per 64-channel chunk and 16-pair group: 48 MFMAs x 16 cycles = 768
+// cycles instead of 64 x 32 = 2048.  Error per product ~2 x 2^-24 relative: the same order as fp32 rounding (tests:
+// features within 2e-5 rel-L2 of the fp32 oracle, measured ~1e-7).
+// The weights are split once at pack time (apr_spconv_pack_weights_bf3) into the exact LDS image of a unit's slice:
+// [k][64-column block][plane h/m/l][32-channel step][column 64][8-channel quad q'][8 bf16], q' = q ^ 3 for columns
+// with bit 3 set: a straight copy stages the slice, and the fragment read (lane (column r16, quad q) -> 16 B) is a
+// conflict-free ds_read_b128 (the 16 lanes of every hardware lane group land in 16 different 16-B slots).
+// The input rows are split in registers after the gather (lane (pair r16, quad q) loads 8 consecutive channels per
+// 32-channel step: two 16-B loads).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline void apr_split3(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& m, bf16x8& l) {
+  const f32x8 x = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  h = __builtin_convertvector(x, bf16x8);
+  const f32x8 r = x - __builtin_convertvector(h, f32x8);
+  m = __builtin_convertvector(r, bf16x8);
+  const f32x8 r2 = r - __builtin_convertvector(m, f32x8);
+  l = __builtin_convertvector(r2, bf16x8);
+}
+
+// w f32 [K, cin, cout] -> wp3 (layout above), one thread per (k, ci, co)
+__global__ void k_pack_weights_bf3(const float* __restrict__ w, int K, int cin, int cout, __bf16* __restrict__ wp3) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * cin * cout;
+  if (t >= total) return;
+  const int co = (int)(t % cout);
+  const int ci = (int)((t / cout) % cin);
+  const int k = (int)(t / ((int64_t)cout * cin));
+  const float x = w[t];
+  const __bf16 h = (__bf16)x;
+  const float r = x - (float)h;
+  const __bf16 m = (__bf16)r;
+  const __bf16 l = (__bf16)(r - (float)m);
+  const int cbk = co >> 6, col = co & 63, s = ci >> 5, q = (ci >> 3) & 3, e = ci & 7;
+  const int qs = (col & 8) ? (q ^ 3) : q;
+  const int nstep = cin >> 5;
+  const int64_t slice = (int64_t)3 * nstep * 64 * 32;                  // bf16 elements of one (k, column block)
+  const int64_t base = ((int64_t)k * (cout >> 6) + cbk) * slice + ((int64_t)s * 64 + col) * 32 + qs * 8 + e;
+  const int64_t plane = (int64_t)nstep * 64 * 32;
+  wp3[base] = h;
+  wp3[base + plane] = m;
+  wp3[base + 2 * plane] = l;
+}
+
+template <int NCH>   // cin / 64: 1, 2 or 4
+__global__ __launch_bounds__(256, 2) void k_ws_gemm_bf3(const float* __restrict__ in, int64_t ldi, PairViews v, int K,
+                                                        int cin, int cout, const __bf16* __restrict__ wp3,
+                                                        float* __restrict__ prod, int n_out, int target_units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];   // [plane 3][step][col 64][quad 4][8 bf16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q = lane >> 4;
+  const int col0 = blockIdx.y * 64;
+  constexpr int nstep = NCH * 2;                       // 32-channel steps
+  constexpr int plane_bytes = nstep * 64 * 64;         // one split plane of the slice
+  constexpr int slice_bytes = 3 * plane_bytes;
+  // unit table in registers (as k_ws_gemm)
+  const int cnt_l = (lane < K) ? v.hdr->cnt[lane * kCntStride] : 0;
+  int P = cnt_l;
+  for (int d = 16; d >= 1; d >>= 1) P += __shfl_xor(P, d);
+  P = __shfl(P, 0);
+  int G = (int)((((int64_t)(P + 63) >> 6) * gridDim.y + target_units - 1) / target_units);
+  G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
+  int span, units, incl;
+  for (;;) {
+    span = 64 * G;
+    units = (cnt_l + span - 1) / span;
+    incl = units;
+    for (int d = 1; d < 32; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (__shfl(incl, 31) <= (int)gridDim.x || G >= kMaxG) break;
+    ++G;
+  }
+  const int total_units = __shfl(incl, 31);
+  // fragment read offset of this lane inside a (step, 16-column block): column r16, swizzled quad
+  const int frag_off = (r16 * 4 + ((r16 & 8) ? (q ^ 3) : q)) * 16;
+
+  for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+    const int k = __popcll(__ballot(lane < K && incl <= unit));
+    const int excl = __builtin_amdgcn_readfirstlane(__shfl(incl - units, k));
+    const int region = k * n_out;
+    const int p_begin = region + (unit - excl) * span;
+    const int p_end = min(p_begin + span, region + __builtin_amdgcn_readfirstlane(__shfl(cnt_l, k)));
+    const int ngroups = (p_end - p_begin + 15) >> 4;
+
+    int g = wave;
+    int my_p = p_begin + g * 16 + r16;
+    const unsigned ldi32 = (unsigned)ldi;
+    unsigned idx = (g < ngroups) ? (unsigned)v.pair_in[my_p < p_end ? my_p : p_begin] : 0u;
+    unsigned idx_n = 0;
+    {
+      const int np = p_begin + (g + 4) * 16 + r16;
+      if (g + 4 < ngroups) idx_n = (unsigned)v.pair_in[np < p_end ? np : p_begin];
+    }
+    {   // stage the slice: a straight copy (the global layout IS the LDS image)
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(wp3) +
+                                 ((int64_t)k * (cout >> 6) + blockIdx.y) * slice_bytes;
+      for (int o0 = tid * 16; o0 < slice_bytes; o0 += 8 * 256 * 16) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (o0 + u * 256 * 16 < slice_bytes) t[u] = *reinterpret_cast<const f32x4*>(src + o0 + u * 256 * 16);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (o0 + u * 256 * 16 < slice_bytes) *reinterpret_cast<f32x4*>(s_raw + o0 + u * 256 * 16) = t[u];
+      }
+    }
+    // rows: lane (pair r16, quad q) holds channels 32 s + 8 q .. + 7 of its pair for the chunk's two steps
+    f32x4 bufA[4], bufB[4];
+    const float* abase = in + (uint64_t)idx * ldi32 + q * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bufA[j] = *reinterpret_cast<const f32x4*>(abase + (j >> 1) * 32 + (j & 1) * 4);
+    __syncthreads();
+
+    const int nsteps = (g < ngroups) ? ((ngroups - g + 3) >> 2) * NCH : 0;
+    int c = 0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define APR_WS3_STEP(cur, nxt)                                                                                    \
+    {                                                                                                             \
+      const bool last = (c + 1 == NCH);                                                                           \
+      const float* nb = last ? in + (uint64_t)idx_n * ldi32 + q * 8 : abase + (c + 1) * 64;                       \
+      const int np2 = p_begin + (g + 8) * 16 + r16;                                                               \
+      const unsigned idx_nn = (unsigned)v.pair_in[np2 < p_end ? np2 : p_begin];                                    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+        nxt[j] = *reinterpret_cast<const f32x4*>(nb + (j >> 1) * 32 + (j & 1) * 4);                               \
+      bf16x8 ah[2], am[2], al[2];                                                                                 \
+      apr_split3(cur[0], cur[1], ah[0], am[0], al[0]);                                                            \
+      apr_split3(cur[2], cur[3], ah[1], am[1], al[1]);                                                            \
+      /* W fragments of (step s, 16-column block cb): three 16-B reads, fetched one (s, cb) ahead of their MFMAs */   \
+      const unsigned char* wb = s_raw + (c * 2 * 64) * 64 + frag_off;                                             \
+      bf16x8 wf[2][3];                                                                                            \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                            \
+        wf[0][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * plane_bytes);                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
+        const int s = i >> 2, cb = i & 3;                                                                         \
+        if (i < 7) {                                                                                              \
+          const int s1 = (i + 1) >> 2, cb1 = (i + 1) & 3;                                                         \
+          _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                        \
+            wf[(i + 1) & 1][pl] =                                                                                 \
+                *reinterpret_cast<const bf16x8*>(wb + (s1 * 64 + cb1 * 16) * 64 + pl * plane_bytes);             \
+          __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                         \
+        const bf16x8 wh = wf[i & 1][0], wm = wf[i & 1][1], wl = wf[i & 1][2];                                     \
+        f32x4 t = acc[cb];                                                                                        \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[s], t, 0, 0, 0);                                       \
+        acc[cb] = t;                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+      }                                                                                                           \
+      if (last) {                                                                                                 \
+        float* dst = prod + (int64_t)(my_p < p_end ? my_p : p_begin) * cout + col0 + q * 4;                       \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                          \
+          __builtin_nontemporal_store(acc[cb], reinterpret_cast<f32x4*>(dst + cb * 16));                         \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};                   \
+        g += 4;                                                                                                   \
+        my_p += 64;                                                                                               \
+        abase = nb;                                                                                               \
+        idx_n = idx_nn;                                                                                           \
+        c = 0;                                                                                                    \
+      } else {                                                                                                    \
+        ++c;                                                                                                      \
+      }                                                                                                           \
+    }
+
+    int s_ = 0;
+    for (; s_ + 2 <= nsteps; s_ += 2) {
+      APR_WS3_STEP(bufA, bufB)
+      APR_WS3_STEP(bufB, bufA)
+    }
+    if (s_ < nsteps) APR_WS3_STEP(bufA, bufB)
+#undef APR_WS3_STEP
+    __syncthreads();   // the slice is re-staged by the next unit
+  }
+}
+
 // All pair ids of the row first, then all product loads in flight at once (exec-masked), summed in offset order:
 // the naive "load id -> branch -> load -> add" loop is a chain of K dependent L2 round trips (~25 us floor).
 template <int KT>
@@ -306,6 +499,20 @@ __global__ __launch_bounds__(256) void k_ws_reduce(const float* __restrict__ pro
 
 }  // namespace
 
+APR_API int64_t apr_spconv_packed_bf3_bytes(int32_t K, int32_t cin, int32_t cout) {
+  return (K >= 1 && cin % 64 == 0 && cout % 64 == 0) ? (int64_t)K * cin * cout * 6 : 0;
+}
+
+APR_API int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream) {
+  APR_CHECK_ARG(w && w_bf3 && K >= 1 && cin % 64 == 0 && cin >= 64 && cin <= 256 && cout % 64 == 0 && cout >= 64,
+                "apr_spconv_pack_weights_bf3: needs cin in {64,128,192,256} and cout %% 64 == 0");
+  const int64_t total = (int64_t)K * cin * cout;
+  hipLaunchKernelGGL(k_pack_weights_bf3, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin,
+                     cout, (__bf16*)w_bf3);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
 APR_API int32_t apr_pairlist_counter_ints(void) { return 32 * kCntStride; }
 
 APR_API size_t apr_pairlist_bytes(int64_t n_out, int32_t K) {
@@ -326,11 +533,10 @@ APR_API int apr_pairlist_build(const int32_t* nbr, int64_t n_out, int32_t K, int
   return APR_OK;
 }
 
-APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
-                              int32_t K, int32_t cin,
-                              int32_t cout, const float* w_packed, const float* scale, const float* shift,
-                              const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
-                              float* prod_scratch, void* stream) {
+static int ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out, int32_t K,
+                  int32_t cin, int32_t cout, const float* w_packed, const void* w_bf3, const float* scale,
+                  const float* shift, const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
+                  float* prod_scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 27, "apr_spconv_ws_fwd: bad n_out / K");
   APR_CHECK_ARG(cin % 64 == 0 && cin <= 512 && cout % 64 == 0,
@@ -367,12 +573,28 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* count
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       s_attr[dev] = true;
     }
   }
+  if (w_bf3 && (cin == 64 || cin == 128 || cin == 256)) {
+    // bf16 3-way split path: slice = cin * 64 * 6 B
+    const size_t lds3 = (size_t)cin * 64 * 6;
+    int64_t per_cu3 = (160 * 1024) / (int64_t)lds3;
+    if (per_cu3 > 8) per_cu3 = 8;
+    int64_t target3 = 256 * per_cu3;
+    if (target3 > s_target) target3 = s_target;
+    int64_t gx3 = cdiv64(target3, cout / 64);
+    if (gx3 > need) gx3 = need;
+    auto k3 = cin == 64 ? k_ws_gemm_bf3<1> : cin == 128 ? k_ws_gemm_bf3<2> : k_ws_gemm_bf3<4>;
+    hipLaunchKernelGGL(k3, dim3((unsigned)gx3, cout / 64), dim3(256), lds3, st, in, ldi, v, K, cin, cout,
+                       (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
+  } else {
   auto kern = cin == 64 ? k_ws_gemm<1> : cin == 128 ? k_ws_gemm<2> : cin == 256 ? k_ws_gemm<4> : k_ws_gemm<0>;
   hipLaunchKernelGGL(kern, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,
                      prod_scratch, (int)n_out, (int)target);
+  }
   const dim3 rgrid((unsigned)cdiv64(n_out * (cout / 4), 256));
   if (K <= 8)
     hipLaunchKernelGGL(k_ws_reduce<8>, rgrid, dim3(256), 0, st, prod_scratch, v, n_out, K, cout, scale, shift, residual,
@@ -385,4 +607,20 @@ APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* count
                        residual, ldr, relu, out, ldo);
   APR_LAUNCH_CHECK();
   return APR_OK;
+}
+
+APR_API int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
+                              int32_t K, int32_t cin, int32_t cout, const float* w_packed, const float* scale,
+                              const float* shift, const float* residual, int64_t ldr, int32_t relu, float* out,
+                              int64_t ldo, float* prod_scratch, void* stream) {
+  return ws_fwd(in, ldi, counters, plist, n_out, K, cin, cout, w_packed, nullptr, scale, shift, residual, ldr, relu, out,
+                ldo, prod_scratch, stream);
+}
+
+APR_API int apr_spconv_ws_fwd_bf3(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
+                                  int32_t K, int32_t cin, int32_t cout, const float* w_packed, const void* w_bf3,
+                                  const float* scale, const float* shift, const float* residual, int64_t ldr,
+                                  int32_t relu, float* out, int64_t ldo, float* prod_scratch, void* stream) {
+  return ws_fwd(in, ldi, counters, plist, n_out, K, cin, cout, w_packed, w_bf3, scale, shift, residual, ldr, relu, out,
+                ldo, prod_scratch, stream);
 }

@@ -221,6 +221,21 @@ def pack_weights(w: torch.Tensor) -> torch.Tensor:
     return wp
 
 
+def pack_weights_bf3(w: torch.Tensor):
+    """[K,cin,cout] fp32 kernel -> the 3-way bf16 split image of apr_spconv_ws_fwd_bf3 (uint8 blob), or None when the
+    shape is not covered (cin not in 64/128/256, cout % 64 != 0)."""
+    w = _f32(w.detach(), "pack_weights_bf3.w")
+    if w.dim() != 3:
+        return None
+    K, cin, cout = w.shape
+    if cin not in (64, 128, 256) or cout % 64 != 0:
+        return None
+    lib = _lib_()
+    blob = torch.empty(int(lib.apr_spconv_packed_bf3_bytes(K, cin, cout)), dtype=torch.uint8, device=w.device)
+    check(lib.apr_spconv_pack_weights_bf3(ptr(w.contiguous()), K, cin, cout, ptr(blob), stream()))
+    return blob
+
+
 class SpconvProfile:
     """Optional per-launch HIP-event timing of the sparse-conv kernel (bench.py roofline leg).
 
@@ -311,7 +326,7 @@ def ws_supported(K, cin, cout):
 
 
 def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
-           plist=None):
+           plist=None, w_bf3=None):
     """out[j] = act((sum_o x[nbr[j,o]] @ W[o]) * scale + shift + residual[j]).
 
     x / residual / out may be column slices of wider row-major buffers.  With `plist` (the PairList of `nbr`)
@@ -347,9 +362,9 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if use_ws:
-        check(_lib_().apr_spconv_ws_fwd(ptr(x), ldi, ptr(plist.counters), ptr(plist.blob), n_out, K, cin, cout, ptr(wp), ptr(scale),
-                                        ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, ptr(prod),
-                                        stream()))
+        check(_lib_().apr_spconv_ws_fwd_bf3(ptr(x), ldi, ptr(plist.counters), ptr(plist.blob), n_out, K, cin, cout, ptr(wp),
+                                            ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr, int(bool(relu)),
+                                            ptr(out), ldo, ptr(prod), stream()))
     else:
         check(_lib_().apr_spconv_fwd(ptr(x), ldi, ptr(nbr), n_out, K, cin, cout, ptr(wp), ptr(scale), ptr(shift),
                                      ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
@@ -417,7 +432,7 @@ class SpconvBatch:
         self.meta = []      # (P, cin, cout, mfma?, path) per launch while a SpconvProfile is active
 
     def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
-            plist=None):
+            plist=None, w_bf3=None):
         x, ldi = _rows(x, "spconv.x")
         if nbr is not None:
             n_out = nbr.shape[0]
@@ -446,13 +461,15 @@ class SpconvBatch:
             if prod is None:
                 prod = self.prod[need] = plist.prod_scratch(cout)
             d.counters, d.plist, d.prod_scratch = plist.counters.data_ptr(), plist.blob.data_ptr(), prod.data_ptr()
+            if w_bf3 is not None:
+                d.w_bf3 = w_bf3.data_ptr()
             if not plist.built:
                 d.plist_bytes, plist.built = plist.blob.numel(), True
         self.descs.append(d)
         if PROFILE is not None:
             self.meta.append((PROFILE.pairs(nbr, n_out), cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0,
                               "ws" if prod is not None else "tile"))
-        self.keep += [x, nbr, wp, scale, shift, residual, out, plist, prod]
+        self.keep += [x, nbr, wp, scale, shift, residual, out, plist, prod, w_bf3]
         return out
 
     def launch(self):

@@ -157,6 +157,17 @@ int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, con
                       int32_t cout, const float* w_packed, const float* scale, const float* shift,
                       const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
                       float* prod_scratch, void* stream);
+/* The same with the per-pair contraction on the bf16 MFMA in a 3-way split (hi/mid/lo bf16 pieces of every fp32
+ * operand, 6 of the 9 cross terms: fp32-equivalent accuracy, ~2e-24 relative per product) - 2.7x fewer MFMA cycles
+ * than the exact-fp32 form, which runs at 1/16 of the bf16 rate on gfx950.  w_bf3: apr_spconv_pack_weights_bf3 of the
+ * layer's [K, cin, cout] kernel (apr_spconv_packed_bf3_bytes bytes; cin in {64, 128, 256}); NULL or another cin falls
+ * back to w_packed / the fp32 form. */
+int64_t apr_spconv_packed_bf3_bytes(int32_t K, int32_t cin, int32_t cout);
+int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream);
+int apr_spconv_ws_fwd_bf3(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
+                          int32_t K, int32_t cin, int32_t cout, const float* w_packed, const void* w_bf3,
+                          const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
+                          float* out, int64_t ldo, float* prod_scratch, void* stream);
 
 /* Weight gradient of apr_spconv_fwd (training; replaces what autograd does inside
  * MinkowskiConvolution / MinkowskiConvolutionTranspose, FCGF_APR/lib/trainer.py:454-527):
@@ -181,6 +192,7 @@ typedef struct apr_spconv_desc {
   void* plist;            /* ... body; non-NULL: run this launch through apr_spconv_ws_fwd with ... */
   float* prod_scratch;    /* ... this product buffer (n_out*K rows); */
   int64_t plist_bytes;    /* > 0: apr_pairlist_build(nbr -> plist) first (first use of the map in the batch) */
+  const void* w_bf3;      /* non-NULL (with plist): apr_spconv_ws_fwd_bf3 with these split weights */
 } apr_spconv_desc;
 int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* stream);
 /* Same, with one HIP event pair per launch recorded on `stream` (around the conv kernels only, not a pair-list

@@ -36,12 +36,13 @@ for name, ti, to, cin, cout, tr in layers:
     nbr = cm.kernel_map(ti, to, 3, tr)
     P = int((nbr >= 0).sum())
     x = torch.randn(cm.size(ti), cin, device=dev)
-    wp = ops.pack_weights(torch.randn(27, cin, cout, device=dev) * 0.05)
+    wraw = torch.randn(27, cin, cout, device=dev) * 0.05
+    wp = ops.pack_weights(wraw)
     out = torch.empty(cm.size(to), cout, device=dev)
-    def batched(plist=None, o=out):      # 20 launches through ONE library call: GPU time, not host time
+    def batched(plist=None, o=out, w3=None):      # 20 launches through ONE library call: GPU time, not host time
         b = ops.SpconvBatch()
         for _ in range(20):
-            b.add(x, nbr, 27, cin, cout, wp, out=o, plist=plist)
+            b.add(x, nbr, 27, cin, cout, wp, out=o, plist=plist, w_bf3=w3)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); b.launch(); e1.record(); torch.cuda.synchronize()
@@ -57,4 +58,11 @@ for name, ti, to, cin, cout, tr in layers:
         us2 = batched(pl, out2)
         err = float((out2 - out).norm() / out.norm())
         line += f" | ws {us2:7.1f} us {2.0*P*cin*cout/us2/1e6:6.1f} TF {(4.0*P*(cin+cout)+8*P)/us2/1e3:6.0f} GB/s  (pairlist build {t_build:5.1f} us, rel diff {err:.1e})"
+        w3 = ops.pack_weights_bf3(wraw)
+        if w3 is not None:
+            out3 = torch.empty_like(out)
+            ops.spconv(x, nbr, 27, cin, cout, wp, out=out3, plist=pl, w_bf3=w3); batched(pl, out3, w3)
+            us3 = batched(pl, out3, w3)
+            err3 = float((out3 - out).norm() / out.norm())
+            line += f" | ws-bf3 {us3:7.1f} us {2.0*P*cin*cout/us3/1e6:6.1f} TF  (rel diff {err3:.1e})"
     print(line, flush=True)
