@@ -273,9 +273,8 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
 // ---------------------------------------------------------------------------------------------------------------
 // k_ws_gemm_bf3: the same unit structure, with the contraction on the bf16 MFMA in a 3-way split that keeps fp32
 // accuracy.  Exact-fp32 MFMA runs at 1/16 of the bf16 rate on gfx950 and k_ws_gemm sits at 57-68 % of that roof: the
-// remaining lever is fewer MFMA cycles, not better scheduling.  x = hi + mid + lo with three round-to-nearest bf16
-// pieces (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); the subtractions are exact in fp32) carries all 24
-// mantissa bits; of the 9 cross terms of (a_h + a_m + a_l)(w_h + w_m + w_l) the three of order 2^-24 and below
+// remaining lever is fewer MFMA cycles, not better scheduling.  x = hi + mid + lo EXACTLY with three bf16 pieces (each
+// the top 8 significant bits of what is left; the subtractions are exact in fp32: all 24 mantissa bits are kept); of the 9 cross terms of (a_h + a_m + a_l)(w_h + w_m + w_l) the three of order 2^-24 and below
 // (a_m w_l, a_l w_m, a_l w_l) are dropped, the other six run as v_mfma_f32_16x16x32_bf16 (K = 32 per instruction, 16
 // cycles), small terms first, fp32 accumulate.  Per 64-channel chunk and 16-pair group: 48 MFMAs x 16 cycles = 768
 // cycles instead of 64 x 32 = 2048.  Error per product ~2 x 2^-24 relative: the same order as fp32 rounding (tests:
@@ -289,13 +288,32 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+// x = h + m + l EXACTLY, each piece the top 8 significant bits of what is left (truncation: an fp32 has 24 significant
+// bits, three 8-bit pieces hold them all; the subtractions are exact).  Pairs of pieces are packed with one byte
+// permute: 2 x (and + sub) per element + 3 permutes per pair = 5.5 VALU per element (the compiler's own
+// float -> bf16 -> float round trips cost ~8.5: one v_cvt_pk per ELEMENT plus unpack and repack).
+__device__ inline unsigned apr_pack_hi16(float x1, float x0) {      // [bf16(x0) | bf16(x1) << 16], truncating
+  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+
 __device__ inline void apr_split3(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& m, bf16x8& l) {
-  const f32x8 x = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  h = __builtin_convertvector(x, bf16x8);
-  const f32x8 r = x - __builtin_convertvector(h, f32x8);
-  m = __builtin_convertvector(r, bf16x8);
-  const f32x8 r2 = r - __builtin_convertvector(m, f32x8);
-  l = __builtin_convertvector(r2, bf16x8);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  u32x4 hp, mp, lp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = x[2 * i], x1 = x[2 * i + 1];
+    hp[i] = apr_pack_hi16(x1, x0);
+    const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
+    const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+    mp[i] = apr_pack_hi16(r1, r0);
+    const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
+    const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    lp[i] = apr_pack_hi16(t1, t0);
+  }
+  h = __builtin_bit_cast(bf16x8, hp);
+  m = __builtin_bit_cast(bf16x8, mp);
+  l = __builtin_bit_cast(bf16x8, lp);
 }
 
 // w f32 [K, cin, cout] -> wp3 (layout above), one thread per (k, ci, co)

@@ -30,11 +30,13 @@ from .residual_block import get_block
 # stages of the fused plan that take the weight-stationary conv path (few pairs per tile, large Cin*Cout); chosen from
 # per-layer timings (scripts/layer_bench.py: tile vs gemm + reduce + pair-list build) and the single-stream step time
 # (scripts/host_vs_gpu.py).  With 12 frames per call: conv3 79 -> 53 + 13 us, conv4 94 -> 56 + 13 us, conv2_tr
-# 204 -> 119 + 19 us; block2_tr (64 channels x 190 k rows, two convs on one pair list) is a draw (2 x 221 vs
-# 2 x 218 + 21 us: its product rows make a round trip through HBM) and stays on the tile kernel, as does the
-# 32-channel level.  Override with APR_WS_STAGES="conv3,block4,..." / "none".
+# 204 -> 119 + 19 us; block2_tr (64 channels x 190 k rows, two convs on one pair list) was a draw on the fp32 MFMA
+# (2 x 221 vs 2 x 218 + 21 us: its product rows make a round trip through HBM); the 32-channel level stays on the
+# tile kernel.  Override with APR_WS_STAGES="conv3,block4,..." / "none".
+# Round 2: with the contraction on the bf16 MFMA (3-way split, spconv_ws.hip) the weight-stationary pair also wins on
+# block2_tr (191 + 10 us of the shared pair-list build against 218 us on the tile kernel): 1906 -> 1964 pairs/s.
 WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", "block3_tr", "conv3", "conv4",
-             "conv2_tr")
+             "conv2_tr", "block2_tr")
 
 
 def _ws_stages():
