@@ -429,22 +429,24 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm_bf3(const float* __restrict_
       bf16x8 ah[2], am[2], al[2];                                                                                 \
       apr_split3(cur[0], cur[1], ah[0], am[0], al[0]);                                                            \
       apr_split3(cur[2], cur[3], ah[1], am[1], al[1]);                                                            \
-      /* W fragments of (step s, 16-column block cb): three 16-B reads, fetched one (s, cb) ahead of their MFMAs */   \
+      /* W fragments of (step s, 16-column block cb): three 16-B reads, fetched TWO (s, cb) ahead of their MFMAs: six  \
+         bf16 MFMAs are only 96 cycles, less than an LDS round trip (the fp32 form has 512 cycles per fragment set) */   \
       const unsigned char* wb = s_raw + (c * 2 * 64) * 64 + frag_off;                                             \
-      bf16x8 wf[2][3];                                                                                            \
-      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                            \
-        wf[0][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * plane_bytes);                                      \
+      bf16x8 wf[3][3];                                                                                            \
+      _Pragma("unroll") for (int i0 = 0; i0 < 2; ++i0)                                                            \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                          \
+          wf[i0][pl] = *reinterpret_cast<const bf16x8*>(wb + ((i0 >> 2) * 64 + (i0 & 3) * 16) * 64 + pl * plane_bytes); \
       __builtin_amdgcn_sched_barrier(0);                                                                          \
       _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
         const int s = i >> 2, cb = i & 3;                                                                         \
-        if (i < 7) {                                                                                              \
-          const int s1 = (i + 1) >> 2, cb1 = (i + 1) & 3;                                                         \
+        if (i < 6) {                                                                                              \
+          const int s2 = (i + 2) >> 2, cb2 = (i + 2) & 3;                                                         \
           _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                        \
-            wf[(i + 1) & 1][pl] =                                                                                 \
-                *reinterpret_cast<const bf16x8*>(wb + (s1 * 64 + cb1 * 16) * 64 + pl * plane_bytes);             \
+            wf[(i + 2) % 3][pl] =                                                                                 \
+                *reinterpret_cast<const bf16x8*>(wb + (s2 * 64 + cb2 * 16) * 64 + pl * plane_bytes);             \
           __builtin_amdgcn_sched_barrier(0);                                                                      \
         }                                                                                                         \
-        const bf16x8 wh = wf[i & 1][0], wm = wf[i & 1][1], wl = wf[i & 1][2];                                     \
+        const bf16x8 wh = wf[i % 3][0], wm = wf[i % 3][1], wl = wf[i % 3][2];                                     \
         f32x4 t = acc[cb];                                                                                        \
         t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[s], t, 0, 0, 0);                                       \
         t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[s], t, 0, 0, 0);                                       \

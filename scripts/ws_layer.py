@@ -21,10 +21,12 @@ cm.build_pyramid([2, 4, 8])
 ti, to, cin, cout, tr = cfg
 nbr = cm.kernel_map(ti, to, 3, tr)
 x = torch.randn(cm.size(ti), cin, device=dev)
-wp = ops.pack_weights(torch.randn(27, cin, cout, device=dev) * 0.05)
+wraw = torch.randn(27, cin, cout, device=dev) * 0.05
+wp = ops.pack_weights(wraw)
+w3 = ops.pack_weights_bf3(wraw) if os.environ.get("APR_WS_BF3", "1") != "0" else None
 out = torch.empty(cm.size(to), cout, device=dev)
 pl = cm.pair_list(ti, to, 3, tr).build()
 for _ in range(10):
-    ops.spconv(x, nbr, 27, cin, cout, wp, out=out, plist=pl)
+    ops.spconv(x, nbr, 27, cin, cout, wp, out=out, plist=pl, w_bf3=w3)
 torch.cuda.synchronize()
 print("done", which, int((nbr >= 0).sum()))
