@@ -1,0 +1,39 @@
+"""Host-side housekeeping shared by the pipelines and bench.py."""
+import os
+
+import torch
+
+_done = False
+
+
+def cpu_quota():
+    """CPUs this process may use: the cgroup v2 / v1 CFS quota if one is set, else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // p)
+    except (OSError, ValueError):
+        pass
+    return len(os.sched_getaffinity(0))
+
+
+def limit_cpu_threads():
+    """torch sizes its intra-op pool from the HOST's core count (128 threads on a 256-core box) even when a cgroup
+    quota allows 16 CPUs: the idle pool threads spin after every small CPU op (a 4x4 pose product is enough), the
+    quota runs out and the kernel throttles the whole process for the rest of the 100 ms period -- measured on the
+    MI355X box as 20-70 ms stalls every few pairs (cpu.stat nr_throttled 82 in a 9 s run, 0 with one thread).  The hot
+    path has no CPU tensor work worth a pool: cap it at a quarter of the quota (once per process)."""
+    global _done
+    if _done:
+        return
+    _done = True
+    cap = max(1, min(8, cpu_quota() // 4))
+    if torch.get_num_threads() > cap:
+        torch.set_num_threads(cap)

@@ -233,6 +233,36 @@ APR_API int apr_instance_norm_act(const float* x, int64_t ldx, int64_t n, int32_
   return APR_OK;
 }
 
+// The same per row segment: seg_offsets_host[s] .. seg_offsets_host[s + 1] are the rows of segment s (a scan PAIR when
+// several pairs are stacked into one KPFCNN forward: the reference normalises over the stacked points of ONE pair,
+// batch size 1, Predator_APR/configs/test/kitti.yaml).  scratch: apr_bn_stats_scratch_bytes(n + 256 * nseg, c).
+APR_API int apr_instance_norm_act_seg(const float* x, int64_t ldx, int64_t n, int32_t c, float eps, const float* residual,
+                                      int64_t ldr, int32_t relu, float negative_slope, float* y, int64_t ldy,
+                                      const int64_t* seg_offsets_host, int32_t nseg, void* scratch, size_t scratch_bytes,
+                                      void* stream) {
+  APR_CHECK_ARG(n > 0 && c > 0 && ldx >= c && ldy >= c && eps >= 0.f && x && y && seg_offsets_host && nseg >= 1,
+                "apr_instance_norm_act_seg: bad arguments");
+  APR_CHECK_ARG(!residual || ldr >= c, "apr_instance_norm_act_seg: ldr < c");
+  APR_CHECK_ARG(seg_offsets_host[0] == 0 && seg_offsets_host[nseg] == n, "apr_instance_norm_act_seg: offsets must run 0 .. n");
+  APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n + 256 * (int64_t)nseg, c),
+                "apr_instance_norm_act_seg: scratch too small");
+  char* sp = (char*)scratch;
+  for (int sgi = 0; sgi < nseg; ++sgi) {
+    const int64_t r0 = seg_offsets_host[sgi], rows = seg_offsets_host[sgi + 1] - r0;
+    APR_CHECK_ARG(rows > 0, "apr_instance_norm_act_seg: empty segment %d", sgi);
+    const int nblk = (int)cdiv64(rows, kRowsPerBlock);
+    const float* xs = x + r0 * ldx;
+    hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, xs, ldx, rows, c,
+                       (double*)sp);
+    hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(rows, 64), (c + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       xs, ldx, rows, c, (const double*)sp, nblk, eps, residual ? residual + r0 * ldr : nullptr, ldr, relu,
+                       negative_slope, y + r0 * ldy, ldy);
+    sp += (size_t)nblk * 2 * (size_t)c * sizeof(double);
+  }
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
 APR_API int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c, const float* scale,
                            const float* shift, const float* residual, int64_t ldr, int32_t relu,
                            float negative_slope, float* y, int64_t ldy, void* stream) {

@@ -109,7 +109,9 @@ __global__ void k_cell_of(const int4* __restrict__ coords, int64_t n, const unsi
 }
 
 // exclusive scan of cnt[0..n) -> start[0..n], single workgroup (n <= a few 10^5)
-__global__ void k_scan_excl(const int* __restrict__ cnt, const int* __restrict__ n_dev, int* __restrict__ start) {
+__global__ void k_scan_excl(const int* __restrict__ cnt, const int* __restrict__ n_dev, int* __restrict__ start,
+                            int* __restrict__ big_count) {
+  if (threadIdx.x == 0) *big_count = 0;   // cells too large for k_barycentre's wave-local sort (listed there)
   __shared__ int wave_sum[16];
   __shared__ int carry_s;
   const int n = *n_dev;
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pt
                                                     const int* __restrict__ n_cells_dev, const int* __restrict__ start,
                                                     int* __restrict__ sorted, const float* __restrict__ feats, int fdim,
                                                     float* __restrict__ out_pts, float* __restrict__ out_feats,
-                                                    int* __restrict__ out_len) {
+                                                    int* __restrict__ out_len, int* __restrict__ big_count,
+                                                    int* __restrict__ big_list) {
   __shared__ int s_raw[4][kCellCap];
   __shared__ int s_ord[4][kCellCap];
   __shared__ int s_hist[kMaxBatch];      // cells per cloud seen by this workgroup (one global atomic per bin at the end;
@@ -194,17 +197,12 @@ __global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pt
       if (lane + 64 * u < m) s_ord[wave][rank[u]] = v[u];
     __builtin_amdgcn_wave_barrier();
     ord = s_ord[wave];
-  } else {   // very dense cell: in-place insertion sort by one lane (rare)
-    if (lane == 0)
-      for (int a = lo + 1; a < hi; ++a) {
-        int v = sorted[a], p = a - 1;
-        while (p >= lo && sorted[p] > v) {
-          sorted[p + 1] = sorted[p];
-          --p;
-        }
-        sorted[p + 1] = v;
-      }
-    ord = sorted + lo;
+  } else {   // very dense cell (an object right at the sensor): left to k_barycentre_big, a whole workgroup per cell
+    if (lane == 0) {
+      big_list[atomicAdd(big_count, 1)] = c;
+      atomicAdd(&s_hist[cell_coords[c].x], 1);
+    }
+    continue;
   }
   // the points of the cell are fetched by all lanes in parallel into LDS (the rank buffer is free again), lane 0 then
   // adds them in index order from LDS: same fp32 sum order as the reference, without one dependent global round
@@ -253,6 +251,101 @@ __global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pt
   }
   __syncthreads();
   if (threadIdx.x < kMaxBatch && s_hist[threadIdx.x]) atomicAdd(&out_len[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+// Cells with more than kCellCap points (listed by k_barycentre): one 1024-thread workgroup per cell sorts the cell's
+// point indices with a bitonic network whose comparators all point the same way (so the padding up to a power of two
+// is virtual: +inf never moves down), in LDS up to kBigLds indices and in place in global memory beyond, then stages
+// the points 1024 at a time in LDS for thread 0 to add in index order -- the same fp32 sum as the reference's
+// sequential loop (grid_subsampling.cpp:60-89), in bounded time: a single lane's insertion sort over 20 k points
+// took a second.
+constexpr int kBigLds = 8192;
+__global__ __launch_bounds__(1024) void k_barycentre_big(const float* __restrict__ pts, const int* __restrict__ big_count,
+                                                         const int* __restrict__ big_list, const int* __restrict__ start,
+                                                         int* __restrict__ sorted, const float* __restrict__ feats,
+                                                         int fdim, float* __restrict__ out_pts,
+                                                         float* __restrict__ out_feats) {
+  __shared__ int s_keys[kBigLds];
+  __shared__ float s_val[3 * 1024];
+  const int nbig = *big_count;
+  const int t = threadIdx.x;
+  for (int b = blockIdx.x; b < nbig; b += gridDim.x) {   // workgroup-uniform
+    const int c = big_list[b];
+    const int lo = start[c], m = start[c + 1] - lo;
+    int* glob = sorted + lo;
+    const bool in_lds = m <= kBigLds;
+    if (in_lds)
+      for (int e = t; e < m; e += 1024) s_keys[e] = glob[e];
+    __syncthreads();
+    int* arr = in_lds ? s_keys : glob;
+    int np2 = 1;
+    while (np2 < m) np2 <<= 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+      // merge of two sorted runs of k/2: first the mirrored comparators, then the half-cleaners
+      for (int i = t; i < (np2 >> 1); i += 1024) {
+        const int blk = i / (k >> 1), off = i - blk * (k >> 1);
+        const int a = blk * k + off, bb = blk * k + k - 1 - off;
+        if (bb < m) {
+          const int va = arr[a], vb = arr[bb];
+          if (va > vb) {
+            arr[a] = vb;
+            arr[bb] = va;
+          }
+        }
+      }
+      __syncthreads();
+      for (int j = k >> 2; j >= 1; j >>= 1) {
+        for (int i = t; i < (np2 >> 1); i += 1024) {
+          const int a = (i / j) * 2 * j + (i % j), bb = a + j;
+          if (bb < m) {
+            const int va = arr[a], vb = arr[bb];
+            if (va > vb) {
+              arr[a] = vb;
+              arr[bb] = va;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int e0 = 0; e0 < m; e0 += 1024) {
+      const int cnt = m - e0 < 1024 ? m - e0 : 1024;
+      if (t < cnt) {
+        const int64_t i = arr[e0 + t];
+        s_val[3 * t] = pts[3 * i];
+        s_val[3 * t + 1] = pts[3 * i + 1];
+        s_val[3 * t + 2] = pts[3 * i + 2];
+      }
+      __syncthreads();
+      if (t == 0)
+        for (int a = 0; a < cnt; ++a) {
+          sx = __fadd_rn(sx, s_val[3 * a]);
+          sy = __fadd_rn(sy, s_val[3 * a + 1]);
+          sz = __fadd_rn(sz, s_val[3 * a + 2]);
+        }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const float inv = (float)(1.0 / (double)m);
+      out_pts[3 * (int64_t)c] = __fmul_rn(sx, inv);
+      out_pts[3 * (int64_t)c + 1] = __fmul_rn(sy, inv);
+      out_pts[3 * (int64_t)c + 2] = __fmul_rn(sz, inv);
+    }
+    for (int f = 0; feats && f < fdim; ++f) {
+      float sacc = 0.f;
+      for (int e0 = 0; e0 < m; e0 += 1024) {
+        const int cnt = m - e0 < 1024 ? m - e0 : 1024;
+        if (t < cnt) s_val[t] = feats[(int64_t)arr[e0 + t] * fdim + f];
+        __syncthreads();
+        if (t == 0)
+          for (int a = 0; a < cnt; ++a) sacc = __fadd_rn(sacc, s_val[a]);
+        __syncthreads();
+      }
+      if (t == 0) out_feats[(int64_t)c * fdim + f] = __fdiv_rn(sacc, (float)m);
+    }
+    __syncthreads();
+  }
 }
 
 // ---- radius search ---------------------------------------------------------------------------
@@ -487,6 +580,7 @@ struct GridWork {
   size_t map_scratch_bytes;
   int* starts_dev;
   float* mins;
+  int* big;   // [0]: number of cells with more than kCellCap points; their ids are listed in `cnt` (dead after the scan)
 };
 
 size_t grid_work_bytes(int64_t n) {
@@ -520,6 +614,7 @@ GridWork carve(void* scratch, int64_t n) {
   w.map_scratch = take(w.map_scratch_bytes);
   w.starts_dev = (int*)take((kMaxBatch + 1) * 4);
   w.mins = (float*)take(kMaxBatch * 12);
+  w.big = (int*)take(256);
   return w;
 }
 
@@ -553,7 +648,7 @@ int build_grid(const float* pts, int64_t n, const int32_t* lengths_host, int nb,
   APR_HIP(hipMemsetAsync(w.cursor, 0, n * 4, st));
   hipLaunchKernelGGL(k_cell_of, dim3(nblk), dim3(kBlock), 0, st, w.coords, n, w.keys, w.vals, (uint32_t)(w.cap - 1),
                      w.cell, w.cnt);
-  hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, w.cnt, w.n_cells, w.start);
+  hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, w.cnt, w.n_cells, w.start, w.big);
   hipLaunchKernelGGL(k_fill, dim3(nblk), dim3(kBlock), 0, st, w.cell, n, w.start, w.cursor, w.sorted);
   APR_LAUNCH_CHECK();
   return APR_OK;
@@ -576,7 +671,9 @@ APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengt
   int* out_len_dev = w.cursor;  // cursor is dead after k_fill; reuse its first nb ints
   APR_HIP(hipMemsetAsync(out_len_dev, 0, kMaxBatch * 4, st));
   hipLaunchKernelGGL(k_barycentre, dim3((unsigned)(cdiv64(n, 4) < 4096 ? cdiv64(n, 4) : 4096)), dim3(256), 0, st, pts, w.cell_coords,
-                     w.n_cells, w.start, w.sorted, feats, fdim, out_pts, out_feats, out_len_dev);
+                     w.n_cells, w.start, w.sorted, feats, fdim, out_pts, out_feats, out_len_dev, w.big, w.cnt);
+  hipLaunchKernelGGL(k_barycentre_big, dim3(64), dim3(1024), 0, st, pts, w.big, w.cnt, w.start, w.sorted, feats, fdim,
+                     out_pts, out_feats);
   APR_LAUNCH_CHECK();
   int status = 0;
   APR_HIP(hipMemcpyAsync(out_lengths_host, out_len_dev, nb * 4, hipMemcpyDeviceToHost, st));

@@ -20,11 +20,12 @@ from __future__ import annotations
 import torch
 
 from .. import MinkowskiEngine as ME
-from .. import ops
+from .. import _host, ops
 
 
 class PairRegistration:
     def __init__(self, model, voxel_size=0.3, ransac_iters=4000000, edge_length=0.9, distance_factor=1.0):
+        _host.limit_cpu_threads()
         self.model = model.eval()
         self.voxel_size = float(voxel_size)
         self.ransac_iters = int(ransac_iters)

@@ -28,19 +28,23 @@ def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_
 
 
 def collate_fn_descriptor(list_data, config, neighborhood_limits):
-    """list_data: [(src_pcd, tgt_pcd, src_feats, tgt_feats, ...extras)] with numpy or tensor clouds."""
-    assert len(list_data) == 1
+    """list_data: [(src_pcd, tgt_pcd, src_feats, tgt_feats, ...extras)] with numpy or tensor clouds.
+
+    The reference collates exactly one pair (dataloader.py:73 asserts it).  Several pairs may be stacked here
+    ([src0, tgt0, src1, tgt1, ...] at every level): neighbourhoods never cross clouds, and the per-level row offsets of
+    the pairs are recorded under 'pair_rows' so that the network keeps its per-pair normalisation statistics and runs
+    its overlap attention pair by pair -- every pair gets the result of its own single-pair batch."""
+    assert len(list_data) >= 1
     item = list_data[0]
-    src_pcd, tgt_pcd, src_feats, tgt_feats = item[:4]
     dev = torch.device('cuda', torch.cuda.current_device())
 
     def to_dev(a):
         a = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
         return a.to(device=dev, dtype=torch.float32)
 
-    batched_points = torch.cat([to_dev(src_pcd), to_dev(tgt_pcd)], 0).contiguous()
-    batched_features = torch.cat([to_dev(src_feats), to_dev(tgt_feats)], 0).contiguous()
-    batched_lengths = torch.tensor([len(src_pcd), len(tgt_pcd)], dtype=torch.int32)
+    batched_points = torch.cat([to_dev(c) for it in list_data for c in it[:2]], 0).contiguous()
+    batched_features = torch.cat([to_dev(f) for it in list_data for f in it[2:4]], 0).contiguous()
+    batched_lengths = torch.tensor([len(c) for it in list_data for c in it[:2]], dtype=torch.int32)
 
     r_normal = config.first_subsampling_dl * config.conv_radius
     layer_blocks, layer = [], 0
@@ -103,6 +107,12 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits):
             lst[i] = t
     out = {'points': input_points, 'neighbors': input_neighbors, 'pools': input_pools, 'upsamples': input_upsamples,
            'features': batched_features, 'stack_lengths': input_batches_len}
+    if len(list_data) > 1:
+        out['pair_rows'] = {}
+        for lens in input_batches_len:
+            ends = np.cumsum(lens.numpy().astype(np.int64))
+            out['pair_rows'][int(ends[-1])] = [0] + [int(v) for v in ends[1::2]]
+        return out
     for key, val in zip(('rot', 'trans', 'correspondences', 'src_pcd_raw', 'tgt_pcd_raw', 'src_nghb', 'tgt_nghb',
                          'sample'), item[4:]):
         out[key] = val

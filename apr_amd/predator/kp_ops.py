@@ -1,6 +1,8 @@
 """Tensor-level wrappers of the KPConv / overlap-attention kernels (all libapr_hip.so calls)."""
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from .. import _lib, ops
@@ -201,11 +203,35 @@ def score_head(x_col):
     return out
 
 
-def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=None):
-    """Per-channel normalisation over all rows, no affine (InstanceNorm1d on [1,C,N]) + activation."""
+def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=None, segments=None):
+    """Per-channel normalisation over all rows, no affine (InstanceNorm1d on [1,C,N]) + activation.
+    `segments`: row offsets [0, ..., n] of the scan pairs stacked in x (one statistic per pair and channel)."""
+    if segments is not None and len(segments) <= 2:
+        segments = None
     if tracking(x, residual):
-        y = instance_norm_rows(x, eps)
+        if segments is None:
+            y = instance_norm_rows(x, eps)
+        else:
+            y = torch.cat([instance_norm_rows(x[a:b], eps) for a, b in zip(segments[:-1], segments[1:])], 0)
         return _act(y if residual is None else y + residual, leaky, relu)
+    if segments is not None:
+        x, ldx = ops._rows(x, "instance_norm_act.x")
+        n, c = x.shape
+        if out is None:
+            out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        out, ldy = ops._rows(out, "instance_norm_act.out")
+        ldr = 0
+        if residual is not None:
+            residual, ldr = ops._rows(residual, "instance_norm_act.residual")
+        lib = _lib.load()
+        nseg = len(segments) - 1
+        sb = int(lib.apr_bn_stats_scratch_bytes(n + 256 * nseg, c))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+        offs = (C.c_int64 * (nseg + 1))(*[int(v) for v in segments])
+        mode = 2 if leaky is not None else int(bool(relu))
+        check(lib.apr_instance_norm_act_seg(ptr(x), ldx, n, c, float(eps), ptr(residual), ldr, mode, float(leaky or 0.0),
+                                            ptr(out), ldy, offs, nseg, ptr(scratch), sb, stream()))
+        return out
     x, ldx = ops._rows(x, "instance_norm_act.x")
     n, c = x.shape
     if out is None:

@@ -98,9 +98,11 @@ class KPFCNN(nn.Module):
 
     def _forward(self, batch, grad):
         x = batch['features'].clone().detach()
-        len_src_c = int(batch['stack_lengths'][-1][0])
+        # rows of the coarsest level: [src, tgt] of one pair (the reference's batch of 1), or of several stacked pairs
+        lens_c = [int(v) for v in batch['stack_lengths'][-1]]
+        if len(lens_c) % 2:
+            raise ValueError("KPFCNN: the batch must hold whole (source, target) pairs")
         pcd_c = batch['points'][-1]
-        src_pcd_c, tgt_pcd_c = pcd_c[:len_src_c], pcd_c[len_src_c:]
 
         # 1. joint encoder
         skip_x = []
@@ -110,32 +112,38 @@ class KPFCNN(nn.Module):
             x = block_op(x, batch)
 
         # 2. bottleneck projection (rows: [N_c, C])
-        feats_c = conv1x1(x, self.bottle, self._c[0])
-        unconditioned_feats = feats_c
+        unconditioned_feats = conv1x1(x, self.bottle, self._c[0])
 
-        # 3. overlap attention between the two clouds
-        src_feats_c, tgt_feats_c = self.gnn(src_pcd_c.contiguous(), tgt_pcd_c.contiguous(),
-                                            feats_c[:len_src_c], feats_c[len_src_c:])
-        feats_c = torch.cat([src_feats_c, tgt_feats_c], dim=0)
-        feats_c = conv1x1(feats_c, self.proj_gnn, self._c[1])
+        # 3./4. per pair: overlap attention between its two clouds, then cross saliency
+        gnn_rows, raw_rows, sal_rows, row0 = [], [], [], 0
+        temperature = (torch.exp(self.epsilon) + 0.03) if grad else float(torch.exp(self.epsilon) + 0.03)
+        for p in range(0, len(lens_c), 2):
+            a, b = row0 + lens_c[p], row0 + lens_c[p] + lens_c[p + 1]
+            src_feats_c, tgt_feats_c = self.gnn(pcd_c[row0:a].contiguous(), pcd_c[a:b].contiguous(),
+                                                unconditioned_feats[row0:a], unconditioned_feats[a:b])
+            gnn_rows += [src_feats_c, tgt_feats_c]
+            row0 = b
+        feats_c = conv1x1(torch.cat(gnn_rows, dim=0), self.proj_gnn, self._c[1])
         scores_c_raw = conv1x1(feats_c, self.proj_score, self._c[2])          # [N_c, 1]
         feats_gnn_norm = (torch.nn.functional.normalize(feats_c, p=2, dim=1) if grad else ops.l2_normalize(feats_c))
         feats_gnn_raw = feats_c
-
-        # 4. cross saliency: softmax(<src, tgt> / T) @ scores, both directions, never forming N x N
-        src_n, tgt_n = feats_gnn_norm[:len_src_c], feats_gnn_norm[len_src_c:]
-        src_s, tgt_s = scores_c_raw[:len_src_c], scores_c_raw[len_src_c:]
-        if grad:    # architectures.py:176-181 (the N_c x N_c product is ~1 k x 1 k at the coarsest level)
-            temperature = torch.exp(self.epsilon) + 0.03
-            inner = torch.matmul(src_n, tgt_n.t())
-            s1 = torch.matmul(torch.softmax(inner / temperature, dim=1), tgt_s)
-            s2 = torch.matmul(torch.softmax(inner.t() / temperature, dim=1), src_s)
-            scores_saliency = torch.cat((s1, s2), dim=0)
-        else:
-            temperature = float(torch.exp(self.epsilon) + 0.03)
-            s1 = kp_ops.softmax_matvec(src_n, tgt_n, tgt_s, temperature)
-            s2 = kp_ops.softmax_matvec(tgt_n, src_n, src_s, temperature)
-            scores_saliency = torch.cat((s1, s2), dim=0).unsqueeze(1)
+        # softmax(<src, tgt> / T) @ scores, both directions, never forming N x N outside autograd
+        row0 = 0
+        for p in range(0, len(lens_c), 2):
+            a, b = row0 + lens_c[p], row0 + lens_c[p] + lens_c[p + 1]
+            src_n, tgt_n = feats_gnn_norm[row0:a], feats_gnn_norm[a:b]
+            src_s, tgt_s = scores_c_raw[row0:a], scores_c_raw[a:b]
+            if grad:    # architectures.py:176-181 (the N_c x N_c product is ~1 k x 1 k at the coarsest level)
+                inner = torch.matmul(src_n, tgt_n.t())
+                sal_rows += [torch.matmul(torch.softmax(inner / temperature, dim=1), tgt_s),
+                             torch.matmul(torch.softmax(inner.t() / temperature, dim=1), src_s)]
+            else:
+                sal_rows += [kp_ops.softmax_matvec(src_n, tgt_n, tgt_s, temperature),
+                             kp_ops.softmax_matvec(tgt_n, src_n, src_s, temperature)]
+            row0 = b
+        scores_saliency = torch.cat(sal_rows, dim=0)
+        if not grad:
+            scores_saliency = scores_saliency.unsqueeze(1)
 
         if self.condition and self.add_cross_overlap:
             x = torch.cat([scores_c_raw, scores_saliency, feats_gnn_raw], dim=1)

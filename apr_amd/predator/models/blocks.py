@@ -113,9 +113,10 @@ class BatchNormBlock(nn.Module):
         else:
             self.bias = Parameter(torch.zeros(in_dim, dtype=torch.float32), requires_grad=True)
 
-    def forward(self, x, leaky=None, residual=None):
+    def forward(self, x, leaky=None, residual=None, segments=None):
         if self.use_bn:
-            return kp_ops.instance_norm_act(x, eps=self.batch_norm.eps, leaky=leaky, residual=residual)
+            return kp_ops.instance_norm_act(x, eps=self.batch_norm.eps, leaky=leaky, residual=residual,
+                                            segments=segments)
         if kp_ops.tracking(x, self.bias, residual):
             y = x + self.bias
             return kp_ops._act(y if residual is None else y + residual, leaky, False)
@@ -142,7 +143,7 @@ class UnaryBlock(nn.Module):
 
     def forward(self, x, batch=None):
         y = self.mlp(x) if kp_ops.tracking(x, self.mlp.weight) else kp_ops.linear(x, self._weight())
-        return self.batch_norm(y, leaky=None if self.no_relu else 0.1)
+        return self.batch_norm(y, leaky=None if self.no_relu else 0.1, segments=pair_segments(batch, y))
 
 
 class LastUnaryBlock(nn.Module):
@@ -160,6 +161,16 @@ class LastUnaryBlock(nn.Module):
             self._packed = kp_ops.pack_linear(self.mlp.weight.detach().t())
             self._key = key
         return kp_ops.linear(x, self._packed)
+
+
+def pair_segments(batch, x):
+    """Row offsets of the scan pairs stacked in `x`, or None for the reference's one pair per batch.  A collate of
+    several pairs (`collate_fn_descriptor` with len(list_data) > 1) records them per level under 'pair_rows', keyed by
+    the level's row count (two levels with the same count hold the same clouds row for row)."""
+    if batch is None:
+        return None
+    table = batch.get('pair_rows')
+    return None if not table else table[int(x.shape[0])]
 
 
 def _layer_inputs(block_name, layer_ind, batch):
@@ -183,7 +194,8 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
-        return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x), leaky=0.1)
+        y = self.KPConv(q_pts, s_pts, inds, x)
+        return self.batch_norm(y, leaky=0.1, segments=pair_segments(batch, y))
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -206,13 +218,16 @@ class ResnetBottleneckBlock(nn.Module):
 
     def forward(self, features, batch):
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
-        x = self.unary1(features)
-        x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x), leaky=0.1)
+        x = self.unary1(features, batch) if isinstance(self.unary1, UnaryBlock) else features
+        x = self.KPConv(q_pts, s_pts, inds, x)
+        seg = pair_segments(batch, x)
+        x = self.batch_norm_conv(x, leaky=0.1, segments=seg)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
-        shortcut = self.unary_shortcut(shortcut)
+        if isinstance(self.unary_shortcut, UnaryBlock):
+            shortcut = self.unary_shortcut(shortcut, batch)
         # unary2 (no ReLU) + shortcut + LeakyReLU fused into the normalisation epilogue
         y = self.unary2.mlp(x) if kp_ops.tracking(x, self.unary2.mlp.weight) else kp_ops.linear(x, self.unary2._weight())
-        return self.unary2.batch_norm(y, leaky=0.1, residual=shortcut)
+        return self.unary2.batch_norm(y, leaky=0.1, residual=shortcut, segments=seg)
 
 
 class NearestUpsampleBlock(nn.Module):

@@ -10,6 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .. import _host
 from . import point_ops
 from .datasets.dataloader import calibrate_neighbors, collate_fn_descriptor   # noqa: F401  (re-exported)
 from .lib import benchmark_utils as BU
@@ -21,6 +22,7 @@ class PredatorRegistration:
         """`neighborhood_limits`: per-level caps of the radius neighbourhoods (the reference calibrates them once per
         dataset, datasets/dataloader.py:calibrate_neighbors); `n_points`: interest points kept per frame
         (configs/test/kitti.yaml n_points)."""
+        _host.limit_cpu_threads()
         self.model = model.eval()
         self.config = config
         self.limits = list(neighborhood_limits)
@@ -40,6 +42,49 @@ class PredatorRegistration:
         batch = collate_fn_descriptor([(src, tgt, ones(src), ones(tgt))], self.config, self.limits)
         feats, overlap, saliency = self.model(batch)
         return src, tgt, feats, overlap, saliency
+
+    @torch.no_grad()
+    def encode_batch(self, pairs):
+        """Several pairs through ONE collate and ONE network forward (their clouds stacked at every level; see
+        `collate_fn_descriptor`).  -> per pair (src points, tgt points, features, overlap, saliency), each what
+        `encode` returns for that pair alone."""
+        dev = pairs[0][0].device
+        clouds = [c for pair in pairs for c in pair]
+        lens = np.array([len(c) for c in clouds], np.int32)
+        pts, lens = point_ops.grid_subsample(torch.cat(clouds), lens, self.voxel_size)
+        ends = np.cumsum(lens)
+        sub = [pts[e - n:e] for e, n in zip(ends, lens)]
+        ones = lambda p: torch.ones((len(p), 1), device=dev)
+        items = [(sub[2 * i], sub[2 * i + 1], ones(sub[2 * i]), ones(sub[2 * i + 1])) for i in range(len(pairs))]
+        feats, overlap, saliency = self.model(collate_fn_descriptor(items, self.config, self.limits))
+        out = []
+        for i in range(len(pairs)):
+            a, b = int(ends[2 * i] - lens[2 * i]), int(ends[2 * i + 1])
+            out.append((sub[2 * i], sub[2 * i + 1], feats[a:b], overlap[a:b], saliency[a:b]))
+        return out
+
+    @torch.no_grad()
+    def register_batch(self, pairs, seeds=None):
+        """[(xyz0, xyz1), ...] -> [(T, info), ...]: one stacked encode, then the reference's per-pair tail
+        (lib/tester.py:80-100: score-weighted draws on the host RNG seeded per pair, feature NN, RANSAC)."""
+        seeds = list(range(len(pairs))) if seeds is None else list(seeds)
+        enc = self.encode_batch(pairs) if len(pairs) > 1 else [self.encode(*pairs[0])]
+        # one device->host copy of every pair's sampling weights
+        w_all = torch.cat([ov * sal for (_, _, _, ov, sal) in enc]).cpu()
+        out, row0 = [], 0
+        for (src, tgt, feats, _, _), seed in zip(enc, seeds):
+            n0, n1 = len(src), len(tgt)
+            rng = np.random.RandomState(seed)
+            w0, w1 = w_all[row0:row0 + n0], w_all[row0 + n0:row0 + n0 + n1]
+            row0 += n0 + n1
+            s_p, s_f, _ = BU.sample_by_score(src, feats[:n0], w0, self.n_points, rng=rng)
+            t_p, t_f, _ = BU.sample_by_score(tgt, feats[n0:], w1, self.n_points, rng=rng)
+            T, info = BU.ransac_pose_estimation(s_p, t_p, s_f, t_f, distance_threshold=self.distance_threshold,
+                                                ransac_n=4, max_iteration=self.max_iteration,
+                                                max_validation=self.max_validation, seed=seed, return_info=True)
+            info.update(n0=n0, n1=n1)
+            out.append((T, info))
+        return out
 
     @torch.no_grad()
     def __call__(self, xyz0, xyz1, seed=0):

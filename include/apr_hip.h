@@ -223,6 +223,13 @@ int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, float eps,
 int apr_instance_norm_act(const float* x, int64_t ldx, int64_t n, int32_t c, float eps, const float* residual,
                           int64_t ldr, int32_t relu, float negative_slope, float* y, int64_t ldy, void* scratch,
                           size_t scratch_bytes, void* stream);
+/* The same per row segment [seg_offsets_host[s], seg_offsets_host[s+1]) (int64, 0 .. n): several scan pairs stacked into
+ * one KPFCNN forward keep the reference's statistics (over the stacked points of ONE pair).  scratch:
+ * apr_bn_stats_scratch_bytes(n + 256 * nseg, c). */
+int apr_instance_norm_act_seg(const float* x, int64_t ldx, int64_t n, int32_t c, float eps, const float* residual,
+                              int64_t ldr, int32_t relu, float negative_slope, float* y, int64_t ldy,
+                              const int64_t* seg_offsets_host, int32_t nseg, void* scratch, size_t scratch_bytes,
+                              void* stream);
 
 /* y = act(x * scale[c] + shift[c] (+ residual)); scale/shift/residual nullable.
  * relu: 0 none, 1 ReLU, 2 LeakyReLU(negative_slope) (Predator_APR/models/blocks.py:489,574). */
@@ -389,6 +396,15 @@ int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t*
  * ---------------------------------------------------------------------- */
 
 /* out[i] = sum_c x[i,c]  (neighbour-count normaliser of KPConv, blocks.py:369-372). */
+/* Host-only (no device needed): ONE round of NumPy's legacy `RandomState.choice(n, size, replace=False, p=p)` loop
+ * (Predator_APR/lib/tester.py:83-92 draws its 5000 interest points per cloud with it).  The caller owns the RNG: per
+ * round it passes k = size - n_uniq uniforms from `random_sample`.  p: float64 working copy (zeroed in place for found
+ * indices; n_new_zeroed = how many of found[0..n_uniq) were added by the previous round); cdf: double[n] work; stamp:
+ * int32[n] work, zero before round 1; round_id = 1, 2, ...  Returns the new n_uniq (loop until it reaches size), or a
+ * negative error code. */
+int64_t apr_weighted_choice_round(double* p, int64_t n, int64_t* found, int64_t n_uniq, int64_t n_new_zeroed,
+                                  const double* x, int64_t k, double* cdf, int32_t* stamp, int32_t round_id);
+
 int apr_row_sums(const float* x, int64_t ld, int64_t n, int32_t c, float* out, void* stream);
 
 /* KPConv step 1 (blocks.py:269-289,326-329,347-372): kernel-point correlation

@@ -30,6 +30,35 @@ def test_grid_subsample_bit_exact_up_to_row_order(dev, seed, dl):
                           REF.canonical_rows(rp, rl).view(np.uint32))
 
 
+def test_grid_subsample_cells_beyond_the_wave_sort(dev):
+    """An object right at the sensor puts thousands of raw points into one 0.3 m cell: cells with more than 1024 points
+    go through the workgroup-wide bitonic sort (LDS up to 8192 points, global memory beyond) and must still give the
+    reference's sequential fp32 sum, in bounded time (a 20 k-point cell used to take a second)."""
+    import time
+    rng = np.random.default_rng(17)
+    a, b, _ = synth.make_pair(3, n_beams=16, n_azimuth=1250)
+    blobs = [rng.uniform(0.02, 0.28, (m, 3)).astype(np.float32) + np.float32(o)
+             for m, o in ((1500, 0.0), (9000, 3.0), (20000, -6.0), (1025, 9.0))]
+    cloud0 = np.concatenate([a] + blobs[:3]).astype(np.float32)
+    cloud0 = cloud0[rng.permutation(len(cloud0))]          # the cell's points are scattered over the index range
+    cloud1 = np.concatenate([b, blobs[3], blobs[2][:5000] + np.float32(1.2)]).astype(np.float32)
+    pts = np.concatenate([cloud0, cloud1])
+    lens = np.array([len(cloud0), len(cloud1)], np.int32)
+    rp, rl = REF.subsample_batch(pts, lens, sampleDl=0.3)
+    tp = torch.from_numpy(pts).to(dev)
+    tf = tp.clone()                     # features = the points: same cells, same order, mean by division
+    point_ops.grid_subsample(tp, lens, 0.3, tf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gp, gl, gf = point_ops.grid_subsample(tp, lens, 0.3, tf)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05
+    assert np.array_equal(gl, rl)
+    assert np.array_equal(REF.canonical_rows(gp.cpu().numpy(), gl).view(np.uint32),
+                          REF.canonical_rows(rp, rl).view(np.uint32))
+    assert torch.allclose(gf, gp, rtol=1e-6, atol=1e-6)
+
+
 def test_subsample_batch_reference_api(dev):
     from apr_amd.predator.cpp_wrappers.cpp_subsampling import grid_subsampling as G
     a = synth.make_small_frame(5)
