@@ -13,6 +13,7 @@
 // stream straight from global memory into MFMA operand registers one chunk ahead, and the epilogue stores 16-B
 // row pieces.  Exact fp32 (v_mfma_f32_16x16x4_f32, D^T form: a lane ends with 4 consecutive channels of one row).
 #include "common.h"
+#include "bf3.h"
 
 namespace {
 
@@ -125,6 +126,141 @@ __global__ __launch_bounds__(256) void k_dense_gemm(const float* __restrict__ in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_dense_gemm_bf3: the same tile (64 G rows x 64 columns per workgroup, cin walked in 64-channel chunks), with the
+// contraction on the bf16 MFMA in the 3-way split of bf3.h (fp32-equivalent: 6 of the 9 cross terms, small terms
+// first, fp32 accumulate -- see spconv_ws.hip).  The exact-fp32 kernel above runs the deep KPConv contractions
+// ([1382, 7680] x [7680, 512], [3770, 3840] x [3840, 256], [9918, 1920] x [1920, 128]: 46 of the ~90 GFLOP of one
+// KPFCNN forward) at 36-44 % of the 157 TFLOP/s fp32-MFMA roof, and the roof itself is the limit: 48 bf16 MFMAs x 16
+// cycles per 16 rows x 64 channels x 64 columns instead of 64 x 32.
+// Weights: apr_spconv_pack_weights_bf3 with K = 1 ([column block][plane h/m/l][32-channel step][col 64][quad'][8]):
+// a chunk is 3 x 8 KB contiguous pieces, staged by straight copies into a double-buffered 2 x 24 KB LDS image; the
+// fragment reads are the conflict-free ds_read_b128 of the sparse kernel.  A rows stream from global memory one chunk
+// ahead (lane (row r16, quad q): 8 consecutive channels per 32-channel step) and are split in registers per step.
+// ---------------------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restrict__ in, int64_t ldi, int M, int cin,
+                                                           int cout, const unsigned char* __restrict__ wp3,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ residual, int64_t ldr, int relu,
+                                                           float* __restrict__ out, int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_w[2][3 * 8192];   // [buf][plane][step 2][col 64][quad 4][16 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q = lane >> 4;
+  const int ncol = cout >> 6;
+  const int tile_m = blockIdx.x / ncol, tile_n = blockIdx.x - tile_m * ncol;
+  const int row0 = tile_m * (64 * G) + wave * (16 * G);
+  const int col0 = tile_n * 64;
+  const int nchunk = cin >> 6;
+  const int64_t plane_bytes = (int64_t)(cin >> 5) * 4096;
+  const unsigned char* wsrc = wp3 + (int64_t)tile_n * 3 * plane_bytes + tid * 16;
+  const int frag_off = (r16 * 4 + ((r16 & 8) ? (q ^ 3) : q)) * 16;
+
+  const float* arow[G];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int r = row0 + gi * 16 + r16;
+    arow[gi] = in + (int64_t)(r < M ? r : M - 1) * ldi + q * 8;
+  }
+  f32x4 abuf[2][G][4];
+  f32x4 acc[G][4];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[gi][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // chunk c of plane pl: 8 KB at pl * plane_bytes + c * 8192; thread t copies 16 B at t * 16 and 4096 + t * 16, by
+  // LDS-DMA (no staging registers: wave-uniform LDS base + lane * 16, which is exactly the straight copy)
+#define APR_DENSE3_STAGE(buf, c)                                                                                   \
+  _Pragma("unroll") for (int u = 0; u < 6; ++u)                                                                    \
+    __builtin_amdgcn_global_load_lds(                                                                              \
+        (const __attribute__((address_space(1))) void*)(wsrc + (int64_t)(c) * 8192 + (u >> 1) * plane_bytes +      \
+                                                         (u & 1) * 4096),                                          \
+        (__attribute__((address_space(3))) void*)&s_w[buf][(u >> 1) * 8192 + (u & 1) * 4096 + wave * 1024], 16, 0, 0);
+  APR_DENSE3_STAGE(0, 0)
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) abuf[0][gi][j] = *reinterpret_cast<const f32x4*>(arow[gi] + (j >> 1) * 32 + (j & 1) * 4);
+  __syncthreads();
+
+#define APR_DENSE3_CHUNK(cur, nxt, c)                                                                              \
+  {                                                                                                                \
+    const bool more = (c) + 1 < nchunk;                                                                            \
+    if (more) {                                                                                                    \
+      APR_DENSE3_STAGE(((c) + 1) & 1, (c) + 1)                                                                     \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                              \
+          abuf[nxt][gi][j] =                                                                                       \
+              *reinterpret_cast<const f32x4*>(arow[gi] + ((c) + 1) * 64 + (j >> 1) * 32 + (j & 1) * 4);            \
+    }                                                                                                              \
+    const unsigned char* wb = &s_w[(c) & 1][frag_off];                                                             \
+    bf16x8 wf[3][3];                                                                                               \
+    _Pragma("unroll") for (int i0 = 0; i0 < 2; ++i0)                                                               \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                             \
+        wf[i0][pl] = *reinterpret_cast<const bf16x8*>(wb + (i0 * 16) * 64 + pl * 8192);                            \
+    bf16x8 ah[G], am[G], al[G];                                                                                    \
+    _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                               \
+      apr_split3(abuf[cur][gi][0], abuf[cur][gi][1], ah[gi], am[gi], al[gi]);                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
+      const int cb = i & 3;                                                                                        \
+      if (i < 6) {                                                                                                 \
+        const int s2 = (i + 2) >> 2, cb2 = (i + 2) & 3;                                                            \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                           \
+          wf[(i + 2) % 3][pl] = *reinterpret_cast<const bf16x8*>(wb + (s2 * 64 + cb2 * 16) * 64 + pl * 8192);      \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+      }                                                                                                            \
+      if (i == 4) {                                                                                                \
+        _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                           \
+          apr_split3(abuf[cur][gi][2], abuf[cur][gi][3], ah[gi], am[gi], al[gi]);                                  \
+      }                                                                                                            \
+      const bf16x8 wh = wf[i % 3][0], wm = wf[i % 3][1], wl = wf[i % 3][2];                                        \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi) {                                                           \
+        f32x4 t = acc[gi][cb];                                                                                     \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[gi], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[gi], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[gi], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[gi], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[gi], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[gi], t, 0, 0, 0);                                       \
+        acc[gi][cb] = t;                                                                                           \
+      }                                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }                                                                                                              \
+    __syncthreads();   /* drains the LDS-DMA of the next chunk (vmcnt(0)) and frees this chunk's buffer */        \
+  }
+
+  int c = 0;
+  for (; c + 2 <= nchunk; c += 2) {
+    APR_DENSE3_CHUNK(0, 1, c)
+    APR_DENSE3_CHUNK(1, 0, c + 1)
+  }
+  if (c < nchunk) APR_DENSE3_CHUNK(0, 1, c)
+#undef APR_DENSE3_CHUNK
+#undef APR_DENSE3_STAGE
+
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int r = row0 + gi * 16 + r16;
+    if (r >= M) continue;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = col0 + cb * 16 + q * 4;
+      f32x4 v = acc[gi][cb];
+      if (scale) v *= *reinterpret_cast<const f32x4*>(scale + col);
+      if (shift) v += *reinterpret_cast<const f32x4*>(shift + col);
+      if (residual) v += *reinterpret_cast<const f32x4*>(residual + (int64_t)r * ldr + col);
+      if (relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(out + (int64_t)r * ldo + col) = v;
+    }
+  }
+}
+
 }  // namespace
 
 // true if the dense kernel takes this shape (the caller has checked the 16-B alignment of in / out / residual rows)
@@ -148,6 +284,34 @@ int apr_internal_dense_gemm(const float* in, int64_t ldi, int64_t M, int32_t cin
   else
     hipLaunchKernelGGL(k_dense_gemm<1>, dim3((unsigned)(cdiv64(M, 64) * ncol)), dim3(256), 0, st, in, ldi, (int)M, cin,
                        cout, wp, scale, shift, residual, ldr, relu, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// The same contraction on the bf16 3-way split (k_dense_gemm_bf3): out = act((in @ W) * scale + shift + residual) for
+// an identity map.  w_bf3: apr_spconv_pack_weights_bf3(w, K = 1, cin, cout).  cin % 64 == 0, cout % 64 == 0, rows of
+// in / out / residual 16-B aligned (ld % 4 == 0).
+APR_API int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const void* w_bf3,
+                               const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
+                               float* out, int64_t ldo, void* stream) {
+  APR_CHECK_ARG(in && out && w_bf3 && M > 0 && M < (1ll << 31) && cin >= 64 && cin % 64 == 0 && cout >= 64 &&
+                    cout % 64 == 0,
+                "apr_dense_gemm_bf3: needs M > 0, cin %% 64 == 0, cout %% 64 == 0");
+  APR_CHECK_ARG(ldi >= cin && ldo >= cout && ldi % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
+                    ((uintptr_t)out & 15) == 0,
+                "apr_dense_gemm_bf3: rows of in / out must be 16-byte aligned");
+  APR_CHECK_ARG(!residual || (ldr >= cout && ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0),
+                "apr_dense_gemm_bf3: residual rows must be 16-byte aligned");
+  APR_CHECK_ARG((!scale || ((uintptr_t)scale & 15) == 0) && (!shift || ((uintptr_t)shift & 15) == 0),
+                "apr_dense_gemm_bf3: scale / shift must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ncol = cout / 64;
+  if (cdiv64(M, 128) * ncol >= 512)
+    hipLaunchKernelGGL(k_dense_gemm_bf3<2>, dim3((unsigned)(cdiv64(M, 128) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
+                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo);
+  else
+    hipLaunchKernelGGL(k_dense_gemm_bf3<1>, dim3((unsigned)(cdiv64(M, 64) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
+                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

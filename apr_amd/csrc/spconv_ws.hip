@@ -18,6 +18,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "bf3.h"
 
 namespace {
 
@@ -285,37 +286,6 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
 // conflict-free ds_read_b128 (the 16 lanes of every hardware lane group land in 16 different 16-B slots).
 // The input rows are split in registers after the gather (lane (pair r16, quad q) loads 8 consecutive channels per
 // 32-channel step: two 16-B loads).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-
-// x = h + m + l EXACTLY, each piece the top 8 significant bits of what is left (truncation: an fp32 has 24 significant
-// bits, three 8-bit pieces hold them all; the subtractions are exact).  Pairs of pieces are packed with one byte
-// permute: 2 x (and + sub) per element + 3 permutes per pair = 5.5 VALU per element (the compiler's own
-// float -> bf16 -> float round trips cost ~8.5: one v_cvt_pk per ELEMENT plus unpack and repack).
-__device__ inline unsigned apr_pack_hi16(float x1, float x0) {      // [bf16(x0) | bf16(x1) << 16], truncating
-  return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-}
-
-__device__ inline void apr_split3(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& m, bf16x8& l) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  u32x4 hp, mp, lp;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x0 = x[2 * i], x1 = x[2 * i + 1];
-    hp[i] = apr_pack_hi16(x1, x0);
-    const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
-    const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
-    mp[i] = apr_pack_hi16(r1, r0);
-    const float t0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
-    const float t1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-    lp[i] = apr_pack_hi16(t1, t0);
-  }
-  h = __builtin_bit_cast(bf16x8, hp);
-  m = __builtin_bit_cast(bf16x8, mp);
-  l = __builtin_bit_cast(bf16x8, lp);
-}
-
 // w f32 [K, cin, cout] -> wp3 (layout above), one thread per (k, ci, co)
 __global__ void k_pack_weights_bf3(const float* __restrict__ w, int K, int cin, int cout, __bf16* __restrict__ wp3) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -524,8 +494,8 @@ APR_API int64_t apr_spconv_packed_bf3_bytes(int32_t K, int32_t cin, int32_t cout
 }
 
 APR_API int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream) {
-  APR_CHECK_ARG(w && w_bf3 && K >= 1 && cin % 64 == 0 && cin >= 64 && cin <= 256 && cout % 64 == 0 && cout >= 64,
-                "apr_spconv_pack_weights_bf3: needs cin in {64,128,192,256} and cout %% 64 == 0");
+  APR_CHECK_ARG(w && w_bf3 && K >= 1 && cin % 64 == 0 && cin >= 64 && cout % 64 == 0 && cout >= 64,
+                "apr_spconv_pack_weights_bf3: needs cin %% 64 == 0 and cout %% 64 == 0");
   const int64_t total = (int64_t)K * cin * cout;
   hipLaunchKernelGGL(k_pack_weights_bf3, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin,
                      cout, (__bf16*)w_bf3);

@@ -107,7 +107,7 @@ class GenerativeMLP(nn.Module):
             m = mods[i]
             if isinstance(m, nn.Linear):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = kp_ops.linear(x, kp_ops.pack_linear(m.weight.detach().t()), shift=m.bias.detach(), relu=relu)
+                x = kp_ops.linear(x, kp_ops.pack_linear(m.weight.detach().t(), bf3=False), shift=m.bias.detach(), relu=relu)
                 i += 2 if relu else 1
             elif isinstance(m, nn.BatchNorm1d):
                 if self.training:

@@ -223,12 +223,13 @@ def pack_weights(w: torch.Tensor) -> torch.Tensor:
 
 def pack_weights_bf3(w: torch.Tensor):
     """[K,cin,cout] fp32 kernel -> the 3-way bf16 split image of apr_spconv_ws_fwd_bf3 (uint8 blob), or None when the
-    shape is not covered (cin not in 64/128/256, cout % 64 != 0)."""
+    shape is not covered (sparse kernels: cin not in 64/128/256; the dense K = 1 form takes any cin % 64 == 0;
+    cout % 64 != 0)."""
     w = _f32(w.detach(), "pack_weights_bf3.w")
     if w.dim() != 3:
         return None
     K, cin, cout = w.shape
-    if cin not in (64, 128, 256) or cout % 64 != 0:
+    if (cin not in (64, 128, 256) and not (K == 1 and cin % 64 == 0 and cin >= 64)) or cout % 64 != 0 or cout < 64:
         return None
     lib = _lib_()
     blob = torch.empty(int(lib.apr_spconv_packed_bf3_bytes(K, cin, cout)), dtype=torch.uint8, device=w.device)
@@ -372,6 +373,23 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         e1.record()
         prof.records.append((P, cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0, e0, e1,
                              "ws" if use_ws else "tile"))
+    return out
+
+
+def dense_gemm_bf3(x, w_bf3, cin, cout, scale=None, shift=None, residual=None, relu=False, out=None):
+    """act((x @ W) * scale + shift + residual) through apr_dense_gemm_bf3; `w_bf3` from pack_weights_bf3(W[None])."""
+    x, ldi = _rows(x, "dense_gemm_bf3.x")
+    if x.shape[1] != cin:
+        raise _lib.AprHipError(f"dense_gemm_bf3: input has {x.shape[1]} channels, weight expects {cin}")
+    n = x.shape[0]
+    if out is None:
+        out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    out, ldo = _rows(out, "dense_gemm_bf3.out")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "dense_gemm_bf3.residual")
+    check(_lib_().apr_dense_gemm_bf3(ptr(x), ldi, n, cin, cout, ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr,
+                                     int(bool(relu)), ptr(out), ldo, stream()))
     return out
 
 

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -62,10 +63,14 @@ def linear(x, wp_info, shift=None, relu=False, out=None):
     Channel counts that are not multiples of 32 (the decoder's 1282->129, 641->64, 320->34, the 256->1 score
     head) run zero-padded: W is padded once at pack time, x / shift per call; the result is a column slice.
     """
-    wp, cin, cout, cin_p, cout_p = wp_info
+    wp, cin, cout, cin_p, cout_p, w_bf3 = wp_info
     if cin_p != cin or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
         x = torch.nn.functional.pad(x, (0, cin_p - cin))
     if cout_p == cout:
+        if w_bf3 is not None and DENSE_BF3 and (out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)) \
+                and (shift is None or shift.data_ptr() % 16 == 0):
+            # fp32-equivalent contraction on the bf16 MFMA (apr_dense_gemm_bf3): 1.5-1.7x the exact-fp32 kernel
+            return ops.dense_gemm_bf3(x, w_bf3, cin_p, cout_p, shift=shift, relu=relu, out=out)
         return ops.spconv(x, None, 1, cin_p, cout_p, wp, shift=shift, relu=relu, out=out, n_out=x.shape[0])
     if shift is not None:
         shift = torch.nn.functional.pad(shift.view(-1), (0, cout_p - cout))
@@ -76,14 +81,20 @@ def linear(x, wp_info, shift=None, relu=False, out=None):
     return y
 
 
-def pack_linear(w_in_out):
-    """[cin, cout] weight -> (packed, cin, cout, cin_padded, cout_padded)."""
+DENSE_BF3 = os.environ.get("APR_DENSE_BF3", "1") != "0"     # A/B switch: 0 keeps every Linear on the exact-fp32 MFMA
+
+
+def pack_linear(w_in_out, bf3=True):
+    """[cin, cout] weight -> (packed, cin, cout, cin_padded, cout_padded, bf16 3-way split image or None).
+    The split image exists when both padded channel counts are multiples of 64 (apr_dense_gemm_bf3)."""
     w = w_in_out.detach().to(torch.float32)
     cin, cout = w.shape
     cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
     if (cin_p, cout_p) != (cin, cout):
         w = torch.nn.functional.pad(w, (0, cout_p - cout, 0, cin_p - cin))
-    return ops.pack_weights(w.contiguous()), cin, cout, cin_p, cout_p
+    w = w.contiguous()
+    w_bf3 = ops.pack_weights_bf3(w[None]) if (bf3 and DENSE_BF3 and cin_p % 64 == 0 and cout_p % 64 == 0) else None
+    return ops.pack_weights(w), cin, cout, cin_p, cout_p, w_bf3
 
 
 def row_sums(x):
@@ -125,7 +136,7 @@ class KPConvFunction(torch.autograd.Function):
         w2 = weights.detach().reshape(K * cin, cout)
         if wf.shape[1] != K * cin:
             w2 = torch.cat([w2, torch.zeros((wf.shape[1] - K * cin, cout), dtype=w2.dtype, device=w2.device)], 0)
-        out = linear(wf, pack_linear(w2))
+        out = linear(wf, pack_linear(w2, bf3=False))
         ctx.save_for_backward(q_pts, s_pts, inds, x, weights, kernel_points)
         ctx.extent = float(extent)
         return out
@@ -140,7 +151,7 @@ class KPConvFunction(torch.autograd.Function):
             wf = kpconv_weighted(q_pts, s_pts, inds, x, kernel_points, ctx.extent)
             dw = ops.spconv_wgrad(wf, dout, None, 1, wf.shape[1], cout)[0, :K * cin].reshape(K, cin, cout)
         if ctx.needs_input_grad[3]:
-            dwf = linear(dout, pack_linear(weights.detach().reshape(K * cin, cout).t().contiguous()))   # [nq, K*cin]
+            dwf = linear(dout, pack_linear(weights.detach().reshape(K * cin, cout).t().contiguous(), bf3=False))   # [nq, K*cin]
             dwf, lddwf = ops._rows(dwf, "kpconv.dwf")
             dx = torch.zeros_like(x)
             rs = row_sums(x)

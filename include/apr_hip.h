@@ -396,6 +396,15 @@ int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t*
  * ---------------------------------------------------------------------- */
 
 /* out[i] = sum_c x[i,c]  (neighbour-count normaliser of KPConv, blocks.py:369-372). */
+/* Dense out = act((in[M, cin] @ W) * scale + shift + residual) on the bf16 MFMA in the 3-way split (fp32-equivalent
+ * accuracy, see apr_spconv_ws_fwd_bf3): the unary / bottleneck Linear layers and KPConv's second step
+ * [N, 15 cin] x [15 cin, cout] of KPFCNN (Predator_APR/models/blocks.py:347-374, 499-504), and K = 1 convolutions.
+ * w_bf3 = apr_spconv_pack_weights_bf3(w, 1, cin, cout).  cin % 64 == 0, cout % 64 == 0; rows of in / out / residual
+ * and scale / shift 16-byte aligned. */
+int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const void* w_bf3,
+                       const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
+                       float* out, int64_t ldo, void* stream);
+
 /* Host-only (no device needed): ONE round of NumPy's legacy `RandomState.choice(n, size, replace=False, p=p)` loop
  * (Predator_APR/lib/tester.py:83-92 draws its 5000 interest points per cloud with it).  The caller owns the RNG: per
  * round it passes k = size - n_uniq uniforms from `random_sample`.  p: float64 working copy (zeroed in place for found
