@@ -6,16 +6,38 @@
 namespace {
 
 constexpr int kRowsPerBlock = 256;
+constexpr int kMaxSeg = 32;
+
+// Row segments normalised independently in ONE launch (blockIdx.z = segment): the scan pairs stacked into one KPFCNN
+// forward.  row0[s] .. row0[s + 1]: rows of segment s; blk0[s]: first 256-row partial block of segment s.
+struct Segs {
+  long long row0[kMaxSeg + 1];
+  int blk0[kMaxSeg + 1];
+};
+
+Segs one_segment(int64_t n) {
+  Segs g;
+  g.row0[0] = 0;
+  g.row0[1] = n;
+  g.blk0[0] = 0;
+  g.blk0[1] = (int)cdiv64(n, kRowsPerBlock);
+  return g;
+}
 
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over this block's rows.
 // 1024 threads = 64 columns x 16 row lanes: a thread sums 16 rows (two batches of 8 independent loads), the 16 row
 // lanes meet in LDS in fixed order.  (256 threads x 64 rows each was a chain of 8 dependent L2 round trips per
 // thread: 18 us per call whatever the size.)
-__global__ __launch_bounds__(1024) void k_bn_partial(const float* __restrict__ x, int64_t ld, int64_t n, int c,
+__global__ __launch_bounds__(1024) void k_bn_partial(const float* __restrict__ x, int64_t ld, int c, Segs sg,
                                                      double* __restrict__ partial) {
   __shared__ double s_sum[16][64], s_sq[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 + tx;
+  const int seg = blockIdx.z;
+  if ((int)blockIdx.x >= sg.blk0[seg + 1] - sg.blk0[seg]) return;        // workgroup-uniform: shorter segment
+  x += sg.row0[seg] * ld;
+  partial += (int64_t)sg.blk0[seg] * 2 * c;
+  const int64_t n = sg.row0[seg + 1] - sg.row0[seg];
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
   const int64_t r1 = min((long long)(r0 + kRowsPerBlock), (long long)n);
   double s = 0.0, s2 = 0.0;
@@ -117,14 +139,22 @@ __global__ void k_affine_act(const float* __restrict__ x, int64_t ldx, int64_t n
 // (scale, shift) from the block partials (every workgroup of a column repeats the same fixed-order sum: a few
 // hundred fp64 adds against a launch, a 4 KB round trip and a host-side call saved per normalisation), then
 // y = act(x * scale + shift (+ residual)).
-__global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
-                                                    const double* __restrict__ partial, int nblk, float eps,
+__global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ x, int64_t ldx, int c, Segs sg,
+                                                    const double* __restrict__ partial, float eps,
                                                     const float* __restrict__ residual, int64_t ldr, int relu,
                                                     float slope, float* __restrict__ y, int64_t ldy) {
   __shared__ double s_a[4][64], s_q[4][64];
   __shared__ float s_scale[64], s_shift[64];
   const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 + tx;
+  const int seg = blockIdx.z;
+  const int64_t n = sg.row0[seg + 1] - sg.row0[seg];
+  if ((int64_t)blockIdx.x * 64 >= n) return;                               // workgroup-uniform: shorter segment
+  const int nblk = sg.blk0[seg + 1] - sg.blk0[seg];
+  x += sg.row0[seg] * ldx;
+  y += sg.row0[seg] * ldy;
+  if (residual) residual += sg.row0[seg] * ldr;
+  partial += (int64_t)sg.blk0[seg] * 2 * c;
   double s = 0.0, s2 = 0.0;
   if (col < c) {
     for (int b0 = grp; b0 < nblk; b0 += 32) {      // same order as k_bn_finish: bit-identical statistics
@@ -197,8 +227,8 @@ APR_API int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c, float
   APR_CHECK_ARG(n > 0 && c > 0 && ld >= c, "apr_bn_stats: bad shape n=%lld c=%d", (long long)n, c);
   APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_bn_stats: scratch too small");
   const int nblk = (int)cdiv64(n, kRowsPerBlock);
-  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, n, c,
-                     (double*)scratch);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, c,
+                     one_segment(n), (double*)scratch);
   hipLaunchKernelGGL(k_bn_finish, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const double*)scratch, nblk, n, c, mean, var, 0.f, (float*)nullptr, (float*)nullptr);
   APR_LAUNCH_CHECK();
@@ -210,8 +240,8 @@ APR_API int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, fl
   APR_CHECK_ARG(n > 0 && c > 0 && ld >= c && eps >= 0.f, "apr_norm_params: bad arguments");
   APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_norm_params: scratch too small");
   const int nblk = (int)cdiv64(n, kRowsPerBlock);
-  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, n, c,
-                     (double*)scratch);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, c,
+                     one_segment(n), (double*)scratch);
   hipLaunchKernelGGL(k_bn_finish, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const double*)scratch, nblk, n, c, (float*)nullptr, (float*)nullptr, eps, scale, shift);
   APR_LAUNCH_CHECK();
@@ -225,10 +255,10 @@ APR_API int apr_instance_norm_act(const float* x, int64_t ldx, int64_t n, int32_
   APR_CHECK_ARG(!residual || ldr >= c, "apr_instance_norm_act: ldr < c");
   APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_instance_norm_act: scratch too small");
   const int nblk = (int)cdiv64(n, kRowsPerBlock);
-  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ldx, n, c,
-                     (double*)scratch);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ldx, c,
+                     one_segment(n), (double*)scratch);
   hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(n, 64), (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x,
-                     ldx, n, c, (const double*)scratch, nblk, eps, residual, ldr, relu, negative_slope, y, ldy);
+                     ldx, c, one_segment(n), (const double*)scratch, eps, residual, ldr, relu, negative_slope, y, ldy);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -246,19 +276,24 @@ APR_API int apr_instance_norm_act_seg(const float* x, int64_t ldx, int64_t n, in
   APR_CHECK_ARG(seg_offsets_host[0] == 0 && seg_offsets_host[nseg] == n, "apr_instance_norm_act_seg: offsets must run 0 .. n");
   APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n + 256 * (int64_t)nseg, c),
                 "apr_instance_norm_act_seg: scratch too small");
-  char* sp = (char*)scratch;
+  APR_CHECK_ARG(nseg <= kMaxSeg, "apr_instance_norm_act_seg: at most %d segments", kMaxSeg);
+  Segs sg;
+  sg.row0[0] = 0;
+  sg.blk0[0] = 0;
+  int64_t max_rows = 0;
   for (int sgi = 0; sgi < nseg; ++sgi) {
-    const int64_t r0 = seg_offsets_host[sgi], rows = seg_offsets_host[sgi + 1] - r0;
+    const int64_t rows = seg_offsets_host[sgi + 1] - seg_offsets_host[sgi];
     APR_CHECK_ARG(rows > 0, "apr_instance_norm_act_seg: empty segment %d", sgi);
-    const int nblk = (int)cdiv64(rows, kRowsPerBlock);
-    const float* xs = x + r0 * ldx;
-    hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, xs, ldx, rows, c,
-                       (double*)sp);
-    hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(rows, 64), (c + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       xs, ldx, rows, c, (const double*)sp, nblk, eps, residual ? residual + r0 * ldr : nullptr, ldr, relu,
-                       negative_slope, y + r0 * ldy, ldy);
-    sp += (size_t)nblk * 2 * (size_t)c * sizeof(double);
+    sg.row0[sgi + 1] = seg_offsets_host[sgi + 1];
+    sg.blk0[sgi + 1] = sg.blk0[sgi] + (int)cdiv64(rows, kRowsPerBlock);
+    if (rows > max_rows) max_rows = rows;
   }
+  // ONE pair of launches for all segments (blockIdx.z): the per-pair statistics cost no extra launches
+  hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)cdiv64(max_rows, kRowsPerBlock), (c + 63) / 64, nseg), dim3(1024), 0,
+                     (hipStream_t)stream, x, ldx, c, sg, (double*)scratch);
+  hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(max_rows, 64), (c + 63) / 64, nseg), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, c, sg, (const double*)scratch, eps, residual, ldr, relu, negative_slope,
+                     y, ldy);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

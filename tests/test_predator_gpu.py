@@ -203,3 +203,33 @@ def test_kpconv_backward_kernels_match_autograd_through_oracle(dev):
         assert rel_l2(out.detach().cpu(), KO.kpconv(q, s, inds, x, W, kp, 1.2)) < 5e-6
         assert rel_l2(xg.grad.cpu(), xr.grad) < 1e-4, (cin, cout)
         assert rel_l2(Wg.grad.cpu(), Wr.grad) < 1e-4, (cin, cout)
+
+
+def test_stacked_pairs_equal_one_pair_at_a_time(dev):
+    """Several pairs through ONE collate + ONE KPFCNN forward (clouds stacked at every level, InstanceNorm statistics
+    per pair through apr_instance_norm_act_seg, overlap attention pair by pair) give every pair the result of its own
+    batch-of-one forward -- the reference's batch size (Predator_APR/configs/test/kitti.yaml batch_size 1) -- up to the
+    fp32 summation order inside a neighbourhood; the registration tail (host-RNG sampling + RANSAC) then returns the
+    same poses."""
+    from apr_amd.predator.pipeline import PredatorRegistration
+    cfg = kitti_config()
+    np.random.seed(2)
+    torch.manual_seed(2)
+    model = KPFCNN(cfg).to(dev).eval()
+    pipe = PredatorRegistration(model, cfg, [38, 36, 36, 38], max_iteration=20000)
+    pairs = []
+    for s in range(3):
+        a, b, _ = synth.make_pair(70 + s, n_beams=32, n_azimuth=700 + 100 * s)
+        pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    single = [pipe.encode(*p) for p in pairs]
+    stacked = pipe.encode_batch(pairs)
+    for one, many in zip(single, stacked):
+        assert torch.equal(one[0], many[0]) and torch.equal(one[1], many[1])          # subsampled clouds
+        assert rel_l2(many[2].cpu().numpy(), one[2].cpu().numpy()) < 2e-5             # features
+        assert torch.allclose(one[3], many[3], atol=2e-5) and torch.allclose(one[4], many[4], atol=2e-5)
+    want = [pipe(*p, seed=11 + i) for i, p in enumerate(pairs)]
+    got = pipe.register_batch(pairs, seeds=[11, 12, 13])
+    for (Ta, ia), (Tb, ib) in zip(want, got):
+        assert ia["n0"] == ib["n0"] and ia["n1"] == ib["n1"]
+        # the draws depend on float32 score ratios: identical unless a last-bit score difference moves a draw
+        assert np.allclose(Ta, Tb, atol=5e-2)
