@@ -219,26 +219,19 @@ __global__ __launch_bounds__(256) void k_barycentre(const float* __restrict__ pt
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane != 0) continue;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  if (staged) {
-    for (int a = 0; a < m; ++a) {
-      sx = __fadd_rn(sx, s_val[3 * a]);
-      sy = __fadd_rn(sy, s_val[3 * a + 1]);
-      sz = __fadd_rn(sz, s_val[3 * a + 2]);
+  // lanes 0, 1, 2 add x, y, z: three independent chains in ONE instruction stream (a lone lane running the three
+  // chains one after the other issues 3x the instructions; each wave64 instruction costs 4 cycles whatever the mask)
+  if (lane < 3) {
+    float acc1 = 0.f;
+    if (staged) {
+      for (int a = 0; a < m; ++a) acc1 = __fadd_rn(acc1, s_val[3 * a + lane]);
+    } else {
+      for (int a = 0; a < m; ++a) acc1 = __fadd_rn(acc1, pts[3 * (int64_t)ord[a] + lane]);
     }
-  } else {
-    for (int a = 0; a < m; ++a) {
-      const int64_t i = ord[a];
-      sx = __fadd_rn(sx, pts[3 * i]);
-      sy = __fadd_rn(sy, pts[3 * i + 1]);
-      sz = __fadd_rn(sz, pts[3 * i + 2]);
-    }
+    const float inv = (float)(1.0 / (double)m);
+    out_pts[3 * (int64_t)c + lane] = __fmul_rn(acc1, inv);
   }
-  const float inv = (float)(1.0 / (double)m);
-  out_pts[3 * (int64_t)c] = __fmul_rn(sx, inv);
-  out_pts[3 * (int64_t)c + 1] = __fmul_rn(sy, inv);
-  out_pts[3 * (int64_t)c + 2] = __fmul_rn(sz, inv);
+  if (lane != 0) continue;
   if (feats) {
     const float fc = (float)m;
     for (int f = 0; f < fdim; ++f) {
@@ -308,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_barycentre_big(const float* __restrict
         __syncthreads();
       }
     }
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    float acc1 = 0.f;     // threads 0, 1, 2: the x, y, z chains
     for (int e0 = 0; e0 < m; e0 += 1024) {
       const int cnt = m - e0 < 1024 ? m - e0 : 1024;
       if (t < cnt) {
@@ -318,20 +311,11 @@ __global__ __launch_bounds__(1024) void k_barycentre_big(const float* __restrict
         s_val[3 * t + 2] = pts[3 * i + 2];
       }
       __syncthreads();
-      if (t == 0)
-        for (int a = 0; a < cnt; ++a) {
-          sx = __fadd_rn(sx, s_val[3 * a]);
-          sy = __fadd_rn(sy, s_val[3 * a + 1]);
-          sz = __fadd_rn(sz, s_val[3 * a + 2]);
-        }
+      if (t < 3)
+        for (int a = 0; a < cnt; ++a) acc1 = __fadd_rn(acc1, s_val[3 * a + t]);
       __syncthreads();
     }
-    if (t == 0) {
-      const float inv = (float)(1.0 / (double)m);
-      out_pts[3 * (int64_t)c] = __fmul_rn(sx, inv);
-      out_pts[3 * (int64_t)c + 1] = __fmul_rn(sy, inv);
-      out_pts[3 * (int64_t)c + 2] = __fmul_rn(sz, inv);
-    }
+    if (t < 3) out_pts[3 * (int64_t)c + t] = __fmul_rn(acc1, (float)(1.0 / (double)m));
     for (int f = 0; feats && f < fdim; ++f) {
       float sacc = 0.f;
       for (int e0 = 0; e0 < m; e0 += 1024) {

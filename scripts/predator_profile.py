@@ -1,39 +1,31 @@
-"""Host (cProfile) + device (caller runs under rocprofv3) view of one Predator pair."""
+"""Host (cProfile) + device (caller runs under rocprofv3) view of the Predator path: 8 distinct synthetic pairs,
+4 pairs stacked per collate / KPFCNN forward (PredatorRegistration.register_batch), ONE host thread and stream so
+that the kernel table reads per pair (40 pairs under the profiler: divide Calls and TotalDurationNs by 40)."""
 import sys, os, time, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from apr_amd import synth
-from apr_amd.predator import point_ops
 from apr_amd.predator.configs.models import kitti_config
-from apr_amd.predator.datasets.dataloader import collate_fn_descriptor
-from apr_amd.predator.lib import benchmark_utils as BU
 from apr_amd.predator.models.architectures import KPFCNN
+from apr_amd.predator.pipeline import PredatorRegistration
 LIMITS = [58, 59, 58, 57]
 dev = torch.device("cuda:0")
 np.random.seed(0); torch.manual_seed(0)
 cfg = kitti_config()
-model = KPFCNN(cfg).to(dev).eval()
-a, b, T = synth.make_pair(0)
-ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+pipe = PredatorRegistration(KPFCNN(cfg).to(dev).eval(), cfg, LIMITS)
+pairs = []
+for s in range(8):
+    a, b, _ = synth.make_pair(s)
+    pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
 
-@torch.no_grad()
-def one(rep):
-    pts, lens = point_ops.grid_subsample(torch.cat([ta, tb]), np.array([len(a), len(b)], np.int32), 0.3)
-    src, tgt = pts[:lens[0]], pts[lens[0]:]
-    ones = lambda p: torch.ones((len(p), 1), device=dev)
-    batch = collate_fn_descriptor([(src, tgt, ones(src), ones(tgt))], cfg, LIMITS)
-    feats, ov, sal = model(batch)
-    n0 = int(lens[0])
-    np.random.seed(rep)
-    s_p, s_f, _ = BU.sample_by_score(src, feats[:n0], ov[:n0] * sal[:n0], 5000)
-    t_p, t_f, _ = BU.sample_by_score(tgt, feats[n0:], ov[n0:] * sal[n0:], 5000)
-    return BU.ransac_pose_estimation(s_p, t_p, s_f, t_f, distance_threshold=0.3, ransac_n=4, seed=rep, return_info=True)
+def sweep(n):
+    for r in range(n):
+        pipe.register_batch(pairs[:4], seeds=range(4))
+        pipe.register_batch(pairs[4:], seeds=range(4, 8))
+    torch.cuda.synchronize()
 
-for r in range(3): one(r)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for r in range(10): one(r)
-torch.cuda.synchronize(); print("ms/pair", (time.perf_counter() - t0) * 100)
-pr = cProfile.Profile(); pr.enable()
-for r in range(10): one(r)
-torch.cuda.synchronize(); pr.disable()
+sweep(1)
+t0 = time.perf_counter(); sweep(2); print("ms/pair (4 stacked, one thread)", (time.perf_counter() - t0) / 16 * 1e3)
+pr = cProfile.Profile(); pr.enable(); sweep(2); pr.disable()
+print("pairs run under the profiler: 40")
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
