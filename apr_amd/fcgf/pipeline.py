@@ -177,8 +177,12 @@ def run_pipelined(make_step, indices, streams):
     results, done_at = {}, []
     exhausted = False
 
+    host_busy = 0.0                        # seconds spent inside the generators (enqueueing), not waiting
+
     def advance(s):
+        nonlocal host_busy
         i, gen, _ = slots[s]
+        t_in = time.perf_counter()
         with torch.cuda.stream(streams[s]):
             try:
                 slots[s] = (i, gen, next(gen))
@@ -186,6 +190,7 @@ def run_pipelined(make_step, indices, streams):
                 results[i] = stop.value
                 done_at.append((i, time.perf_counter()))
                 slots[s] = None
+        host_busy += time.perf_counter() - t_in
 
     while True:
         moved = False
@@ -206,6 +211,7 @@ def run_pipelined(make_step, indices, streams):
                 moved = True
         live = [sl for sl in slots if sl is not None]
         if not live and exhausted:
+            run_pipelined.last_host_busy_s = host_busy      # read by bench.py (host enqueue time per step)
             return results, done_at
         if not moved and live:
             min(live, key=lambda sl: sl[0])[2].event.synchronize()      # nothing ready: wait for the oldest step

@@ -424,6 +424,8 @@ def main():
     threads = [] if pipelined else [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(nstreams)]
     [t.start() for t in threads]
 
+    host_busy = {"s": None, "steps": 0}     # time the scheduling thread spent enqueueing (inside the generators)
+
     def make_step(i):
         batch = [pairs[(i * B + j) % len(pairs)] for j in range(B)]
         return pipe.register_batch_phases(batch, seeds=[i * B + j for j in range(B)])
@@ -432,6 +434,7 @@ def main():
         if pipelined:       # one host thread, `nstreams` steps in flight (apr_amd.fcgf.pipeline.run_pipelined)
             from apr_amd.fcgf.pipeline import run_pipelined
             res, done_at = run_pipelined(make_step, range(first, last), streams)
+            host_busy["s"], host_busy["steps"] = run_pipelined.last_host_busy_s, last - first
             for i, r in res.items():
                 results[i] = r[-1]
             step_log.extend((i, 0, t, t) for i, t in done_at)
@@ -510,6 +513,8 @@ def main():
                    "pairs_per_step": B, "streams_per_gpu": nstreams,
                    "host": "one thread, steps resumed on fetch completion" if pipelined else f"{nstreams} threads",
                    "sharding": f"{world} ranks x independent pairs",
+                   "host_enqueue_ms_per_step": (None if host_busy["s"] is None
+                                                else 1e3 * host_busy["s"] / max(host_busy["steps"], 1)),
                    "pool_pairs": npool, "ransac_valid_hypotheses_last_pair": int(info["n_valid"]),
                    "per_rank_pairs_per_s": [float(r[0] / r[1]) for r in stats.tolist()]},
     }
