@@ -7,6 +7,8 @@ unchanged.  `batch` is the dict built by `collate_fn_descriptor` (points / neigh
 upsamples / stack_lengths / features), index tensors int32 or int64, everything on the GPU.
 """
 import numpy as np
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -62,6 +64,20 @@ def plan_architecture(config):
     return enc, dec, skips, skip_widths, concats, bottleneck
 
 
+_SIDE = threading.local()
+
+
+def _side_streams(device, n):
+    """Per host thread and device: n streams for the per-pair attention blocks of a stacked batch."""
+    pool = getattr(_SIDE, "pool", None)
+    if pool is None:
+        pool = _SIDE.pool = {}
+    lst = pool.setdefault(device, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=device))
+    return lst
+
+
 class KPFCNN(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -114,15 +130,31 @@ class KPFCNN(nn.Module):
         # 2. bottleneck projection (rows: [N_c, C])
         unconditioned_feats = conv1x1(x, self.bottle, self._c[0])
 
-        # 3./4. per pair: overlap attention between its two clouds, then cross saliency
+        # 3./4. per pair: overlap attention between its two clouds, then cross saliency.  The coarsest level holds
+        # ~1.4 k points per pair: every kernel of the attention block is a few workgroups running serial loops, so the
+        # pairs of a stacked batch go to side streams and run side by side (forked from / joined to the caller's stream)
         gnn_rows, raw_rows, sal_rows, row0 = [], [], [], 0
         temperature = (torch.exp(self.epsilon) + 0.03) if grad else float(torch.exp(self.epsilon) + 0.03)
-        for p in range(0, len(lens_c), 2):
+        npairs = len(lens_c) // 2
+        side = _side_streams(pcd_c.device, npairs) if (npairs > 1 and not grad) else None
+        main = torch.cuda.current_stream() if side else None
+        for pi, p in enumerate(range(0, len(lens_c), 2)):
             a, b = row0 + lens_c[p], row0 + lens_c[p] + lens_c[p + 1]
-            src_feats_c, tgt_feats_c = self.gnn(pcd_c[row0:a].contiguous(), pcd_c[a:b].contiguous(),
-                                                unconditioned_feats[row0:a], unconditioned_feats[a:b])
+            if side:
+                side[pi].wait_stream(main)
+                with torch.cuda.stream(side[pi]):
+                    src_feats_c, tgt_feats_c = self.gnn(pcd_c[row0:a].contiguous(), pcd_c[a:b].contiguous(),
+                                                        unconditioned_feats[row0:a], unconditioned_feats[a:b])
+                src_feats_c.record_stream(main)
+                tgt_feats_c.record_stream(main)
+            else:
+                src_feats_c, tgt_feats_c = self.gnn(pcd_c[row0:a].contiguous(), pcd_c[a:b].contiguous(),
+                                                    unconditioned_feats[row0:a], unconditioned_feats[a:b])
             gnn_rows += [src_feats_c, tgt_feats_c]
             row0 = b
+        if side:
+            for st in side[:npairs]:
+                main.wait_stream(st)
         feats_c = conv1x1(torch.cat(gnn_rows, dim=0), self.proj_gnn, self._c[1])
         scores_c_raw = conv1x1(feats_c, self.proj_score, self._c[2])          # [N_c, 1]
         feats_gnn_norm = (torch.nn.functional.normalize(feats_c, p=2, dim=1) if grad else ops.l2_normalize(feats_c))
@@ -137,10 +169,22 @@ class KPFCNN(nn.Module):
                 inner = torch.matmul(src_n, tgt_n.t())
                 sal_rows += [torch.matmul(torch.softmax(inner / temperature, dim=1), tgt_s),
                              torch.matmul(torch.softmax(inner.t() / temperature, dim=1), src_s)]
+            elif side:
+                pi = p // 2
+                side[pi].wait_stream(main)
+                with torch.cuda.stream(side[pi]):
+                    s12 = [kp_ops.softmax_matvec(src_n, tgt_n, tgt_s, temperature),
+                           kp_ops.softmax_matvec(tgt_n, src_n, src_s, temperature)]
+                for t_ in s12:
+                    t_.record_stream(main)
+                sal_rows += s12
             else:
                 sal_rows += [kp_ops.softmax_matvec(src_n, tgt_n, tgt_s, temperature),
                              kp_ops.softmax_matvec(tgt_n, src_n, src_s, temperature)]
             row0 = b
+        if side:
+            for st in side[:npairs]:
+                main.wait_stream(st)
         scores_saliency = torch.cat(sal_rows, dim=0)
         if not grad:
             scores_saliency = scores_saliency.unsqueeze(1)
