@@ -7,6 +7,7 @@ namespace {
 
 constexpr int kRowsPerBlock = 256;
 constexpr int kMaxSeg = 32;
+constexpr int kApplyRows = 256;   // rows per k_norm_apply workgroup (the statistics prelude is paid once per workgroup)
 
 // Row segments normalised independently in ONE launch (blockIdx.z = segment): the scan pairs stacked into one KPFCNN
 // forward.  row0[s] .. row0[s + 1]: rows of segment s; blk0[s]: first 256-row partial block of segment s.
@@ -144,12 +145,13 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ x,
                                                     const float* __restrict__ residual, int64_t ldr, int relu,
                                                     float slope, float* __restrict__ y, int64_t ldy) {
   __shared__ double s_a[4][64], s_q[4][64];
-  __shared__ float s_scale[64], s_shift[64];
+  __shared__ __attribute__((aligned(16))) float s_scale[64];
+  __shared__ __attribute__((aligned(16))) float s_shift[64];
   const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 + tx;
   const int seg = blockIdx.z;
   const int64_t n = sg.row0[seg + 1] - sg.row0[seg];
-  if ((int64_t)blockIdx.x * 64 >= n) return;                               // workgroup-uniform: shorter segment
+  if ((int64_t)blockIdx.x * kApplyRows >= n) return;                       // workgroup-uniform: shorter segment
   const int nblk = sg.blk0[seg + 1] - sg.blk0[seg];
   x += sg.row0[seg] * ldx;
   y += sg.row0[seg] * ldy;
@@ -187,10 +189,33 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ x,
     s_shift[tx] = -mf * sc;
   }
   __syncthreads();
+  // apply: the workgroup's kApplyRows x 64 slab, 16 B per lane where the rows allow it (thread = 4 columns x one row
+  // of every 16), else 4 B per lane
+  const int64_t r0 = (int64_t)blockIdx.x * kApplyRows;
+  const int64_t r1 = min((long long)(r0 + kApplyRows), (long long)n);
+  const bool vec = (c & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (!residual || (ldr & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                     reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  if (vec) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int c4 = (threadIdx.x & 15) * 4, rr = threadIdx.x >> 4;          // 16 lanes x 4 columns, 16 rows per pass
+    const int colv = blockIdx.y * 64 + c4;
+    if (colv >= c) return;
+    const f32x4 scv = *reinterpret_cast<const f32x4*>(&s_scale[c4]), shv = *reinterpret_cast<const f32x4*>(&s_shift[c4]);
+    for (int64_t r = r0 + rr; r < r1; r += 16) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + colv) * scv + shv;
+      if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * ldr + colv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (relu == 1) v[e] = fmaxf(v[e], 0.f);
+        else if (relu == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+      }
+      *reinterpret_cast<f32x4*>(y + r * ldy + colv) = v;
+    }
+    return;
+  }
   if (col >= c) return;
   const float sc = s_scale[tx], sh = s_shift[tx];
-  const int64_t r0 = (int64_t)blockIdx.x * 64;
-  const int64_t r1 = min((long long)(r0 + 64), (long long)n);
   for (int64_t r = r0 + grp; r < r1; r += 4) {
     float v = x[r * ldx + col] * sc + sh;
     if (residual) v += residual[r * ldr + col];
@@ -257,7 +282,7 @@ APR_API int apr_instance_norm_act(const float* x, int64_t ldx, int64_t n, int32_
   const int nblk = (int)cdiv64(n, kRowsPerBlock);
   hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ldx, c,
                      one_segment(n), (double*)scratch);
-  hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(n, 64), (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(n, kApplyRows), (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, x,
                      ldx, c, one_segment(n), (const double*)scratch, eps, residual, ldr, relu, negative_slope, y, ldy);
   APR_LAUNCH_CHECK();
   return APR_OK;
@@ -291,7 +316,7 @@ APR_API int apr_instance_norm_act_seg(const float* x, int64_t ldx, int64_t n, in
   // ONE pair of launches for all segments (blockIdx.z): the per-pair statistics cost no extra launches
   hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)cdiv64(max_rows, kRowsPerBlock), (c + 63) / 64, nseg), dim3(1024), 0,
                      (hipStream_t)stream, x, ldx, c, sg, (double*)scratch);
-  hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(max_rows, 64), (c + 63) / 64, nseg), dim3(256), 0,
+  hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(max_rows, kApplyRows), (c + 63) / 64, nseg), dim3(256), 0,
                      (hipStream_t)stream, x, ldx, c, sg, (const double*)scratch, eps, residual, ldr, relu, negative_slope,
                      y, ldy);
   APR_LAUNCH_CHECK();

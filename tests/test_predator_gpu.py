@@ -233,3 +233,20 @@ def test_stacked_pairs_equal_one_pair_at_a_time(dev):
         assert ia["n0"] == ib["n0"] and ia["n1"] == ib["n1"]
         # the draws depend on float32 score ratios: identical unless a last-bit score difference moves a draw
         assert np.allclose(Ta, Tb, atol=5e-2)
+
+
+@pytest.mark.parametrize("c,ld_extra", [(128, 0), (129, 0), (64, 4), (34, 2)])
+def test_instance_norm_segments_match_per_segment_calls(dev, c, ld_extra):
+    """apr_instance_norm_act_seg (all segments in one pair of launches; 16-B and 4-B apply paths, rows inside wider
+    buffers, residual + LeakyReLU) against the torch statement per segment."""
+    g = torch.Generator().manual_seed(c)
+    segs = [0, 700, 1999, 2300, 5000]
+    wide = torch.randn(5000, c + ld_extra, generator=g) * 3 + 1.5
+    x = wide[:, :c].to(dev) if ld_extra == 0 else wide.to(dev)[:, :c]
+    res = torch.randn(5000, c, generator=g).to(dev)
+    y = kp_ops.instance_norm_act(x, leaky=0.1, residual=res, segments=segs)
+    ref = torch.cat([KO.instance_norm_rows(wide[a:b, :c]) for a, b in zip(segs[:-1], segs[1:])])
+    ref = torch.nn.functional.leaky_relu(ref + res.cpu(), 0.1)
+    assert rel_l2(y.cpu(), ref) < 1e-6
+    y1 = kp_ops.instance_norm_act(x[:700], relu=True)
+    assert rel_l2(y1.cpu(), torch.relu(KO.instance_norm_rows(wide[:700, :c]))) < 1e-6
