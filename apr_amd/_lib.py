@@ -83,6 +83,9 @@ PROTOTYPES = {
     "apr_ransac_pose": (C.c_int, [_p, _i64, _p, _i64, _p, _f64, _f64, _i64, _u64, _p, _sz, _p, _p]),
     "apr_ransac_geometric_scratch_bytes": (_sz, [_i64, _i64, _i64]),
     "apr_ransac_pose_geometric": (C.c_int, [_p, _i64, _p, _i64, _p, _f64, _f64, _i64, _i64, _u64, _p, _sz, _p, _p]),
+    "apr_ransac_raw_bytes": (_sz, []),
+    "apr_ransac_pose_geometric_async": (C.c_int, [_p, _i64, _p, _i64, _p, _f64, _f64, _i64, _i64, _u64, _p, _sz, _p, _p]),
+    "apr_ransac_decode": (C.c_int, [_p, _p]),
     "apr_irls_pose": (C.c_int, [_p, _p, _p, _i64, _p, _p, _sz, _p]),
     "apr_match_pose_batch_scratch_bytes": (_sz, [_i32, _i64, _i64, _i32, _i64]),
     "apr_match_pose_batch": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p]),
@@ -93,6 +96,7 @@ PROTOTYPES = {
     "apr_contrastive_reduce": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _f32, _f32, _p, _p]),
     "apr_grid_subsample_scratch_bytes": (_sz, [_i64]),
     "apr_grid_subsample": (C.c_int, [_p, _i64, _p, _i32, _f32, _p, _i32, _p, _p, _p, _p, _sz, _p]),
+    "apr_grid_subsample_async": (C.c_int, [_p, _i64, _p, _i32, _f32, _p, _i32, _p, _p, _p, _p, _sz, _p]),
     "apr_radius_scratch_bytes": (_sz, [_i64, _i64]),
     "apr_radius_neighbors_async": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "apr_radius_neighbors_regrid_async": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),

@@ -642,10 +642,10 @@ int build_grid(const float* pts, int64_t n, const int32_t* lengths_host, int nb,
 
 APR_API size_t apr_grid_subsample_scratch_bytes(int64_t n) { return grid_work_bytes(n > 0 ? n : 1); }
 
-APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
-                               const float* feats, int32_t fdim, float* out_pts, float* out_feats,
-                               int32_t* out_lengths_host, void* scratch, size_t scratch_bytes, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+int grid_subsample_enqueue(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
+                           const float* feats, int32_t fdim, float* out_pts, float* out_feats, void* scratch,
+                           size_t scratch_bytes, GridWork* w_out, hipStream_t st) {
   APR_CHECK_ARG(n > 0 && n < (1ll << 31) && nb > 0 && nb <= kMaxBatch && dl > 0.f, "apr_grid_subsample: bad arguments");
   APR_CHECK_ARG(scratch_bytes >= grid_work_bytes(n), "apr_grid_subsample: scratch too small");
   for (int b = 0; b < nb; ++b) APR_CHECK_ARG(lengths_host[b] > 0, "apr_grid_subsample: empty cloud in batch");
@@ -659,14 +659,44 @@ APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengt
   hipLaunchKernelGGL(k_barycentre_big, dim3(64), dim3(1024), 0, st, pts, w.big, w.cnt, w.start, w.sorted, feats, fdim,
                      out_pts, out_feats);
   APR_LAUNCH_CHECK();
+  *w_out = w;
+  return APR_OK;
+}
+}  // namespace
+
+APR_API int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
+                               const float* feats, int32_t fdim, float* out_pts, float* out_feats,
+                               int32_t* out_lengths_host, void* scratch, size_t scratch_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GridWork w;
+  int rc = grid_subsample_enqueue(pts, n, lengths_host, nb, dl, feats, fdim, out_pts, out_feats, scratch, scratch_bytes,
+                                  &w, st);
+  if (rc != APR_OK) return rc;
   int status = 0;
-  APR_HIP(hipMemcpyAsync(out_lengths_host, out_len_dev, nb * 4, hipMemcpyDeviceToHost, st));
+  APR_HIP(hipMemcpyAsync(out_lengths_host, w.cursor, nb * 4, hipMemcpyDeviceToHost, st));
   APR_HIP(hipMemcpyAsync(&status, w.status, 4, hipMemcpyDeviceToHost, st));
   APR_HIP(hipStreamSynchronize(st));
   if (status != 0) {
     apr_set_error("apr_grid_subsample: cell index outside the packed-key range");
     return APR_ERANGE;
   }
+  return APR_OK;
+}
+
+// The same without the host synchronisation: the cloud lengths and the status word go to `lengths_status_dev`
+// (int32[nb + 1] on the device: nb subsampled lengths, then 0 or the out-of-range flag), which the caller fetches
+// when convenient; out_pts / out_feats must hold n rows (the subsampled rows are the first sum(lengths) of them).
+APR_API int apr_grid_subsample_async(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
+                                     const float* feats, int32_t fdim, float* out_pts, float* out_feats,
+                                     int32_t* lengths_status_dev, void* scratch, size_t scratch_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(lengths_status_dev, "apr_grid_subsample_async: lengths_status_dev is NULL");
+  GridWork w;
+  int rc = grid_subsample_enqueue(pts, n, lengths_host, nb, dl, feats, fdim, out_pts, out_feats, scratch, scratch_bytes,
+                                  &w, st);
+  if (rc != APR_OK) return rc;
+  APR_HIP(hipMemcpyAsync(lengths_status_dev, w.cursor, nb * 4, hipMemcpyDeviceToDevice, st));
+  APR_HIP(hipMemcpyAsync(lengths_status_dev + nb, w.status, 4, hipMemcpyDeviceToDevice, st));
   return APR_OK;
 }
 

@@ -20,6 +20,8 @@
 // sqrt(d2) < m is evaluated as d2 < T2 with T2 = the smallest double whose
 // correctly-rounded sqrt is >= m (found on the host): sqrt is monotone, so the two
 // predicates are identical for every d2, and no fp64 sqrt runs per point.
+#include <cstring>
+
 #include "common.h"
 
 namespace {
@@ -695,11 +697,10 @@ APR_API size_t apr_ransac_geometric_scratch_bytes(int64_t n0, int64_t n1, int64_
          apr_internal_grid_bytes(n1) + 256;
 }
 
-APR_API int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1,
-                                      const int64_t* corr, double max_dist, double edge_ratio, int64_t max_iter,
-                                      int64_t max_validation, uint64_t seed, void* scratch, size_t scratch_bytes,
-                                      double* result_host, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+int geometric_enqueue(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1, const int64_t* corr,
+                      double max_dist, double edge_ratio, int64_t max_iter, int64_t max_validation, uint64_t seed,
+                      void* scratch, size_t scratch_bytes, RansacScratch* r_out, hipStream_t st) {
   APR_CHECK_ARG(n0 > 0 && n0 < (1ll << 31) && n1 > 0 && n1 < (1ll << 31), "apr_ransac_pose_geometric: empty point set");
   APR_CHECK_ARG(max_iter > 0 && max_iter <= kChunk && max_validation > 0 && max_dist > 0,
                 "apr_ransac_pose_geometric: need 0 < max_iter <= %lld and max_validation > 0", (long long)kChunk);
@@ -722,8 +723,61 @@ APR_API int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float
                      (int)cap, selected);
   hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
   APR_LAUNCH_CHECK();
+  *r_out = r;
+  return APR_OK;
+}
+
+void decode_result(const Hyp& hb, long long tv, double* result_host) {
+  for (int k = 0; k < 12; ++k) result_host[k] = hb.T[k];
+  result_host[12] = 0.0; result_host[13] = 0.0; result_host[14] = 0.0; result_host[15] = 1.0;
+  result_host[16] = (double)(hb.inliers < 0 ? 0 : hb.inliers);
+  result_host[17] = hb.inliers > 0 ? sqrt(hb.err2 / (double)hb.inliers) : 0.0;
+  result_host[18] = (double)hb.it;
+  result_host[19] = (double)tv;
+}
+}  // namespace
+
+APR_API int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1,
+                                      const int64_t* corr, double max_dist, double edge_ratio, int64_t max_iter,
+                                      int64_t max_validation, uint64_t seed, void* scratch, size_t scratch_bytes,
+                                      double* result_host, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RansacScratch r;
+  int rc = geometric_enqueue(xyz0, n0, xyz1, n1, corr, max_dist, edge_ratio, max_iter, max_validation, seed, scratch,
+                             scratch_bytes, &r, st);
+  if (rc != APR_OK) return rc;
   long long tv;
   return fetch_result(r, result_host, &tv, st);
+}
+
+// The same without the host synchronisation: the raw result (apr_ransac_raw_bytes() bytes) is copied to `raw_dev`, a
+// device buffer of the caller's, so that the scratch can serve the next pair at once; the caller fetches the raw
+// results of a whole batch with one copy and decodes them on the host with apr_ransac_decode.
+APR_API size_t apr_ransac_raw_bytes(void) { return sizeof(Hyp) + 8; }
+
+APR_API int apr_ransac_pose_geometric_async(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1,
+                                            const int64_t* corr, double max_dist, double edge_ratio, int64_t max_iter,
+                                            int64_t max_validation, uint64_t seed, void* scratch, size_t scratch_bytes,
+                                            void* raw_dev, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(raw_dev, "apr_ransac_pose_geometric_async: raw_dev is NULL");
+  RansacScratch r;
+  int rc = geometric_enqueue(xyz0, n0, xyz1, n1, corr, max_dist, edge_ratio, max_iter, max_validation, seed, scratch,
+                             scratch_bytes, &r, st);
+  if (rc != APR_OK) return rc;
+  APR_HIP(hipMemcpyAsync(raw_dev, r.best, sizeof(Hyp), hipMemcpyDeviceToDevice, st));
+  APR_HIP(hipMemcpyAsync((char*)raw_dev + sizeof(Hyp), r.total_valid, 8, hipMemcpyDeviceToDevice, st));
+  return APR_OK;
+}
+
+APR_API int apr_ransac_decode(const void* raw_host, double* result_host) {
+  APR_CHECK_ARG(raw_host && result_host, "apr_ransac_decode: NULL argument");
+  Hyp hb;
+  long long tv;
+  memcpy(&hb, raw_host, sizeof(Hyp));
+  memcpy(&tv, (const char*)raw_host + sizeof(Hyp), 8);
+  decode_result(hb, tv, result_host);
+  return APR_OK;
 }
 
 APR_API size_t apr_ransac_scratch_bytes(int64_t n0, int64_t max_iter) { return ransac_core_bytes(n0, max_iter); }

@@ -731,6 +731,36 @@ def ransac_pose_geometric(xyz0, xyz1, corr, max_dist, edge_ratio=0.9, max_iter=5
     return r[:16].reshape(4, 4).copy(), info
 
 
+def ransac_pose_geometric_async(xyz0, xyz1, corr, max_dist, edge_ratio=0.9, max_iter=50000, max_validation=1000, seed=0):
+    """`ransac_pose_geometric` enqueued without a host synchronisation -> uint8 device tensor holding the raw result;
+    fetch the raw results of a batch with one copy and decode each with `ransac_decode`."""
+    xyz0 = _f32(xyz0, "ransac.xyz0").contiguous()
+    xyz1 = _f32(xyz1, "ransac.xyz1").contiguous()
+    if corr.dtype != torch.int64 or not corr.is_cuda or corr.shape[0] != xyz0.shape[0]:
+        raise _lib.AprHipError("ransac_pose_geometric: corr must be an int64 GPU tensor, one entry per source point")
+    corr = corr.contiguous()
+    n0, n1 = xyz0.shape[0], xyz1.shape[0]
+    lib = _lib_()
+    sb = int(lib.apr_ransac_geometric_scratch_bytes(n0, n1, int(max_iter)))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=xyz0.device)
+    raw = torch.empty(int(lib.apr_ransac_raw_bytes()), dtype=torch.uint8, device=xyz0.device)
+    check(lib.apr_ransac_pose_geometric_async(ptr(xyz0), n0, ptr(xyz1), n1, ptr(corr), float(max_dist),
+                                              float(edge_ratio), int(max_iter), int(max_validation),
+                                              int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(scratch), sb, ptr(raw), stream()))
+    return raw
+
+
+def ransac_decode(raw_host, n0):
+    """numpy uint8 raw result -> (T [4,4] float64, info) as `ransac_pose_geometric` returns them."""
+    res = (C.c_double * 20)()
+    raw_host = np.ascontiguousarray(raw_host)
+    check(_lib_().apr_ransac_decode(raw_host.ctypes.data, res))
+    r = np.array(list(res), dtype=np.float64)
+    info = dict(inliers=int(r[16]), rmse=float(r[17]), best_iteration=int(r[18]), n_valid=int(r[19]),
+                fitness=float(r[16]) / max(n0, 1))
+    return r[:16].reshape(4, 4).copy(), info
+
+
 def irls_pose(pts0, pts1, weight=None):
     """est_quad_linear_robust on the GPU -> float32 [4,4] CPU tensor.  Synchronises."""
     pts0 = _f32(pts0, "irls.pts0").contiguous()

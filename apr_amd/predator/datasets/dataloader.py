@@ -28,12 +28,27 @@ def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_
 
 
 def collate_fn_descriptor(list_data, config, neighborhood_limits):
+    """The reference's collate (dataloader.py:72-198) on device tensors; blocking form of `collate_phases`."""
+    gen = collate_phases(list_data, config, neighborhood_limits)
+    try:
+        pending = next(gen)
+        while True:
+            pending.event.synchronize()
+            pending = gen.send(None)
+    except StopIteration as stop:
+        return stop.value
+
+
+def collate_phases(list_data, config, neighborhood_limits):
     """list_data: [(src_pcd, tgt_pcd, src_feats, tgt_feats, ...extras)] with numpy or tensor clouds.
 
     The reference collates exactly one pair (dataloader.py:73 asserts it).  Several pairs may be stacked here
     ([src0, tgt0, src1, tgt1, ...] at every level): neighbourhoods never cross clouds, and the per-level row offsets of
     the pairs are recorded under 'pair_rows' so that the network keeps its per-pair normalisation statistics and runs
     its overlap attention pair by pair -- every pair gets the result of its own single-pair batch."""
+    # A generator: it yields an ops.PendingFetch wherever the host needs bytes back from the device (the cloud lengths
+    # of every pooled level, the table widths) and returns the batch dict -- a single-thread scheduler resumes it when
+    # the fetch has landed (PredatorRegistration.register_batch_phases), `collate_fn_descriptor` just waits.
     assert len(list_data) >= 1
     item = list_data[0]
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -83,7 +98,10 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits):
             conv_i = empty_i
         if 'pool' in block or 'strided' in block:
             dl = 2 * r_normal / config.conv_radius
-            pool_p, pool_b = batch_grid_subsampling_kpconv(batched_points, batched_lengths, sampleDl=dl)
+            sub = point_ops.grid_subsample_async(batched_points, batched_lengths, dl)
+            yield sub.fetch
+            pool_p, pool_b = sub.finish()
+            pool_b = torch.from_numpy(pool_b.astype(np.int32))
             r = r_normal * config.deform_radius / config.conv_radius if 'deformable' in block else r_normal
             pool_i = neighbors(pool_p, batched_points, pool_b, batched_lengths, r, neighborhood_limits[layer],
                                (input_pools, len(input_pools)))
@@ -103,7 +121,9 @@ def collate_fn_descriptor(list_data, config, neighborhood_limits):
         layer += 1
         layer_blocks = []
     if deferred:
-        for (lst, i), t in zip(slots, point_ops.finish_radius_tables(deferred, flags_all)):
+        widths = point_ops.finish_radius_tables_async(deferred, flags_all)
+        yield widths
+        for (lst, i), t in zip(slots, widths.finish()):
             lst[i] = t
     out = {'points': input_points, 'neighbors': input_neighbors, 'pools': input_pools, 'upsamples': input_upsamples,
            'features': batched_features, 'stack_lengths': input_batches_len}

@@ -82,5 +82,6 @@ def sample_by_score(pcd, feats, scores, n_points, rng=np.random):
     s = scores.detach().cpu().float()
     probs = (s / s.sum()).numpy().flatten()
     idx = weighted_choice(rng, pcd.shape[0], n_points, probs)
-    idx_t = torch.from_numpy(idx).to(pcd.device) if torch.is_tensor(pcd) else idx
+    # pinned + non_blocking: a pageable host->device copy blocks the host until the stream gets to it
+    idx_t = torch.from_numpy(idx).pin_memory().to(pcd.device, non_blocking=True) if torch.is_tensor(pcd) else idx
     return pcd[idx_t], feats[idx_t], idx

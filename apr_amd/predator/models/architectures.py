@@ -100,6 +100,16 @@ class KPFCNN(nn.Module):
         self.decoder_concats = concats
         self._c = [_Packed(), _Packed(), _Packed()]
 
+    def _host_temperature(self):
+        """exp(epsilon) + 0.03 as a host float, fetched once per parameter version: reading it inside every forward is a
+        device->host synchronisation in the middle of the network (the host then waits for the whole encoder before it
+        can enqueue the attention block, and a single-thread scheduler serves no other batch meanwhile)."""
+        key = (self.epsilon._version, self.epsilon.data_ptr())
+        if getattr(self, "_temp_key", None) != key:
+            self._temp = float(torch.exp(self.epsilon.detach()) + 0.03)
+            self._temp_key = key
+        return self._temp
+
     def regular_score(self, score):
         score = torch.where(torch.isnan(score), torch.zeros_like(score), score)
         return torch.where(torch.isinf(score), torch.zeros_like(score), score)
@@ -134,7 +144,7 @@ class KPFCNN(nn.Module):
         # ~1.4 k points per pair: every kernel of the attention block is a few workgroups running serial loops, so the
         # pairs of a stacked batch go to side streams and run side by side (forked from / joined to the caller's stream)
         gnn_rows, raw_rows, sal_rows, row0 = [], [], [], 0
-        temperature = (torch.exp(self.epsilon) + 0.03) if grad else float(torch.exp(self.epsilon) + 0.03)
+        temperature = (torch.exp(self.epsilon) + 0.03) if grad else self._host_temperature()
         npairs = len(lens_c) // 2
         side = _side_streams(pcd_c.device, npairs) if (npairs > 1 and not grad) else None
         main = torch.cuda.current_stream() if side else None

@@ -44,6 +44,50 @@ def grid_subsample(points, lengths, dl, features=None):
     return out[:m], out_len
 
 
+class PendingSubsample:
+    """`grid_subsample` in flight: `fetch` (an ops.PendingFetch) completes when the cloud lengths have landed on the
+    host; `finish()` then returns what `grid_subsample` returns."""
+    __slots__ = ("fetch", "_out", "_feats")
+
+    def __init__(self, fetch, out, feats):
+        self.fetch, self._out, self._feats = fetch, out, feats
+
+    def finish(self):
+        out_len = self.fetch.finish()
+        m = int(out_len.sum())
+        if self._feats is not None:
+            return self._out[:m], out_len, self._feats[:m]
+        return self._out[:m], out_len
+
+
+def grid_subsample_async(points, lengths, dl, features=None):
+    """`grid_subsample` without the host synchronisation -> PendingSubsample (single-thread schedulers yield its
+    `.fetch`; `finish()` alone is the blocking form)."""
+    from .. import ops
+    lib = _lib.load()
+    points = _pts(points, "grid_subsample.points")
+    n = points.shape[0]
+    la, lp = _lens(lengths)
+    out = torch.empty_like(points)
+    fdim, of = 0, None
+    if features is not None:
+        features = features.to(torch.float32).contiguous()
+        fdim = features.shape[1]
+        of = torch.empty_like(features)
+    sb = int(lib.apr_grid_subsample_scratch_bytes(n))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=points.device)
+    ls = torch.empty(len(la) + 1, dtype=torch.int32, device=points.device)
+    check(lib.apr_grid_subsample_async(ptr(points), n, lp, len(la), float(dl), ptr(features), fdim, ptr(out), ptr(of),
+                                       ptr(ls), ptr(scratch), sb, stream()))
+
+    def then(host):
+        if host[-1] != 0:
+            raise _lib.AprHipError("apr_grid_subsample: cell index outside the packed-key range")
+        return host[:-1].astype(np.int32).copy()
+
+    return PendingSubsample(ops.PendingFetch(ls, then), out, of)
+
+
 def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, limit=0):
     """int32 [Nq, width] neighbour table sorted by distance, padded with len(supports)."""
     lib = _lib.load()
@@ -115,14 +159,23 @@ def finish_radius_tables(tables, flags_all):
     """One synchronisation for a whole pyramid of `radius_neighbors_async` tables: flags_all int32 [n, 2] on the
     device.  Returns the tables cut to the reference's width min(max count, limit) (columns beyond the largest
     neighbour count hold padding only); raises like `radius_neighbors` if a query overflowed the candidate buffer."""
-    host = flags_all[:len(tables)].cpu().numpy()
-    done = []
-    for t, (maxc, status) in zip(tables, host):
-        if status != 0:
-            raise _lib.AprHipError("apr_radius_neighbors: a query has more neighbours within the radius than the "
-                                   "kernel's candidate buffer holds")
-        done.append(t if maxc >= t.shape[1] else t[:, :int(maxc)].contiguous())
-    return done
+    return finish_radius_tables_async(tables, flags_all).finish()
+
+
+def finish_radius_tables_async(tables, flags_all):
+    """-> ops.PendingFetch whose finish() is `finish_radius_tables`' result."""
+    from .. import ops
+
+    def then(host):
+        done = []
+        for t, (maxc, status) in zip(tables, host):
+            if status != 0:
+                raise _lib.AprHipError("apr_radius_neighbors: a query has more neighbours within the radius than the "
+                                       "kernel's candidate buffer holds")
+            done.append(t if maxc >= t.shape[1] else t[:, :int(maxc)].contiguous())
+        return done
+
+    return ops.PendingFetch(flags_all[:len(tables)], then)
 
 
 def knn(points, k, skip_first=True):

@@ -293,6 +293,15 @@ int apr_ransac_pose_geometric(const float* xyz0, int64_t n0, const float* xyz1, 
                               const int64_t* corr, double max_dist, double edge_ratio,
                               int64_t max_iter, int64_t max_validation, uint64_t seed,
                               void* scratch, size_t scratch_bytes, double* result_host, void* stream);
+/* The same without the host synchronisation: the raw result (apr_ransac_raw_bytes() bytes) is copied to `raw_dev`
+ * (device memory of the caller's); fetch the raw results of a whole batch with one copy and decode each on the host
+ * with apr_ransac_decode (result_host as apr_ransac_pose). */
+size_t apr_ransac_raw_bytes(void);
+int apr_ransac_pose_geometric_async(const float* xyz0, int64_t n0, const float* xyz1, int64_t n1,
+                                    const int64_t* corr, double max_dist, double edge_ratio, int64_t max_iter,
+                                    int64_t max_validation, uint64_t seed, void* scratch, size_t scratch_bytes,
+                                    void* raw_dev, void* stream);
+int apr_ransac_decode(const void* raw_host, double* result_host);
 
 /* B independent pairs, matching + pose, in ONE call and ONE host synchronisation: per pair apr_feature_nn_fast
  * (apr_feature_nn for channel counts other than 32/64/128) -> apr_nn_unpack -> single-round RANSAC, enqueued back to
@@ -356,6 +365,11 @@ size_t apr_grid_subsample_scratch_bytes(int64_t n);
 int apr_grid_subsample(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
                        const float* feats, int32_t fdim, float* out_pts, float* out_feats,
                        int32_t* out_lengths_host, void* scratch, size_t scratch_bytes, void* stream);
+/* The same without the host synchronisation: lengths_status_dev = int32[nb + 1] on the device (nb subsampled lengths,
+ * then 0 or the out-of-range flag); out_pts / out_feats hold n rows, the result is their first sum(lengths) rows. */
+int apr_grid_subsample_async(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float dl,
+                             const float* feats, int32_t fdim, float* out_pts, float* out_feats,
+                             int32_t* lengths_status_dev, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Batched radius neighbours, sorted by distance; replaces
  *   cpp_wrappers.cpp_neighbors.radius_neighbors.batch_query(queries, supports, q_batches, s_batches, radius=)

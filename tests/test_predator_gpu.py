@@ -250,3 +250,28 @@ def test_instance_norm_segments_match_per_segment_calls(dev, c, ld_extra):
     assert rel_l2(y.cpu(), ref) < 1e-6
     y1 = kp_ops.instance_norm_act(x[:700], relu=True)
     assert rel_l2(y1.cpu(), torch.relu(KO.instance_norm_rows(wide[:700, :c]))) < 1e-6
+
+
+def test_single_thread_pipelined_predator_matches_blocking_calls(dev):
+    """PredatorRegistration.register_batch_phases driven by run_pipelined (ONE host thread, 3 batches in flight on 3
+    streams, resumed when their device->host fetches land: 8 fetches per batch) returns exactly what the blocking
+    register_batch returns."""
+    from apr_amd.fcgf.pipeline import run_pipelined
+    from apr_amd.predator.pipeline import PredatorRegistration
+    cfg = kitti_config()
+    np.random.seed(4)
+    torch.manual_seed(4)
+    pipe = PredatorRegistration(KPFCNN(cfg).to(dev).eval(), cfg, [38, 36, 36, 38], max_iteration=20000)
+    pairs = []
+    for s in range(5):
+        a, b, _ = synth.make_pair(90 + s, n_beams=32, n_azimuth=600 + 150 * s)
+        pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    batches = [[pairs[i % 5], pairs[(i + 2) % 5]] for i in range(6)]
+    want = [pipe.register_batch(b, seeds=[5 * i, 5 * i + 1]) for i, b in enumerate(batches)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    got, done_at = run_pipelined(lambda i: pipe.register_batch_phases(batches[i], seeds=[5 * i, 5 * i + 1]),
+                                 range(len(batches)), streams)
+    assert sorted(got) == list(range(len(batches)))
+    for i in range(len(batches)):
+        for (Ta, ia), (Tb, ib) in zip(want[i], got[i]):
+            assert np.array_equal(Ta, Tb) and ia == ib
