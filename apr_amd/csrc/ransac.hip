@@ -536,77 +536,124 @@ __global__ void k_rank_by_iteration(const Hyp* __restrict__ hyps, const int* __r
   selected[h] = rank < max_validation ? 1 : 0;
 }
 
-// One WORKGROUP per selected survivor: every transformed source point looks for its nearest target point
-// within max_dist in a uniform grid whose cell edge is 2*max_dist, so the 2x2x2 block of cells around
-// (p - max_dist) covers the search ball with 8 hash probes: inlier count + sum of squared NN distances
-// (GetRegistrationResultAndCorrespondences of open3d <= 0.11).
+// Every transformed source point looks for its nearest target point within max_dist in a uniform grid whose cell edge
+// is 2*max_dist, so the 2x2x2 block of cells around (p - max_dist) covers the search ball with 8 hash probes: inlier
+// count + sum of squared NN distances (GetRegistrationResultAndCorrespondences of open3d <= 0.11).
+// Work split: a hypothesis is dealt to S = min(kGeoGrid / nv, #256-point chunks) workgroups (nv = survivors on the
+// device; with the usual handful of survivors ONE workgroup per hypothesis left 5 workgroups walking 5000 points each
+// through chains of dependent loads: 210 us).  A workgroup adds the (count, sum) of its chunks in chunk order into its
+// slot part[h * S + p]; k_score_geometric_finish adds the S slots in order: a fixed summation order for given inputs.
+constexpr int kGeoGrid = 2048;
+struct GeoPart {
+  double e2;
+  int cnt;
+  int pad;
+};
+
+__device__ inline int geo_parts(int nv, int64_t n0) {
+  const int nchunk = (int)((n0 + 255) >> 8);
+  int S = nv > 0 ? kGeoGrid / nv : 1;
+  if (S > nchunk) S = nchunk;
+  return S < 1 ? 1 : S;
+}
+
 __global__ __launch_bounds__(256) void k_score_geometric(const float* __restrict__ xyz0, int64_t n0,
                                                          const float* __restrict__ xyz1, AprSearchGrid g,
-                                                         double max_dist, Hyp* __restrict__ hyps,
+                                                         double max_dist, const Hyp* __restrict__ hyps,
                                                          const int* __restrict__ n_valid, int cap,
-                                                         const int* __restrict__ selected) {
+                                                         const int* __restrict__ selected, GeoPart* __restrict__ part) {
   __shared__ int s_cnt[4];
   __shared__ double s_e2[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = min(*n_valid, cap);
+  const int S = geo_parts(nv, n0);
+  const int nchunk = (int)((n0 + 255) >> 8);
   const float md2 = (float)(max_dist * max_dist);
   const float inv_cell = 1.0f / g.cell;
-  for (int h = blockIdx.x; h < nv; h += gridDim.x) {
-    if (!selected[h]) {
-      if (threadIdx.x == 0) hyps[h].inliers = -1;
-      continue;
-    }
+  for (int64_t item = blockIdx.x; item < (int64_t)nv * S; item += gridDim.x) {
+    const int h = (int)(item / S), p = (int)(item - (int64_t)h * S);
+    if (!selected[h]) continue;                      // workgroup-uniform
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = hyps[h].T[k];
-    int cnt = 0;
-    double e2 = 0.0;
-    for (int64_t i = threadIdx.x; i < n0; i += 256) {
-      const double sx = xyz0[3 * i], sy = xyz0[3 * i + 1], sz = xyz0[3 * i + 2];
-      const float px = (float)(T[0] * sx + T[1] * sy + T[2] * sz + T[3]);
-      const float py = (float)(T[4] * sx + T[5] * sy + T[6] * sz + T[7]);
-      const float pz = (float)(T[8] * sx + T[9] * sy + T[10] * sz + T[11]);
-      const int bx = (int)floorf((px - g.mins[0]) * inv_cell - 0.5f), by = (int)floorf((py - g.mins[1]) * inv_cell - 0.5f),
-                bz = (int)floorf((pz - g.mins[2]) * inv_cell - 0.5f);
-      float best = md2;
-      bool found = false;
+    const int c0 = (int)((int64_t)nchunk * p / S), c1 = (int)((int64_t)nchunk * (p + 1) / S);
+    int cnt_total = 0;
+    double e2_total = 0.0;
+    for (int c = c0; c < c1; ++c) {
+      const int64_t i = (int64_t)c * 256 + threadIdx.x;
+      int cnt = 0;
+      double e2 = 0.0;
+      if (i < n0) {
+        const double sx = xyz0[3 * i], sy = xyz0[3 * i + 1], sz = xyz0[3 * i + 2];
+        const float px = (float)(T[0] * sx + T[1] * sy + T[2] * sz + T[3]);
+        const float py = (float)(T[4] * sx + T[5] * sy + T[6] * sz + T[7]);
+        const float pz = (float)(T[8] * sx + T[9] * sy + T[10] * sz + T[11]);
+        const int bx = (int)floorf((px - g.mins[0]) * inv_cell - 0.5f), by = (int)floorf((py - g.mins[1]) * inv_cell - 0.5f),
+                  bz = (int)floorf((pz - g.mins[2]) * inv_cell - 0.5f);
+        float best = md2;
+        bool found = false;
 #pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const int x = bx + (o & 1), y = by + ((o >> 1) & 1), z = bz + (o >> 2);
-        if (!apr_key_in_range(0, x, y, z)) continue;
-        const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, x, y, z));
-        if (id < 0) continue;
-        for (int a = g.start[id]; a < g.start[id + 1]; ++a) {
-          const int j = g.sorted[a];
-          const float ex = px - xyz1[3 * (int64_t)j], ey = py - xyz1[3 * (int64_t)j + 1],
-                      ez = pz - xyz1[3 * (int64_t)j + 2];
-          const float d2 = ex * ex + ey * ey + ez * ez;
-          if (d2 < best) {
-            best = d2;
-            found = true;
+        for (int o = 0; o < 8; ++o) {
+          const int x = bx + (o & 1), y = by + ((o >> 1) & 1), z = bz + (o >> 2);
+          if (!apr_key_in_range(0, x, y, z)) continue;
+          const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, x, y, z));
+          if (id < 0) continue;
+          for (int a = g.start[id]; a < g.start[id + 1]; ++a) {
+            const int j = g.sorted[a];
+            const float ex = px - xyz1[3 * (int64_t)j], ey = py - xyz1[3 * (int64_t)j + 1],
+                        ez = pz - xyz1[3 * (int64_t)j + 2];
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 < best) {
+              best = d2;
+              found = true;
+            }
           }
         }
+        if (found) {
+          cnt = 1;
+          e2 = (double)best;
+        }
       }
-      if (found) {
-        ++cnt;
-        e2 += (double)best;
+      for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_xor(cnt, d);
+        e2 += __shfl_xor(e2, d);
+      }
+      __syncthreads();
+      if (lane == 0) {
+        s_cnt[wave] = cnt;
+        s_e2[wave] = e2;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        cnt_total += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        e2_total += (s_e2[0] + s_e2[1]) + (s_e2[2] + s_e2[3]);
       }
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-      cnt += __shfl_xor(cnt, d);
-      e2 += __shfl_xor(e2, d);
-    }
-    __syncthreads();
-    if (lane == 0) {
-      s_cnt[wave] = cnt;
-      s_e2[wave] = e2;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
-      hyps[h].inliers = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-      hyps[h].err2 = (s_e2[0] + s_e2[1]) + (s_e2[2] + s_e2[3]);
+      part[item].cnt = cnt_total;
+      part[item].e2 = e2_total;
     }
   }
+}
+
+__global__ void k_score_geometric_finish(Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int64_t n0,
+                                         const int* __restrict__ selected, const GeoPart* __restrict__ part) {
+  const int nv = min(*n_valid, cap);
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= nv) return;
+  if (!selected[h]) {
+    hyps[h].inliers = -1;
+    return;
+  }
+  const int S = geo_parts(nv, n0);
+  int cnt = 0;
+  double e2 = 0.0;
+  for (int p = 0; p < S; ++p) {
+    cnt += part[(int64_t)h * S + p].cnt;
+    e2 += part[(int64_t)h * S + p].e2;
+  }
+  hyps[h].inliers = cnt;
+  hyps[h].err2 = e2;
 }
 
 constexpr int64_t kChunk = 1 << 20;
@@ -693,8 +740,9 @@ static int fetch_result(const RansacScratch& r, double* result_host, long long* 
 }  // namespace
 
 APR_API size_t apr_ransac_geometric_scratch_bytes(int64_t n0, int64_t n1, int64_t max_iter) {
-  return ransac_core_bytes(n0, max_iter) + align256((size_t)(max_iter < kChunk ? max_iter : kChunk) * 4) + 256 +
-         apr_internal_grid_bytes(n1) + 256;
+  const size_t cap = (size_t)(max_iter < kChunk ? max_iter : kChunk);
+  return ransac_core_bytes(n0, max_iter) + align256(cap * 4) + 256 + apr_internal_grid_bytes(n1) + 256 +
+         align256((cap + kGeoGrid) * sizeof(GeoPart));
 }
 
 namespace {
@@ -710,6 +758,7 @@ int geometric_enqueue(const float* xyz0, int64_t n0, const float* xyz1, int64_t 
   const RansacScratch r = carve_ransac(scratch, n0, max_iter);
   int* selected = (int*)r.end;
   void* grid_scratch = (void*)(r.end + align256((size_t)cap * 4));
+  GeoPart* part = (GeoPart*)((char*)grid_scratch + align256(apr_internal_grid_bytes(n1)) + 256);
   AprSearchGrid g;
   int rc = apr_internal_search_grid(xyz1, n1, (float)(2.0 * max_dist), grid_scratch, &g, st);
   if (rc != APR_OK) return rc;
@@ -719,8 +768,10 @@ int geometric_enqueue(const float* xyz0, int64_t n0, const float* xyz1, int64_t 
   launch_hypotheses(r, n0, max_dist, edge_ratio, 0, max_iter, seed, (int)cap, st);
   hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, r.hyps, r.n_valid,
                      (int)cap, (int)(max_validation < (1ll << 30) ? max_validation : (1ll << 30)), selected);
-  hipLaunchKernelGGL(k_score_geometric, dim3(2048), dim3(256), 0, st, xyz0, n0, xyz1, g, max_dist, r.hyps, r.n_valid,
-                     (int)cap, selected);
+  hipLaunchKernelGGL(k_score_geometric, dim3(kGeoGrid), dim3(256), 0, st, xyz0, n0, xyz1, g, max_dist, r.hyps, r.n_valid,
+                     (int)cap, selected, part);
+  hipLaunchKernelGGL(k_score_geometric_finish, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, r.hyps, r.n_valid,
+                     (int)cap, n0, selected, part);
   hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
   APR_LAUNCH_CHECK();
   *r_out = r;
