@@ -140,6 +140,85 @@ __global__ __launch_bounds__(256) void k2(float* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = sacc;
 }
 
+// MODE 7: G = 2, per 32-channel step ONE scheduling region: the 12 fragment reads, the 48 MFMAs of the step and the
+// split of the NEXT step's operands, interleaved by sched_group_barrier as (1 MFMA, 2 VALU) x 44 with a fragment read
+// every 4 MFMAs -- the vector pipe works in the 12 spare issue cycles behind every 16-cycle MFMA of the same wave.
+__global__ __launch_bounds__(256) void k3(float* out, int iters) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_w[2][3 * 8192];
+  for (int i = threadIdx.x; i < 2 * 3 * 8192 / 4; i += 256) reinterpret_cast<float*>(&s_w[0][0])[i] = i * 1e-6f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+  const int frag_off = (r16 * 4 + ((r16 & 8) ? (q ^ 3) : q)) * 16;
+  constexpr int G = 2;
+  f32x4 acc[G][4];
+  for (int g = 0; g < G; ++g) for (int i = 0; i < 4; ++i) acc[g][i] = (f32x4){0, 0, 0, 0};
+  f32x4 x0[G], x1[G];
+  for (int g = 0; g < G; ++g) { x0[g] = (f32x4){lane * .1f, 1.f, 2.f, 3.f + g}; x1[g] = (f32x4){lane * .2f, 4.f, 5.f, 6.f + g}; }
+  bf16x8 ah[2][G], am[2][G], al[2][G];
+  for (int g = 0; g < G; ++g) apr_split3(x0[g], x1[g], ah[0][g], am[0][g], al[0][g]);
+  for (int it = 0; it < iters; ++it) {
+    const unsigned char* wb = &s_w[it & 1][frag_off];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int cu = s & 1, nx = cu ^ 1;
+      bf16x8 wf[4][3];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[cb][pl] = *reinterpret_cast<const bf16x8*>(wb + (s * 64 + cb * 16) * 64 + pl * 8192);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        x0[g] += acc[g][0] * 1e-30f;
+        apr_split3(x0[g], x1[g], ah[nx][g], am[nx][g], al[nx][g]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          f32x4 t = acc[g][cb];
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][2], ah[cu][g], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][0], al[cu][g], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][1], am[cu][g], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][1], ah[cu][g], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][0], am[cu][g], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb][0], ah[cu][g], t, 0, 0, 0);
+          acc[g][cb] = t;
+        }
+      // 3 fragment reads up front, then per 4 MFMAs: one more read; per MFMA: 2 VALU
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 48; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        if ((i & 3) == 3 && i < 36) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float sacc = 0;
+  for (int g = 0; g < G; ++g) for (int i = 0; i < 4; ++i) sacc += acc[g][i][0] + acc[g][i][1] + acc[g][i][2] + acc[g][i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = sacc;
+}
+
+void run3(float* out, const char* name) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int wgs_per_cu : {1, 2, 3}) {
+    const int iters = 10000, grid = 256 * wgs_per_cu;
+    hipLaunchKernelGGL(k3, dim3(grid), dim3(256), 0, 0, out, 100);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k3, dim3(grid), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double mfma = (double)grid * 4 * iters * 96.0;
+    printf("%-22s %d WG/CU: %8.3f ms  %7.1f bf16 TFLOP/s (%.0f %% of 2517) = %.0f fp32-equivalent TFLOP/s\n", name, wgs_per_cu, ms,
+           mfma * 16384.0 / ms / 1e9, mfma * 16384.0 / ms / 1e9 / 2517 * 100, mfma * 16384.0 / ms / 1e9 / 6);
+  }
+}
+
 template <int MODE>
 void run2(float* out, const char* name) {
   hipEvent_t e0, e1;
@@ -167,6 +246,7 @@ int main() {
   run2<4>(out, "LDS frags + chain");
   run2<5>(out, "LDS frags + split");
   run2<6>(out, "same, G = 2");
+  run3(out, "G = 2, interleaved");
   run<0>(out, "chain of 6");
   run<1>(out, "term-major x4 acc");
   run<2>(out, "chain + 40 VALU");
