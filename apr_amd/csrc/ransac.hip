@@ -256,38 +256,69 @@ __global__ __launch_bounds__(256) void k_fit_check(const float4* __restrict__ re
   }
 }
 
+constexpr int kGeoGrid = 2048;
+struct GeoPart {
+  double e2;
+  int cnt;
+  int pad;
+};
+
+__device__ inline int geo_parts(int nv, int64_t n0) {
+  const int nchunk = (int)((n0 + 255) >> 8);
+  int S = nv > 0 ? kGeoGrid / nv : 1;
+  if (S > nchunk) S = nchunk;
+  return S < 1 ? 1 : S;
+}
+
 constexpr int kScoreThreads = 256;   // 1024 threads per hypothesis cut the kernel from 14 to 12 us in isolation (4 instead of
                                      // 14 dependent L2 round trips per thread) but cost 2.4 % pairs/s with three steps in
                                      // flight: a 16-wave workgroup waits for a whole CU's worth of free slots
 // A workgroup per hypothesis (grid-stride; every workgroup reaches the exit): only a few hundred hypotheses survive
 // the checkers, so one WAVE per hypothesis would leave the chip idle behind ~220 serial iterations per wave.
 // The per-thread partial sums are combined in a fixed order (lane tree, then the waves in order): bitwise reproducible.
+// With few survivors (the usual case: tens to hundreds) a hypothesis is dealt to S = kGeoGrid / nv workgroups, each
+// scoring a contiguous range of 1024-record blocks into part[h * S + p]; k_score_finish adds the S slots in order
+// (a fixed order for given inputs).  With more than kGeoGrid survivors S = 1 and the workgroup writes the hypothesis
+// itself, as before.
+__device__ inline int score_parts(int nv, int64_t n0) {
+  const int nblk = (int)((n0 + 4 * kScoreThreads - 1) / (4 * kScoreThreads));
+  int S = nv > 0 ? kGeoGrid / nv : 1;
+  if (S > nblk) S = nblk;
+  return S < 1 ? 1 : S;
+}
+
 __global__ __launch_bounds__(kScoreThreads) void k_score(const float4* __restrict__ rec, int64_t n0, double thr_lt,
-                                               Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap) {
+                                               Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                               GeoPart* __restrict__ part) {
   constexpr int NW = kScoreThreads / 64;
   __shared__ int s_cnt[NW];
   __shared__ double s_e2[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = min(*n_valid, cap);
-  for (int h = blockIdx.x; h < nv; h += gridDim.x) {
+  const int S = score_parts(nv, n0);
+  const int64_t nblk = (n0 + 4 * kScoreThreads - 1) / (4 * kScoreThreads);
+  for (int64_t item = blockIdx.x; item < (int64_t)nv * S; item += gridDim.x) {
+    const int h = (int)(item / S), pp = (int)(item - (int64_t)h * S);
+    const int64_t i_begin = (nblk * pp / S) * (4 * kScoreThreads);
+    const int64_t i_end = min((long long)((nblk * (pp + 1) / S) * (4 * kScoreThreads)), (long long)n0);
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = hyps[h].T[k];
     int cnt = 0;
     double e2 = 0.0;
-    for (int64_t i0 = threadIdx.x; i0 < n0; i0 += 4 * kScoreThreads) {   // 4 records in flight, consumed in index order
+    for (int64_t i0 = i_begin + threadIdx.x; i0 < i_end; i0 += 4 * kScoreThreads) {   // 4 records in flight, consumed in index order
       float4 a[4], b[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int64_t i = i0 + u * kScoreThreads;
-        if (i < n0) {
+        if (i < i_end) {
           a[u] = rec[2 * i];
           b[u] = rec[2 * i + 1];
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (i0 + u * kScoreThreads >= n0) break;
+        if (i0 + u * kScoreThreads >= i_end) break;
         const double sx = a[u].x, sy = a[u].y, sz = a[u].z;
         double dx = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - (double)b[u].x;
         double dy = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - (double)b[u].y;
@@ -315,11 +346,32 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(const float4* __restric
         c += s_cnt[w];
         e += s_e2[w];
       }
-      hyps[h].inliers = c;
-      hyps[h].err2 = e;
+      if (S == 1) {
+        hyps[h].inliers = c;
+        hyps[h].err2 = e;
+      } else {
+        part[item].cnt = c;
+        part[item].e2 = e;
+      }
     }
     __syncthreads();
   }
+}
+
+__global__ void k_score_finish(Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int64_t n0,
+                               const GeoPart* __restrict__ part) {
+  const int nv = min(*n_valid, cap);
+  const int S = score_parts(nv, n0);
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (S == 1 || h >= nv) return;          // S > 1 only when nv <= kGeoGrid
+  int c = 0;
+  double e = 0.0;
+  for (int p = 0; p < S; ++p) {
+    c += part[(int64_t)h * S + p].cnt;
+    e += part[(int64_t)h * S + p].e2;
+  }
+  hyps[h].inliers = c;
+  hyps[h].err2 = e;
 }
 
 __device__ inline bool better(int c1, double r1, long long i1, int c2, double r2, long long i2) {
@@ -543,20 +595,6 @@ __global__ void k_rank_by_iteration(const Hyp* __restrict__ hyps, const int* __r
 // device; with the usual handful of survivors ONE workgroup per hypothesis left 5 workgroups walking 5000 points each
 // through chains of dependent loads: 210 us).  A workgroup adds the (count, sum) of its chunks in chunk order into its
 // slot part[h * S + p]; k_score_geometric_finish adds the S slots in order: a fixed summation order for given inputs.
-constexpr int kGeoGrid = 2048;
-struct GeoPart {
-  double e2;
-  int cnt;
-  int pad;
-};
-
-__device__ inline int geo_parts(int nv, int64_t n0) {
-  const int nchunk = (int)((n0 + 255) >> 8);
-  int S = nv > 0 ? kGeoGrid / nv : 1;
-  if (S > nchunk) S = nchunk;
-  return S < 1 ? 1 : S;
-}
-
 __global__ __launch_bounds__(256) void k_score_geometric(const float* __restrict__ xyz0, int64_t n0,
                                                          const float* __restrict__ xyz1, AprSearchGrid g,
                                                          double max_dist, const Hyp* __restrict__ hyps,
@@ -681,6 +719,7 @@ struct RansacScratch {
   Hyp* hyps;
   float4* rec;
   long long* cand;
+  GeoPart* part;   // [kGeoGrid] partial scores of k_score / k_score_geometric's split form
   char* end;
 };
 
@@ -689,7 +728,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t ransac_core_bytes(int64_t n0, int64_t max_iter) {
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   return align256(sizeof(Hyp) + 64) + align256((size_t)(cap < 1 ? 1 : cap) * sizeof(Hyp)) + align256((size_t)n0 * 32) +
-         align256((size_t)(max_iter < 1 ? 1 : max_iter) * 8) + 256;
+         align256((size_t)(max_iter < 1 ? 1 : max_iter) * 8) + align256(kGeoGrid * sizeof(GeoPart)) + 256;
 }
 
 static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
@@ -707,6 +746,8 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   p += align256((size_t)n0 * 32);
   r.cand = (long long*)p;
   p += align256((size_t)max_iter * 8);
+  r.part = (GeoPart*)p;
+  p += align256(kGeoGrid * sizeof(GeoPart));
   r.end = p;
   return r;
 }
@@ -855,7 +896,9 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
     for (int64_t it0 = 0; it0 < max_iter; it0 += step) {
       const int64_t it1 = (it0 + step < max_iter) ? it0 + step : max_iter;
       launch_hypotheses(r, n0, max_dist, edge_ratio, it0, it1, seed, (int)cap, st);
-      hipLaunchKernelGGL(k_score, dim3(2048), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, (int)cap);
+      hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, (int)cap,
+                         r.part);
+      hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.n_valid, (int)cap, n0, r.part);
       hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
     }
     APR_LAUNCH_CHECK();
@@ -944,7 +987,9 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
                        (const long long*)corr, d.n0, r.rec);
     hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
     launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, st);
-    hipLaunchKernelGGL(k_score, dim3(2048), dim3(kScoreThreads), 0, st, r.rec, d.n0, thr_lt, r.hyps, r.n_valid, (int)cap);
+    hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, d.n0, thr_lt, r.hyps, r.n_valid, (int)cap,
+                       r.part);
+    hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.n_valid, (int)cap, d.n0, r.part);
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
   }
   APR_LAUNCH_CHECK();
