@@ -139,18 +139,13 @@ __global__ void k_scan_excl(const int* __restrict__ cnt, const int* __restrict__
   if (threadIdx.x == 0) start[n] = carry_s;
 }
 
-// sxyz (search grids only): the point itself, in cell order, next to its index -- a radius query then reads its
-// candidates as contiguous 16-B records instead of an index followed by a dependent 12-B gather.
 __global__ void k_fill(const int* __restrict__ cell, int64_t n, const int* __restrict__ start,
-                       int* __restrict__ cursor, int* __restrict__ sorted, const float* __restrict__ pts,
-                       float4* __restrict__ sxyz) {
+                       int* __restrict__ cursor, int* __restrict__ sorted) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int id = cell[i];
   if (id < 0) return;
-  const int pos = start[id] + atomicAdd(&cursor[id], 1);
-  sorted[pos] = (int)i;
-  if (sxyz) sxyz[pos] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float((int)i));
+  sorted[start[id] + atomicAdd(&cursor[id], 1)] = (int)i;
 }
 
 // one WAVE per cell: rank-sort the cell's point indices in LDS (cells of a raw scan near the sensor hold
@@ -346,7 +341,6 @@ struct Grid {
   const int* sorted;  // support indices bucketed by cell
   const float* mins;  // [nb,3] per-cloud support minimum
   float cell;
-  const float4* sxyz;  // (x, y, z, index bits) of the supports in the order of `sorted`
 };
 
 // MODE 0: count only.  MODE 1: fill + sort.  MODE 2: fill + sort, and the query's neighbour count to counts[].
@@ -398,9 +392,9 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
       int L = 0;                        // cell range holding candidate t: first L with incl[L] > t
       while (s_incl[wave][L] <= t) ++L;
       const int before = L ? s_incl[wave][L - 1] : 0;
-      const float4 rec = g.sxyz[s_lo[wave][L] + (t - before)];
-      sidx = __float_as_int(rec.w);
-      const float dx = __fsub_rn(qx, rec.x), dy = __fsub_rn(qy, rec.y), dz = __fsub_rn(qz, rec.z);
+      sidx = g.sorted[s_lo[wave][L] + (t - before)];
+      const float dx = __fsub_rn(qx, s[3 * (int64_t)sidx]), dy = __fsub_rn(qy, s[3 * (int64_t)sidx + 1]),
+                  dz = __fsub_rn(qz, s[3 * (int64_t)sidx + 2]);
       d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       hit = d2 < r2;
     }
@@ -439,9 +433,9 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
             int L = 0;
             while (s_incl[wave][L] <= t) ++L;
             const int before = L ? s_incl[wave][L - 1] : 0;
-            const float4 rec = g.sxyz[s_lo[wave][L] + (t - before)];
-            sidx = __float_as_int(rec.w);
-            const float dx = __fsub_rn(qx, rec.x), dy = __fsub_rn(qy, rec.y), dz = __fsub_rn(qz, rec.z);
+            sidx = g.sorted[s_lo[wave][L] + (t - before)];
+            const float dx = __fsub_rn(qx, s[3 * (int64_t)sidx]), dy = __fsub_rn(qy, s[3 * (int64_t)sidx + 1]),
+                        dz = __fsub_rn(qz, s[3 * (int64_t)sidx + 2]);
             d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
             hit = d2 < r2;
           }
@@ -639,9 +633,7 @@ int build_grid(const float* pts, int64_t n, const int32_t* lengths_host, int nb,
   hipLaunchKernelGGL(k_cell_of, dim3(nblk), dim3(kBlock), 0, st, w.coords, n, w.keys, w.vals, (uint32_t)(w.cap - 1),
                      w.cell, w.cnt);
   hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, w.cnt, w.n_cells, w.start, w.big);
-  // w.coords (n x 16 B) is dead once k_cell_of has run: search grids keep the points there in cell order
-  hipLaunchKernelGGL(k_fill, dim3(nblk), dim3(kBlock), 0, st, w.cell, n, w.start, w.cursor, w.sorted, pts,
-                     mode == 1 ? (float4*)w.coords : (float4*)nullptr);
+  hipLaunchKernelGGL(k_fill, dim3(nblk), dim3(kBlock), 0, st, w.cell, n, w.start, w.cursor, w.sorted);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -753,7 +745,7 @@ APR_API int apr_radius_neighbors(const float* queries, int64_t nq, const float* 
   for (int b = 0; b < nb; ++b) qs[b + 1] = qs[b] + q_lengths_host[b];
   APR_CHECK_ARG(qs[nb] == nq, "apr_radius_neighbors: query batch lengths sum to %d, expected %lld", qs[nb], (long long)nq);
   APR_HIP(hipMemcpyAsync(qstarts, qs, (nb + 1) * 4, hipMemcpyHostToDevice, st));
-  Grid g{w.keys, w.vals, (uint32_t)(w.cap - 1), w.start, w.sorted, w.mins, radius, (const float4*)w.coords};
+  Grid g{w.keys, w.vals, (uint32_t)(w.cap - 1), w.start, w.sorted, w.mins, radius};
   const float r2 = radius * radius;
   const unsigned grid = (unsigned)cdiv64(nq, 4);
   // counting pass: the reference pads every row to the global maximum neighbour count and the
@@ -816,7 +808,7 @@ static int radius_async(const float* queries, int64_t nq, const float* supports,
   APR_CHECK_ARG(qs[nb] == nq, "apr_radius_neighbors_async: query batch lengths sum to %d, expected %lld", qs[nb],
                 (long long)nq);
   hipLaunchKernelGGL(k_set_starts, dim3(1), dim3(128), 0, st, qstarts, qb, nb + 1);
-  Grid g{w.keys, w.vals, (uint32_t)(w.cap - 1), w.start, w.sorted, w.mins, radius, (const float4*)w.coords};
+  Grid g{w.keys, w.vals, (uint32_t)(w.cap - 1), w.start, w.sorted, w.mins, radius};
   APR_HIP(hipMemsetAsync(flags_dev, 0, 8, st));
   hipLaunchKernelGGL(k_radius<2>, dim3((unsigned)cdiv64(nq, 4)), dim3(256), 0, st, queries, nq, qstarts, supports, nb, g,
                      radius * radius, counts, out, (int)limit, out_ld, (int)ns, flags_dev + 1);
