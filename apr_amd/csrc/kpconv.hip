@@ -422,6 +422,76 @@ __global__ __launch_bounds__(256) void k_softmax_matvec(const float* __restrict_
   if (threadIdx.x == 0) out[ni] = s_red[0] / den;
 }
 
+// The same with b given TRANSPOSED (bt [c, m]) and kSmvQ queries per workgroup: lane j reads bt[d * m + j] -- coalesced,
+// and every element fetched serves kSmvQ queries -- where k_softmax_matvec's lanes each walk their own 1 KB row of b
+// (700 workgroups x 717 KB through the L1: 110 us per call at 700 x 700 x 256).  Same fma order over d and the same
+// reduction trees: bit-identical results.
+constexpr int kSmvQ = 4;
+__global__ __launch_bounds__(256) void k_softmax_matvec_t(const float* __restrict__ a, const float* __restrict__ bt,
+                                                          const float* __restrict__ w, int n, int m, int c,
+                                                          float temperature, float* __restrict__ out) {
+  extern __shared__ float s_sc[];  // [kSmvQ][m] + [kSmvQ][c]
+  float* s_a = s_sc + kSmvQ * m;
+  __shared__ float s_red[256];
+  const int n0 = blockIdx.x * kSmvQ;
+  for (int e = threadIdx.x; e < kSmvQ * c; e += 256) {
+    const int qi = e / c, d = e - qi * c;
+    s_a[e] = a[(int64_t)min(n0 + qi, n - 1) * c + d];
+  }
+  __syncthreads();
+  float mx[kSmvQ];
+#pragma unroll
+  for (int qi = 0; qi < kSmvQ; ++qi) mx[qi] = -__builtin_inff();
+  for (int j = threadIdx.x; j < m; j += 256) {
+    float sc[kSmvQ];
+#pragma unroll
+    for (int qi = 0; qi < kSmvQ; ++qi) sc[qi] = 0.f;
+    for (int d = 0; d < c; ++d) {
+      const float bv = bt[(int64_t)d * m + j];
+#pragma unroll
+      for (int qi = 0; qi < kSmvQ; ++qi) sc[qi] = fmaf(s_a[qi * c + d], bv, sc[qi]);
+    }
+#pragma unroll
+    for (int qi = 0; qi < kSmvQ; ++qi) {
+      sc[qi] /= temperature;
+      s_sc[qi * m + j] = sc[qi];
+      mx[qi] = fmaxf(mx[qi], sc[qi]);
+    }
+  }
+  for (int qi = 0; qi < kSmvQ; ++qi) {          // per query: the reductions of k_softmax_matvec, unchanged
+    s_red[threadIdx.x] = mx[qi];
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
+      __syncthreads();
+    }
+    const float mq = s_red[0];
+    __syncthreads();
+    float num = 0.f, den = 0.f;
+    for (int j = threadIdx.x; j < m; j += 256) {
+      float e = expf(s_sc[qi * m + j] - mq);
+      den += e;
+      num = fmaf(e, w[j], num);
+    }
+    s_red[threadIdx.x] = den;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+      __syncthreads();
+    }
+    den = s_red[0];
+    __syncthreads();
+    s_red[threadIdx.x] = num;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && n0 + qi < n) out[n0 + qi] = s_red[0] / den;
+    __syncthreads();
+  }
+}
+
 // y = clamp(sigmoid(x), 0, 1) with NaN / Inf -> 0   (architectures.py:131-134, 203-207)
 __global__ void k_score_head(const float* __restrict__ x, int64_t ldx, int64_t n, float* __restrict__ y) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,6 +616,18 @@ APR_API int apr_softmax_matvec(const float* a, const float* b, const float* w, i
   APR_CHECK_ARG((size_t)(m + c) * 4 <= 60 * 1024, "apr_softmax_matvec: m + c too large for LDS");
   hipLaunchKernelGGL(k_softmax_matvec, dim3((unsigned)n), dim3(256), (size_t)(m + c) * 4, (hipStream_t)stream, a, b, w, n,
                      m, c, temperature, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// b transposed by the caller (bt [c, m] row-major): coalesced reads, 4 queries per workgroup; same bits as the above
+APR_API int apr_softmax_matvec_bt(const float* a, const float* bt, const float* w, int32_t n, int32_t m, int32_t c,
+                                  float temperature, float* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && c > 0 && temperature > 0.f && a && bt && w && out, "apr_softmax_matvec_bt: bad arguments");
+  const size_t lds = (size_t)kSmvQ * (m + c) * 4;
+  APR_CHECK_ARG(lds <= 60 * 1024, "apr_softmax_matvec_bt: m + c too large for LDS");
+  hipLaunchKernelGGL(k_softmax_matvec_t, dim3((unsigned)((n + kSmvQ - 1) / kSmvQ)), dim3(256), lds, (hipStream_t)stream,
+                     a, bt, w, n, m, c, temperature, out);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

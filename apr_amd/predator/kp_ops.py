@@ -199,10 +199,15 @@ def mha(q, k, v, heads):
 
 
 def softmax_matvec(a, b, w, temperature):
-    a, b, w = a.contiguous(), b.contiguous(), w.contiguous().view(-1)
+    a, w = a.contiguous(), w.contiguous().view(-1)
     out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
-    check(_lib.load().apr_softmax_matvec(ptr(a), ptr(b), ptr(w), a.shape[0], b.shape[0], a.shape[1], float(temperature),
-                                         ptr(out), stream()))
+    n, m, c = a.shape[0], b.shape[0], a.shape[1]
+    if 4 * (m + c) * 4 <= 60 * 1024:
+        bt = b.t().contiguous()          # [c, m]: the kernel's lanes run along the keys
+        check(_lib.load().apr_softmax_matvec_bt(ptr(a), ptr(bt), ptr(w), n, m, c, float(temperature), ptr(out), stream()))
+    else:
+        check(_lib.load().apr_softmax_matvec(ptr(a), ptr(b.contiguous()), ptr(w), n, m, c, float(temperature), ptr(out),
+                                             stream()))
     return out
 
 

@@ -466,6 +466,10 @@ int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m
 /* out[i] = sum_j softmax_j(<a_i, b_j> / temperature) * w[j]  (cross saliency, architectures.py:176-181). */
 int apr_softmax_matvec(const float* a, const float* b, const float* w, int32_t n, int32_t m, int32_t c,
                        float temperature, float* out, void* stream);
+/* The same with b handed over transposed (bt [c, m] row-major): coalesced reads, several queries per workgroup; the
+ * result has the same bits. */
+int apr_softmax_matvec_bt(const float* a, const float* bt, const float* w, int32_t n, int32_t m, int32_t c,
+                          float temperature, float* out, void* stream);
 
 /* y[i] = clamp(sigmoid(x[i*ldx]), 0, 1), NaN/Inf -> 0  (architectures.py:131-134,203-207). */
 int apr_score_head(const float* x, int64_t ldx, int64_t n, float* y, void* stream);
