@@ -137,6 +137,41 @@ def test_dense_gemm_identity_map(dev, m, cin, cout):
     assert float(wide_out[:, :64].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,cin,cout", [
+    (4001, 64, 64), (27674, 960, 64), (129, 128, 256), (1382, 7680, 512), (64, 512, 512), (1, 64, 64),
+    (40000, 256, 256), (9918, 1920, 128),
+])
+def test_dense_gemm_bf3_matches_fp64(dev, m, cin, cout):
+    """apr_dense_gemm_bf3 (bf16 MFMA, 3-way split of both operands, LDS-DMA weight staging; both tile heights): fp32
+    accuracy against the float64 product, with column slices as input / output / residual, the fused epilogue and a
+    ragged last tile; operands over several orders of magnitude."""
+    rng = np.random.default_rng(m + cin + cout)
+    mag = np.exp(rng.uniform(-4, 4, (m, 1))).astype(np.float32)
+    wide_in = torch.from_numpy((rng.standard_normal((m, cin + 32)) * mag).astype(np.float32)).to(dev)
+    x = wide_in[:, 32:]
+    W = torch.from_numpy((rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    res_wide = torch.from_numpy(rng.standard_normal((m, cout + 4)).astype(np.float32)).to(dev)
+    res = res_wide[:, 4:]
+    w3 = ops.pack_weights_bf3(W[None].contiguous().to(dev))
+    assert w3 is not None
+    plain = ops.dense_gemm_bf3(x, w3, cin, cout)
+    ref0 = x.cpu().double() @ W.double()
+    assert rel_l2(plain.cpu(), ref0) < 2e-6
+    # per row: every row keeps fp32 accuracy at its own magnitude (a plain bf16 product would be off by 4e-3)
+    err_row = (plain.cpu().double() - ref0).norm(dim=1) / ref0.norm(dim=1).clamp_min(1e-30)
+    assert float(err_row.max()) < 5e-6
+    wide_out = torch.zeros((m, cout + 64), device=dev)
+    ops.dense_gemm_bf3(x, w3, cin, cout, scale=scale.to(dev), shift=shift.to(dev), residual=res, relu=True,
+                       out=wide_out[:, 64:])
+    ref = torch.relu(ref0 * scale.double() + shift.double() + res.cpu().double())
+    assert rel_l2(wide_out[:, 64:].cpu(), ref) < 2e-6
+    assert float(wide_out[:, :64].abs().max()) == 0.0
+    with pytest.raises(Exception):
+        ops.dense_gemm_bf3(wide_in[:, 1:1 + cin], w3, cin, cout)        # rows not 16-byte aligned: refused, loudly
+
+
 def test_weight_stationary_many_rounds(dev):
     """More units than resident workgroups (APR_WS_TARGET=4 is read once per process, hence the child process): every
     workgroup walks several units, re-staging its weight slice, and the result must not change."""
