@@ -41,6 +41,48 @@ __global__ __launch_bounds__(1024) void k_bn_partial(const float* __restrict__ x
   const int64_t n = sg.row0[seg + 1] - sg.row0[seg];
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
   const int64_t r1 = min((long long)(r0 + kRowsPerBlock), (long long)n);
+  // 16-B form (rows 16-byte aligned, c % 4 == 0): thread = 4 columns x one row of every 64 -- a quarter of the load
+  // instructions of the 4-B form; the 64 row lanes of a column quad meet in LDS in fixed order
+  const bool vec = (c & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (vec) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ double s_v[64][16][8];                      // [row lane][column quad][4 sums, 4 sums of squares]
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int colv = blockIdx.y * 64 + cq * 4;
+    double a4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (colv < c) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + rl + 64 * u;
+        v[u] = r < r1 ? *reinterpret_cast<const f32x4*>(x + r * ld + colv) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double d = (double)v[u][e];
+          a4[e] += d;
+          q4[e] += d * d;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s_v[rl][cq][e] = a4[e];
+      s_v[rl][cq][4 + e] = q4[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {                               // thread = (column 0..63, sum | sum of squares)
+      const int cc = threadIdx.x & 63, which = threadIdx.x >> 6;
+      const int colw = blockIdx.y * 64 + cc;
+      if (colw < c) {
+        double t = 0.0;
+        for (int g = 0; g < 64; ++g) t += s_v[g][cc >> 2][which * 4 + (cc & 3)];
+        partial[((int64_t)blockIdx.x * 2 + which) * c + colw] = t;
+      }
+    }
+    return;
+  }
   double s = 0.0, s2 = 0.0;
   if (col < c) {
     for (int64_t rb = r0 + ty; rb < r1; rb += 128) {
