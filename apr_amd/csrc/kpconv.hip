@@ -205,6 +205,41 @@ __global__ __launch_bounds__(256) void k_kpconv_dfeat(
 
 // out[q,:] = max_h x_pad[inds[q,h],:]  (x_pad = x plus a zero shadow row; blocks.py:86-102)
 // mode 1: out[q,:] = x_pad[inds[q,0],:]  (closest_pool, blocks.py:71-83)
+// 16-B form: thread = (query, 4 channels); rows of x / out 16-byte aligned, c % 4 == 0
+__global__ void k_gather_pool4(const float* __restrict__ x, int64_t ldx, int ns, int c, const int* __restrict__ inds,
+                               int H, int64_t nq, int mode, float* __restrict__ out, int64_t ldo) {
+  const int c4 = c >> 2;
+  const int64_t total = nq * c4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 ninf = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t qi = t / c4;
+    const int col = (int)(t - qi * c4) * 4;
+    f32x4 m;
+    if (mode == 1) {
+      const int idx = inds[qi * H];
+      m = (idx >= 0 && idx < ns) ? *reinterpret_cast<const f32x4*>(x + (int64_t)idx * ldx + col) : zero;
+    } else {
+      m = ninf;
+      for (int h0 = 0; h0 < H; h0 += 8) {
+        int idx[8];
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) idx[u] = (h0 + u < H) ? inds[qi * H + h0 + u] : -2;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = (idx[u] >= 0 && idx[u] < ns) ? *reinterpret_cast<const f32x4*>(x + (int64_t)idx[u] * ldx + col)
+                                              : (idx[u] == -2 ? ninf : zero);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[u][e]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + qi * ldo + col) = m;
+  }
+}
+
 __global__ void k_gather_pool(const float* __restrict__ x, int64_t ldx, int ns, int c, const int* __restrict__ inds,
                               int H, int64_t nq, int mode, float* __restrict__ out, int64_t ldo) {
   const int64_t total = nq * c;
@@ -567,10 +602,15 @@ APR_API int apr_gather_pool(const float* x, int64_t ldx, int64_t ns, int32_t c, 
   APR_CHECK_ARG(nq >= 0 && ns >= 0 && c > 0 && H > 0 && ldx >= c && ldo >= c && (mode == 0 || mode == 1),
                 "apr_gather_pool: bad arguments");
   if (nq == 0) return APR_OK;
-  int64_t nblk = cdiv64(nq * c, 256);
+  const bool vec = (c & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+  int64_t nblk = cdiv64(nq * (vec ? c / 4 : c), 256);
   if (nblk > 16384) nblk = 16384;
-  hipLaunchKernelGGL(k_gather_pool, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)ns, c, inds, H,
-                     nq, mode, out, ldo);
+  if (vec)
+    hipLaunchKernelGGL(k_gather_pool4, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)ns, c, inds,
+                       H, nq, mode, out, ldo);
+  else
+    hipLaunchKernelGGL(k_gather_pool, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)ns, c, inds, H,
+                       nq, mode, out, ldo);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
