@@ -97,15 +97,43 @@ __device__ inline int table_lookup(const unsigned long long* __restrict__ keys, 
   return -1;
 }
 
+// Wave-aggregated counting: the lanes of a wave that fall into the same cell issue ONE atomic between them (a raw scan
+// walks its cells in order, and an object at the sensor puts 20 k points into one cell: per-point atomics on one
+// counter serialised k_cell_of and k_fill to 30 us each).  Returns the lane's rank inside its group, the group size and
+// the group's leader (its lowest lane; an inactive lane is its own leader with size 0).
+__device__ inline int wave_group_rank(int id, bool active, int* group_size, int* leader_lane) {
+  const int lane = threadIdx.x & 63;
+  int rank = 0;
+  *group_size = 0;
+  *leader_lane = lane;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const int fid = __shfl(id, first);
+    const unsigned long long grp = __ballot(active && id == fid) & todo;
+    if (active && id == fid && ((todo >> lane) & 1ull)) {
+      rank = __popcll(grp & ((1ull << lane) - 1ull));
+      *group_size = __popcll(grp);
+      *leader_lane = first;
+    }
+    todo &= ~grp;
+  }
+  return rank;
+}
+
 __global__ void k_cell_of(const int4* __restrict__ coords, int64_t n, const unsigned long long* __restrict__ keys,
                           const int* __restrict__ vals, uint32_t mask, int* __restrict__ cell,
                           int* __restrict__ cnt) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int4 c = coords[i];
-  int id = table_lookup(keys, vals, mask, apr_pack_key(c.x, c.y, c.z, c.w));
-  cell[i] = id;
-  if (id >= 0) atomicAdd(&cnt[id], 1);
+  int id = -1;
+  if (i < n) {
+    int4 c = coords[i];
+    id = table_lookup(keys, vals, mask, apr_pack_key(c.x, c.y, c.z, c.w));
+    cell[i] = id;
+  }
+  int gsz, lead;
+  wave_group_rank(id, id >= 0, &gsz, &lead);
+  if (id >= 0 && lead == (int)(threadIdx.x & 63)) atomicAdd(&cnt[id], gsz);
 }
 
 // exclusive scan of cnt[0..n) -> start[0..n], single workgroup (n <= a few 10^5)
@@ -142,10 +170,13 @@ __global__ void k_scan_excl(const int* __restrict__ cnt, const int* __restrict__
 __global__ void k_fill(const int* __restrict__ cell, int64_t n, const int* __restrict__ start,
                        int* __restrict__ cursor, int* __restrict__ sorted) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int id = cell[i];
-  if (id < 0) return;
-  sorted[start[id] + atomicAdd(&cursor[id], 1)] = (int)i;
+  const int id = i < n ? cell[i] : -1;
+  int gsz, lead;
+  const int rank = wave_group_rank(id, id >= 0, &gsz, &lead);
+  int base = 0;
+  if (id >= 0 && lead == (int)(threadIdx.x & 63)) base = atomicAdd(&cursor[id], gsz);
+  base = __shfl(base, lead);            // the leader's range start reaches the members of its group
+  if (id >= 0) sorted[start[id] + base + rank] = (int)i;
 }
 
 // one WAVE per cell: rank-sort the cell's point indices in LDS (cells of a raw scan near the sensor hold
