@@ -146,10 +146,20 @@ __global__ void k_scan_excl(const int* __restrict__ cnt, const int* __restrict__
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int base = 0; base < n; base += blockDim.x) {
-    int idx = base + threadIdx.x;
-    int v = idx < n ? cnt[idx] : 0;
-    int incl = v;
+  // 8 consecutive counts per thread and round (one-per-thread rounds cost 3 barriers per 1024 cells: 137 us for the
+  // 470 k cells of a raw scan pair): serial prefix in registers, then the wave / workgroup scan of the thread totals
+  constexpr int PER = 8;
+  const int chunk = blockDim.x * PER;
+  for (int base = 0; base < n; base += chunk) {
+    const int i0 = base + threadIdx.x * PER;
+    int v[PER];
+    int tsum = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      v[u] = (i0 + u < n) ? cnt[i0 + u] : 0;
+      tsum += v[u];
+    }
+    int incl = tsum;
     for (int d = 1; d < 64; d <<= 1) {
       int t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
@@ -158,8 +168,13 @@ __global__ void k_scan_excl(const int* __restrict__ cnt, const int* __restrict__
     __syncthreads();
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += wave_sum[w];
-    int carry = carry_s;
-    if (idx < n) start[idx] = carry + woff + incl - v;
+    const int carry = carry_s;
+    int run = carry + woff + incl - tsum;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (i0 + u < n) start[i0 + u] = run;
+      run += v[u];
+    }
     __syncthreads();
     if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + incl;
     __syncthreads();
