@@ -131,25 +131,7 @@ class PairRegistration:
 
         Larger launches amortise the ~10-20 us latency floor of every sparse-conv / index kernel and the host cost
         of an encoder call over B pairs.  -> list of (T [4,4] float64, info)."""
-        if seeds is None:
-            seeds = range(len(pairs))
-        clouds = [c for p in pairs for c in p]
-        cm, counts, first, poffs, pts_all = self.voxelize_batch(clouds)
-        F = self.encode_batch(cm)
-        offs = [0]
-        for n in counts:
-            offs.append(offs[-1] + n)
-        pts = [pts_all[offs[b]:offs[b + 1]] for b in range(len(clouds))]     # rows of frame b (contiguous slices)
-        # matching + pose of all B pairs: one library call, one host synchronisation
-        res = ops.match_pose_batch([F[offs[2 * i]:offs[2 * i + 1]] for i in range(len(pairs))],
-                                   [F[offs[2 * i + 1]:offs[2 * i + 2]] for i in range(len(pairs))],
-                                   pts[0::2], pts[1::2], self.distance_threshold, self.edge_length, self.ransac_iters,
-                                   seeds=list(seeds))
-        out = []
-        for i, (T, info) in enumerate(res):
-            info.update(n0=counts[2 * i], n1=counts[2 * i + 1])
-            out.append((T, info))
-        return out
+        return ops.drive(self.register_batch_phases(pairs, seeds))     # one code path: the pipelined step, waited for
 
     @torch.no_grad()
     def __call__(self, xyz0, xyz1, seed=0):

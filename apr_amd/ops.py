@@ -157,6 +157,18 @@ class PendingFetch:
         return self._then(self._host.numpy())
 
 
+def drive(gen):
+    """Run a generator that yields PendingFetch objects (register_batch_phases, collate_phases) to completion on the
+    calling thread, waiting at every fetch: the blocking form of a pipelined step.  -> the generator's return value."""
+    try:
+        pending = next(gen)
+        while True:
+            pending.event.synchronize()
+            pending = gen.send(None)
+    except StopIteration as stop:
+        return stop.value
+
+
 def finalize_maps_async(maps, extras=()):
     """`finalize_maps` without the host synchronisation -> PendingFetch whose finish() applies the counts and returns
     the extras (numpy arrays)."""

@@ -29,14 +29,8 @@ def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_
 
 def collate_fn_descriptor(list_data, config, neighborhood_limits):
     """The reference's collate (dataloader.py:72-198) on device tensors; blocking form of `collate_phases`."""
-    gen = collate_phases(list_data, config, neighborhood_limits)
-    try:
-        pending = next(gen)
-        while True:
-            pending.event.synchronize()
-            pending = gen.send(None)
-    except StopIteration as stop:
-        return stop.value
+    from ... import ops
+    return ops.drive(collate_phases(list_data, config, neighborhood_limits))
 
 
 def collate_phases(list_data, config, neighborhood_limits):

@@ -67,24 +67,8 @@ class PredatorRegistration:
     def register_batch(self, pairs, seeds=None):
         """[(xyz0, xyz1), ...] -> [(T, info), ...]: one stacked encode, then the reference's per-pair tail
         (lib/tester.py:80-100: score-weighted draws on the host RNG seeded per pair, feature NN, RANSAC)."""
-        seeds = list(range(len(pairs))) if seeds is None else list(seeds)
-        enc = self.encode_batch(pairs) if len(pairs) > 1 else [self.encode(*pairs[0])]
-        # one device->host copy of every pair's sampling weights
-        w_all = torch.cat([ov * sal for (_, _, _, ov, sal) in enc]).cpu()
-        out, row0 = [], 0
-        for (src, tgt, feats, _, _), seed in zip(enc, seeds):
-            n0, n1 = len(src), len(tgt)
-            rng = np.random.RandomState(seed)
-            w0, w1 = w_all[row0:row0 + n0], w_all[row0 + n0:row0 + n0 + n1]
-            row0 += n0 + n1
-            s_p, s_f, _ = BU.sample_by_score(src, feats[:n0], w0, self.n_points, rng=rng)
-            t_p, t_f, _ = BU.sample_by_score(tgt, feats[n0:], w1, self.n_points, rng=rng)
-            T, info = BU.ransac_pose_estimation(s_p, t_p, s_f, t_f, distance_threshold=self.distance_threshold,
-                                                ransac_n=4, max_iteration=self.max_iteration,
-                                                max_validation=self.max_validation, seed=seed, return_info=True)
-            info.update(n0=n0, n1=n1)
-            out.append((T, info))
-        return out
+        from .. import ops
+        return ops.drive(self.register_batch_phases(pairs, seeds))     # one code path: the pipelined batch, waited for
 
     @torch.no_grad()
     def register_batch_phases(self, pairs, seeds=None):

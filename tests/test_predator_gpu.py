@@ -275,6 +275,13 @@ def test_single_thread_pipelined_predator_matches_blocking_calls(dev):
     for i in range(len(batches)):
         for (Ta, ia), (Tb, ib) in zip(want[i], got[i]):
             assert np.array_equal(Ta, Tb) and ia == ib
+    # batches of ONE pair through the scheduler against the per-pair call, which goes through the synchronising entry
+    # points (apr_grid_subsample, apr_ransac_pose_geometric): the asynchronous ones return the same bits
+    single = [pipe(*pairs[i], seed=40 + i) for i in range(5)]
+    got1, _ = run_pipelined(lambda i: pipe.register_batch_phases([pairs[i]], seeds=[40 + i]), range(5), streams)
+    for i in range(5):
+        (Ta, ia), (Tb, ib) = single[i], got1[i][0]
+        assert np.array_equal(Ta, Tb) and ia == ib
 
 
 def test_softmax_matvec_transposed_kernel_has_the_same_bits(dev):
