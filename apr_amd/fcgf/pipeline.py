@@ -151,8 +151,10 @@ def run_pipelined(make_step, indices, streams):
     its generator is resumed, otherwise the next slot gets the host; the host only blocks when no slot can move.
     -> ({i: result}, [(i, completion time)]).
 
-    This replaces one Python thread per stream: the threads spent their time fighting over the GIL (3 threads: host
-    time per step 10 ms instead of 1.4 ms), and 8 ranks x 3 threads do not fit a 16-thread host share."""
+    The alternative to one Python thread per stream.  Which is faster depends on where the step's host time goes: the
+    Predator batch is Python between its fetches (GIL-bound: one scheduler 272-279 pairs/s, three threads 208), the FCGF
+    step is library calls, which release the GIL (three threads 2075-2116 pairs/s, one scheduler 1932-1967: a stream
+    never waits for another step's 1 ms enqueue phase).  bench.py defaults accordingly."""
     import time
     it = iter(indices)
     slots = [None] * len(streams)          # (step index, generator, pending fetch)
