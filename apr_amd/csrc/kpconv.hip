@@ -308,6 +308,30 @@ __global__ void k_group_max(const float* __restrict__ y, int64_t ldy, int n, int
 // the 8 queries in LDS ([8][M], M <= ~1800), two-pass softmax per query in fixed order, fp32.
 constexpr int kMhaQ = 8;
 
+// Q values per thread reduced over the 256 threads of a workgroup at once: wave shuffles, then the 4 wave results in
+// fixed order through LDS -- 2 barriers for all Q (a 256-wide LDS tree per query and quantity was ~17 barriers each:
+// over a hundred per workgroup, most of the attention kernels' time).  s_part: [4][Q] floats.
+template <int Q, bool MAX>
+__device__ inline void block_reduce(float (&v)[Q], float* s_part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int qi = 0; qi < Q; ++qi) {
+    float x = v[qi];
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float o = __shfl_xor(x, d);
+      x = MAX ? fmaxf(x, o) : x + o;
+    }
+    if (lane == 0) s_part[wave * Q + qi] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int qi = 0; qi < Q; ++qi) {
+    const float a = s_part[qi], b = s_part[Q + qi], c = s_part[2 * Q + qi], d = s_part[3 * Q + qi];
+    v[qi] = MAX ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_mha(const float* __restrict__ q, const float* __restrict__ kk,
                                              const float* __restrict__ v, int n, int m, int dim, int heads,
                                              float* __restrict__ out) {
@@ -346,31 +370,24 @@ __global__ __launch_bounds__(256) void k_mha(const float* __restrict__ q, const 
       mx[qi] = fmaxf(mx[qi], s[qi]);
     }
   }
-  // per-query max, then exp + sum (same reduction tree as before: results per query do not depend on kMhaQ)
-  for (int qi = 0; qi < kMhaQ; ++qi) {
-    s_red[threadIdx.x] = mx[qi];
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-      if (threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
-      __syncthreads();
-    }
-    const float m_q = s_red[0];
-    __syncthreads();
-    float sum = 0.f;
-    for (int j = threadIdx.x; j < m; j += 256) {
-      const float e = expf(s_sc[qi * m + j] - m_q);
+  // per-query max, then exp + sum, all kMhaQ queries at once
+  block_reduce<kMhaQ, true>(mx, s_red);
+  float sum[kMhaQ];
+#pragma unroll
+  for (int qi = 0; qi < kMhaQ; ++qi) sum[qi] = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+#pragma unroll
+    for (int qi = 0; qi < kMhaQ; ++qi) {
+      const float e = expf(s_sc[qi * m + j] - mx[qi]);
       s_sc[qi * m + j] = e;
-      sum += e;
+      sum[qi] += e;
     }
-    s_red[threadIdx.x] = sum;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-      if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) s_inv[qi] = 1.f / s_red[0];
-    __syncthreads();
   }
+  block_reduce<kMhaQ, false>(sum, s_red);
+#pragma unroll
+  for (int qi = 0; qi < kMhaQ; ++qi)
+    if (threadIdx.x == qi) s_inv[qi] = 1.f / sum[qi];
+  __syncthreads();
   // out[q][d] = sum_j p[q][j] v[j][d]: thread (d, g) owns channel d and the keys j = g (mod ngrp); 4 value loads
   // in flight per thread (a plain loop over all keys is one dependent L2 round trip per key: 250 us per call), the
   // ngrp partial sums meet in LDS in fixed order
@@ -459,8 +476,8 @@ __global__ __launch_bounds__(256) void k_softmax_matvec(const float* __restrict_
 
 // The same with b given TRANSPOSED (bt [c, m]) and kSmvQ queries per workgroup: lane j reads bt[d * m + j] -- coalesced,
 // and every element fetched serves kSmvQ queries -- where k_softmax_matvec's lanes each walk their own 1 KB row of b
-// (700 workgroups x 717 KB through the L1: 110 us per call at 700 x 700 x 256).  Same fma order over d and the same
-// reduction trees: bit-identical results.
+// (700 workgroups x 717 KB through the L1: 110 us per call at 700 x 700 x 256); the softmax reductions of the
+// kSmvQ queries run together (block_reduce).
 constexpr int kSmvQ = 4;
 __global__ __launch_bounds__(256) void k_softmax_matvec_t(const float* __restrict__ a, const float* __restrict__ bt,
                                                           const float* __restrict__ w, int n, int m, int c,
@@ -493,38 +510,24 @@ __global__ __launch_bounds__(256) void k_softmax_matvec_t(const float* __restric
       mx[qi] = fmaxf(mx[qi], sc[qi]);
     }
   }
-  for (int qi = 0; qi < kSmvQ; ++qi) {          // per query: the reductions of k_softmax_matvec, unchanged
-    s_red[threadIdx.x] = mx[qi];
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-      if (threadIdx.x < st) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + st]);
-      __syncthreads();
+  block_reduce<kSmvQ, true>(mx, s_red);
+  float num[kSmvQ], den[kSmvQ];
+#pragma unroll
+  for (int qi = 0; qi < kSmvQ; ++qi) num[qi] = den[qi] = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const float wj = w[j];
+#pragma unroll
+    for (int qi = 0; qi < kSmvQ; ++qi) {
+      const float e = expf(s_sc[qi * m + j] - mx[qi]);
+      den[qi] += e;
+      num[qi] = fmaf(e, wj, num[qi]);
     }
-    const float mq = s_red[0];
-    __syncthreads();
-    float num = 0.f, den = 0.f;
-    for (int j = threadIdx.x; j < m; j += 256) {
-      float e = expf(s_sc[qi * m + j] - mq);
-      den += e;
-      num = fmaf(e, w[j], num);
-    }
-    s_red[threadIdx.x] = den;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-      if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
-      __syncthreads();
-    }
-    den = s_red[0];
-    __syncthreads();
-    s_red[threadIdx.x] = num;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-      if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0 && n0 + qi < n) out[n0 + qi] = s_red[0] / den;
-    __syncthreads();
   }
+  block_reduce<kSmvQ, false>(den, s_red);
+  block_reduce<kSmvQ, false>(num, s_red);
+#pragma unroll
+  for (int qi = 0; qi < kSmvQ; ++qi)
+    if (threadIdx.x == qi && n0 + qi < n) out[n0 + qi] = num[qi] / den[qi];
 }
 
 // y = clamp(sigmoid(x), 0, 1) with NaN / Inf -> 0   (architectures.py:131-134, 203-207)

@@ -284,9 +284,9 @@ def test_single_thread_pipelined_predator_matches_blocking_calls(dev):
         assert np.array_equal(Ta, Tb) and ia == ib
 
 
-def test_softmax_matvec_transposed_kernel_has_the_same_bits(dev):
-    """kp_ops.softmax_matvec runs apr_softmax_matvec_bt (keys transposed, 4 queries per workgroup): same fma order and
-    reduction trees as apr_softmax_matvec, so the very same bits; both against the float64 statement."""
+def test_softmax_matvec_transposed_kernel(dev):
+    """kp_ops.softmax_matvec runs apr_softmax_matvec_bt (keys transposed, 4 queries per workgroup, the softmax sums by
+    wave shuffles): against apr_softmax_matvec (LDS trees) and against the float64 statement."""
     from apr_amd import _lib
     from apr_amd._lib import check, ptr, stream
     g = torch.Generator().manual_seed(3)
@@ -297,6 +297,6 @@ def test_softmax_matvec_transposed_kernel_has_the_same_bits(dev):
         got = kp_ops.softmax_matvec(a, b, w, 0.0367)
         old = torch.empty(n, device=dev)
         check(_lib.load().apr_softmax_matvec(ptr(a), ptr(b), ptr(w), n, m, c, 0.0367, ptr(old), stream()))
-        assert torch.equal(got, old)
+        assert torch.allclose(got, old, rtol=2e-6, atol=2e-7)
         ref = torch.softmax(a.double() @ b.double().t() / 0.0367, dim=1) @ w.double()
         assert rel_l2(got.cpu().double(), ref.cpu()) < 1e-5
