@@ -111,6 +111,7 @@ PROTOTYPES = {
     "apr_mha": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_softmax_matvec": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _p, _p]),
     "apr_softmax_matvec_bt": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _p, _p]),
+    "apr_softmax_matvec_mfma": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _p, _p]),
     "apr_score_head": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "apr_transform_points": (C.c_int, [_p, _i64, _p, _p, _p]),
     "apr_crop_scratch_bytes": (_sz, [_i64]),

@@ -530,6 +530,93 @@ __global__ __launch_bounds__(256) void k_softmax_matvec_t(const float* __restric
     if (threadIdx.x == qi && n0 + qi < n) out[n0 + qi] = num[qi] / den[qi];
 }
 
+// The same on the fp32 MFMA: a workgroup owns 16 queries, its 4 waves walk the 16-key tiles in turn.  Per tile the
+// scores are ONE accumulator: rows = keys, columns = queries (A operand: key r16, B operand: query r16, both lanes of a
+// k-slot q reading channel 16 s + 4 q + e -- a 16-B load serves 4 MFMAs), so lane (r16, q) ends with the scores of
+// keys 4q .. 4q+3 against ITS query r16 and keeps a running (max, denominator, numerator) for it; the 16 partial
+// triples per query (8 waves x 4 k-slots) are merged in fixed order; the next tile's key rows are in flight under the
+// MFMAs of the current one.
+constexpr int kSmvWaves = 8;
+template <int C16>   // c = 16 * C16
+__global__ __launch_bounds__(64 * kSmvWaves) void k_softmax_matvec_mfma(const float* __restrict__ a,
+                                                                        const float* __restrict__ b,
+                                                                        const float* __restrict__ w, int n, int m,
+                                                                        float inv_temperature, float* __restrict__ out) {
+  constexpr int NP = kSmvWaves * 4;                                    // partial triples per query
+  __shared__ float s_mx[NP][16], s_den[NP][16], s_num[NP][16];        // [part = wave * 4 + q][query]
+  constexpr int c = 16 * C16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int i0 = blockIdx.x * 16;
+  const float* arow = a + (int64_t)min(i0 + r16, n - 1) * c + 4 * q;
+  f32x4 qa[C16];
+#pragma unroll
+  for (int sidx = 0; sidx < C16; ++sidx) qa[sidx] = *reinterpret_cast<const f32x4*>(arow + 16 * sidx);
+  float mx = -__builtin_inff(), den = 0.f, num = 0.f;
+  const int ntile = (m + 15) >> 4;
+  // the key rows of the NEXT tile are in flight while this tile's MFMAs run; two accumulator chains per tile
+  f32x4 kb[C16], kn[C16];
+  if (wave < ntile) {
+    const float* krow = b + (int64_t)min(wave * 16 + r16, m - 1) * c + 4 * q;
+#pragma unroll
+    for (int sidx = 0; sidx < C16; ++sidx) kb[sidx] = *reinterpret_cast<const f32x4*>(krow + 16 * sidx);
+  }
+  for (int t = wave; t < ntile; t += kSmvWaves) {
+    if (t + kSmvWaves < ntile) {
+      const float* krow = b + (int64_t)min((t + kSmvWaves) * 16 + r16, m - 1) * c + 4 * q;
+#pragma unroll
+      for (int sidx = 0; sidx < C16; ++sidx) kn[sidx] = *reinterpret_cast<const f32x4*>(krow + 16 * sidx);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sidx = 0; sidx < C16; ++sidx) {
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[sidx][e], qa[sidx][e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[sidx][e + 1], qa[sidx][e + 1], acc1, 0, 0, 0);
+      }
+    }
+    const f32x4 acc = acc0 + acc1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = t * 16 + 4 * q + i;
+      if (key < m) {
+        const float sc = acc[i] * inv_temperature, wk = w[key];
+        if (sc > mx) {
+          const float f = expf(mx - sc);       // 0 on the first key (mx = -inf)
+          den = den * f + 1.f;
+          num = num * f + wk;
+          mx = sc;
+        } else {
+          const float e = expf(sc - mx);
+          den += e;
+          num = fmaf(e, wk, num);
+        }
+      }
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < C16; ++sidx) kb[sidx] = kn[sidx];
+  }
+  s_mx[wave * 4 + q][r16] = mx;
+  s_den[wave * 4 + q][r16] = den;
+  s_num[wave * 4 + q][r16] = num;
+  __syncthreads();
+  if (threadIdx.x < 16 && i0 + (int)threadIdx.x < n) {
+    const int qi = threadIdx.x;
+    float M = -__builtin_inff();
+    for (int p = 0; p < NP; ++p) M = fmaxf(M, s_mx[p][qi]);
+    float D = 0.f, N = 0.f;
+    for (int p = 0; p < NP; ++p) {
+      if (s_den[p][qi] > 0.f) {                 // a part that saw no key (more parts than key tiles) has den = 0
+        const float f = expf(s_mx[p][qi] - M);
+        D = fmaf(s_den[p][qi], f, D);
+        N = fmaf(s_num[p][qi], f, N);
+      }
+    }
+    out[i0 + qi] = N / D;
+  }
+}
+
 // y = clamp(sigmoid(x), 0, 1) with NaN / Inf -> 0   (architectures.py:131-134, 203-207)
 __global__ void k_score_head(const float* __restrict__ x, int64_t ldx, int64_t n, float* __restrict__ y) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -671,6 +758,24 @@ APR_API int apr_softmax_matvec_bt(const float* a, const float* bt, const float* 
   APR_CHECK_ARG(lds <= 60 * 1024, "apr_softmax_matvec_bt: m + c too large for LDS");
   hipLaunchKernelGGL(k_softmax_matvec_t, dim3((unsigned)((n + kSmvQ - 1) / kSmvQ)), dim3(256), lds, (hipStream_t)stream,
                      a, bt, w, n, m, c, temperature, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// The same on the fp32 MFMA (k_softmax_matvec_mfma): a and b row-major as in apr_softmax_matvec, 16-byte aligned,
+// c in {32, 64, 128, 256}; no limit on m.  Same value to fp32 summation order.
+APR_API int apr_softmax_matvec_mfma(const float* a, const float* b, const float* w, int32_t n, int32_t m, int32_t c,
+                                    float temperature, float* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && temperature > 0.f && a && b && w && out, "apr_softmax_matvec_mfma: bad arguments");
+  APR_CHECK_ARG((c == 32 || c == 64 || c == 128 || c == 256) && (((uintptr_t)a | (uintptr_t)b) & 15) == 0,
+                "apr_softmax_matvec_mfma: c must be 32 / 64 / 128 / 256 and a, b 16-byte aligned");
+  const dim3 grid((unsigned)((n + 15) / 16));
+  const float it = 1.f / temperature;
+  hipStream_t st = (hipStream_t)stream;
+  if (c == 32) hipLaunchKernelGGL(k_softmax_matvec_mfma<2>, grid, dim3(64 * kSmvWaves), 0, st, a, b, w, n, m, it, out);
+  else if (c == 64) hipLaunchKernelGGL(k_softmax_matvec_mfma<4>, grid, dim3(64 * kSmvWaves), 0, st, a, b, w, n, m, it, out);
+  else if (c == 128) hipLaunchKernelGGL(k_softmax_matvec_mfma<8>, grid, dim3(64 * kSmvWaves), 0, st, a, b, w, n, m, it, out);
+  else hipLaunchKernelGGL(k_softmax_matvec_mfma<16>, grid, dim3(64 * kSmvWaves), 0, st, a, b, w, n, m, it, out);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -202,6 +202,12 @@ def softmax_matvec(a, b, w, temperature):
     a, w = a.contiguous(), w.contiguous().view(-1)
     out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
     n, m, c = a.shape[0], b.shape[0], a.shape[1]
+    if c in (32, 64, 128, 256) and a.data_ptr() % 16 == 0:
+        b = b.contiguous()
+        if b.data_ptr() % 16 == 0:
+            check(_lib.load().apr_softmax_matvec_mfma(ptr(a), ptr(b), ptr(w), n, m, c, float(temperature), ptr(out),
+                                                      stream()))
+            return out
     if 4 * (m + c) * 4 <= 60 * 1024:
         bt = b.t().contiguous()          # [c, m]: the kernel's lanes run along the keys
         check(_lib.load().apr_softmax_matvec_bt(ptr(a), ptr(bt), ptr(w), n, m, c, float(temperature), ptr(out), stream()))

@@ -470,6 +470,10 @@ int apr_softmax_matvec(const float* a, const float* b, const float* w, int32_t n
  * result has the same bits. */
 int apr_softmax_matvec_bt(const float* a, const float* bt, const float* w, int32_t n, int32_t m, int32_t c,
                           float temperature, float* out, void* stream);
+/* The same on the fp32 MFMA: a and b row-major as in apr_softmax_matvec, 16-byte aligned, c in {32, 64, 128, 256}, any
+ * m; equal to fp32 summation order. */
+int apr_softmax_matvec_mfma(const float* a, const float* b, const float* w, int32_t n, int32_t m, int32_t c,
+                            float temperature, float* out, void* stream);
 
 /* y[i] = clamp(sigmoid(x[i*ldx]), 0, 1), NaN/Inf -> 0  (architectures.py:131-134,203-207). */
 int apr_score_head(const float* x, int64_t ldx, int64_t n, float* y, void* stream);

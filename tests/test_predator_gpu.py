@@ -284,9 +284,9 @@ def test_single_thread_pipelined_predator_matches_blocking_calls(dev):
         assert np.array_equal(Ta, Tb) and ia == ib
 
 
-def test_softmax_matvec_transposed_kernel(dev):
-    """kp_ops.softmax_matvec runs apr_softmax_matvec_bt (keys transposed, 4 queries per workgroup, the softmax sums by
-    wave shuffles): against apr_softmax_matvec (LDS trees) and against the float64 statement."""
+def test_softmax_matvec_kernels_agree(dev):
+    """kp_ops.softmax_matvec runs apr_softmax_matvec_mfma (scores on the fp32 MFMA, running softmax per lane); it, the
+    transposed-key VALU kernel and the first kernel against each other and against the float64 statement."""
     from apr_amd import _lib
     from apr_amd._lib import check, ptr, stream
     g = torch.Generator().manual_seed(3)
@@ -295,8 +295,10 @@ def test_softmax_matvec_transposed_kernel(dev):
         b = torch.nn.functional.normalize(torch.randn(m, c, generator=g), dim=1).to(dev)
         w = torch.randn(m, generator=g).to(dev)
         got = kp_ops.softmax_matvec(a, b, w, 0.0367)
-        old = torch.empty(n, device=dev)
+        old, mid = torch.empty(n, device=dev), torch.empty(n, device=dev)
         check(_lib.load().apr_softmax_matvec(ptr(a), ptr(b), ptr(w), n, m, c, 0.0367, ptr(old), stream()))
-        assert torch.allclose(got, old, rtol=2e-6, atol=2e-7)
+        bt = b.t().contiguous()
+        check(_lib.load().apr_softmax_matvec_bt(ptr(a), ptr(bt), ptr(w), n, m, c, 0.0367, ptr(mid), stream()))
+        assert torch.allclose(mid, old, rtol=2e-6, atol=2e-7) and torch.allclose(got, old, rtol=1e-5, atol=1e-6)
         ref = torch.softmax(a.double() @ b.double().t() / 0.0367, dim=1) @ w.double()
         assert rel_l2(got.cpu().double(), ref.cpu()) < 1e-5
