@@ -530,9 +530,10 @@ def main():
                     "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
                     "mfma_tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12}
 
-        names = {"tile": "k_spconv_pairs", "ws": "k_ws_gemm+k_ws_reduce"}
+        names = {"tile": "k_spconv_pairs", "ws": "k_ws_gemm_bf3+k_ws_reduce"}
         what = {"tile": "pair-compacted gather -> MFMA -> fused epilogue, one kernel",
-                "ws": "weight-stationary gather -> MFMA (k_ws_gemm), then per-row sum + fused epilogue (k_ws_reduce)"}
+                "ws": "weight-stationary gather -> bf16 MFMA in an exact 3-way split, fp32-equivalent FLOP priced against "
+                      "the fp32-MFMA peak (k_ws_gemm_bf3), then per-row sum + fused epilogue (k_ws_reduce)"}
         legs = {k: leg(d) for k, d in s["by_path"].items()}
         dom = max(s["by_path"], key=lambda k: s["by_path"][k]["ms"])      # dominant kernel by summed time
         dd, dl = s["by_path"][dom], legs[dom]
