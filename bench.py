@@ -389,7 +389,8 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     results = {}
     step_log = []      # (step, worker, host start, host end) of every step
-    job = {"first": 0, "last": 0, "stop": False, "err": None}
+    job = {"first": 0, "last": 0, "stop": False, "err": None, "next": 0}
+    take = threading.Lock()
     go = threading.Barrier(nstreams + 1)
     done = threading.Barrier(nstreams + 1)
 
@@ -401,7 +402,12 @@ def main():
                 if job["stop"]:
                     return
                 try:
-                    for i in range(job["first"] + w, job["last"], nstreams):
+                    while True:      # the next unclaimed step (a static deal leaves workers idle at the tail)
+                        with take:
+                            i = job["next"]
+                            job["next"] = i + 1
+                        if i >= job["last"]:
+                            break
                         ta = time.perf_counter()
                         results[i] = step(i)
                         step_log.append((i, w, ta, time.perf_counter()))
@@ -431,7 +437,7 @@ def main():
             for st in streams:
                 st.synchronize()
             return
-        job["first"], job["last"] = first, last
+        job["first"], job["last"], job["next"] = first, last, first
         go.wait()
         done.wait()
         if job["err"] is not None:
