@@ -435,8 +435,12 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
     float d2 = 0.f;
     int sidx = -1;
     if (t < total) {
-      int L = 0;                        // cell range holding candidate t: first L with incl[L] > t
-      while (s_incl[wave][L] <= t) ++L;
+      // cell range holding candidate t: first L with incl[L] > t (27 sorted entries: 5 LDS probes instead of a scan
+      // that averages 13)
+      int L = 0;
+#pragma unroll
+      for (int step = 16; step >= 1; step >>= 1)
+        if (L + step <= 26 && s_incl[wave][L + step - 1] <= t) L += step;
       const int before = L ? s_incl[wave][L - 1] : 0;
       sidx = g.sorted[s_lo[wave][L] + (t - before)];
       const float dx = __fsub_rn(qx, s[3 * (int64_t)sidx]), dy = __fsub_rn(qy, s[3 * (int64_t)sidx + 1]),
@@ -477,7 +481,9 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
           int sidx = -1;
           if (t < total) {
             int L = 0;
-            while (s_incl[wave][L] <= t) ++L;
+#pragma unroll
+            for (int step = 16; step >= 1; step >>= 1)
+              if (L + step <= 26 && s_incl[wave][L + step - 1] <= t) L += step;
             const int before = L ? s_incl[wave][L - 1] : 0;
             sidx = g.sorted[s_lo[wave][L] + (t - before)];
             const float dx = __fsub_rn(qx, s[3 * (int64_t)sidx]), dy = __fsub_rn(qy, s[3 * (int64_t)sidx + 1]),
