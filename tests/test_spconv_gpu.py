@@ -61,11 +61,18 @@ def test_spconv_matches_oracle(dev, cin, cout, K, n_in, n_out):
     (64, 64, 27, 31, 31, 0.3), (256, 256, 27, 1246, 1246, 0.29), (64, 64, 27, 40000, 40000, 0.27),
     (64, 64, 27, 500, 500, 0.0), (128, 64, 27, 100, 1000, 1.0), (512, 64, 27, 400, 700, 0.3),
 ])
-def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, density):
-    """apr_pairlist_build + apr_spconv_ws_fwd (strided / transposed / deep layers) against the same oracle,
-    with the fused epilogue and strided in / out / residual rows; also bit-stable run to run."""
+@pytest.mark.parametrize("gemm", ["fp32", "bf3"])
+def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, density, gemm):
+    """apr_pairlist_build + apr_spconv_ws_fwd[_bf3] (strided / transposed / deep layers) against the same oracle,
+    with the fused epilogue and strided in / out / residual rows; also bit-stable run to run.  `gemm`: the fp32-MFMA
+    kernel (k_ws_gemm) or the default of the encoder, the bf16 3-way split (k_ws_gemm_bf3<1|2|4>), which must keep
+    fp32 accuracy ROW BY ROW on inputs whose row magnitudes span 8 decades."""
     rng = np.random.default_rng(cin * 977 + cout + K + n_out)
     xw = torch.from_numpy(rng.standard_normal((n_in, cin + 32)).astype(np.float32))
+    if gemm == "bf3":
+        if cin not in (64, 128, 256):
+            pytest.skip("k_ws_gemm_bf3 covers cin 64 / 128 / 256")
+        xw = xw * torch.from_numpy(np.exp(rng.uniform(-9.2, 9.2, (n_in, 1))).astype(np.float32))
     x = xw[:, 32:]
     W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32))
     nbr = _random_map(rng, n_in, n_out, K, density)
@@ -74,19 +81,29 @@ def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
     resw = torch.from_numpy(rng.standard_normal((n_out, cout + 64)).astype(np.float32))
     res = resw[:, :cout]
     wp = ops.pack_weights(W.to(dev))
+    w3 = ops.pack_weights_bf3(W.to(dev)) if gemm == "bf3" else None
+    assert (w3 is not None) == (gemm == "bf3")
     nbr_d = torch.from_numpy(nbr).to(dev)
     pl = ops.build_pairlist(nbr_d)
     outw = torch.zeros(n_out, cout + 32, device=dev)
     xd, resd = xw.to(dev)[:, 32:], resw.to(dev)[:, :cout]
     out = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd, relu=True,
-                     out=outw[:, 32:], plist=pl)
+                     out=outw[:, 32:], plist=pl, w_bf3=w3)
     ref = _oracle_conv(x, nbr, W, scale, shift, res, relu=True)
     assert rel_l2(out.cpu(), ref) < 2e-6
+    # the bare contraction, row by row: every output row keeps fp32 accuracy at the magnitude of ITS OWN inputs (the
+    # bound is relative to sum_k |x_row| |W_k|, the scale a row's fp32 rounding errors live on: a row that cancels to
+    # near zero is not asked for more digits than fp32 has)
+    bare = ops.spconv(xd, nbr_d, K, cin, cout, wp, plist=pl, w_bf3=w3).cpu().double()
+    ref0 = _oracle_conv(x, nbr, W)
+    mag = _oracle_conv(x.abs(), nbr, W.abs()).norm(dim=1).clamp_min(1e-300)
+    assert float(((bare - ref0).norm(dim=1) / mag).max()) < 5e-6
+    assert rel_l2(bare, ref0) < 2e-6
     assert float(outw[:, :32].abs().max()) == 0.0          # neighbouring columns untouched
     # pair lists: one region per offset, counts consistent with the map
     assert np.array_equal(pl.counts(), (nbr >= 0).sum(axis=0))
     again = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd,
-                       relu=True, plist=ops.build_pairlist(nbr_d))
+                       relu=True, plist=ops.build_pairlist(nbr_d), w_bf3=w3)
     assert torch.equal(again, out)
     # and agrees with the tile kernel to fp32 summation-order noise
     tile = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd, relu=True)
@@ -172,27 +189,51 @@ def test_dense_gemm_bf3_matches_fp64(dev, m, cin, cout):
         ops.dense_gemm_bf3(wide_in[:, 1:1 + cin], w3, cin, cout)        # rows not 16-byte aligned: refused, loudly
 
 
-def test_weight_stationary_many_rounds(dev):
+@pytest.mark.parametrize("cin,cout,bf3", [(128, 64, 0), (64, 64, 1), (128, 64, 1), (256, 128, 1)])
+def test_weight_stationary_many_rounds(dev, cin, cout, bf3):
     """More units than resident workgroups (APR_WS_TARGET=4 is read once per process, hence the child process): every
-    workgroup walks several units, re-staging its weight slice, and the result must not change."""
+    workgroup walks several units, re-staging its weight slice, and the result must not change -- for the fp32 gemm
+    and for k_ws_gemm_bf3<1|2|4> (cin = 256 x K = 27 at many rounds included)."""
     import os, subprocess, sys
     code = (
         "import numpy as np, torch, sys\n"
         "from apr_amd import ops\n"
         "rng = np.random.default_rng(5)\n"
-        "n, cin, cout, K = 6000, 128, 64, 27\n"
+        f"n, cin, cout, K, bf3 = 6000, {cin}, {cout}, 27, {bf3}\n"
         "x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()\n"
         "W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / 30).astype(np.float32)).cuda()\n"
         "nbr = rng.integers(0, n, size=(n, K)).astype(np.int32); nbr[rng.random((n, K)) > 0.3] = -1\n"
         "nbr = torch.from_numpy(nbr).cuda()\n"
         "wp = ops.pack_weights(W)\n"
         "tile = ops.spconv(x, nbr, K, cin, cout, wp)\n"
-        "ws = ops.spconv(x, nbr, K, cin, cout, wp, plist=ops.build_pairlist(nbr))\n"
+        "w3 = ops.pack_weights_bf3(W) if bf3 else None\n"
+        "assert (w3 is not None) == bool(bf3)\n"
+        "ws = ops.spconv(x, nbr, K, cin, cout, wp, plist=ops.build_pairlist(nbr), w_bf3=w3)\n"
         "err = float((ws - tile).norm() / tile.norm())\n"
         "print('REL', err); sys.exit(0 if err < 1e-6 else 1)\n")
     env = dict(os.environ, APR_WS_TARGET="4", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_weight_stationary_bf3_empty_offsets_and_map(dev):
+    """k_ws_gemm_bf3 on a map whose offsets are mostly EMPTY (only 3 of 27 carry pairs) and on an all-empty map: the
+    unit table must skip the empty offsets, and the reduce must still write the epilogue of every row."""
+    rng = np.random.default_rng(11)
+    n, cin, cout, K = 3000, 64, 128, 27
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / 20).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    nbr = np.full((n, K), -1, np.int32)
+    for k in (0, 13, 26):
+        rows = rng.random(n) < 0.4
+        nbr[rows, k] = rng.integers(0, n, int(rows.sum()))
+    wp, w3 = ops.pack_weights(W.to(dev)), ops.pack_weights_bf3(W.to(dev))
+    for m in (nbr, np.full((n, K), -1, np.int32)):
+        md = torch.from_numpy(m).to(dev)
+        out = ops.spconv(x.to(dev), md, K, cin, cout, wp, shift=shift.to(dev), plist=ops.build_pairlist(md), w_bf3=w3)
+        ref = _oracle_conv(x, m, W, shift=shift)
+        assert rel_l2(out.cpu(), ref) < 2e-6
 
 
 def test_all_empty_offsets(dev):
