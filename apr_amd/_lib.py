@@ -34,7 +34,9 @@ class SpconvDesc(C.Structure):
                 ("w_packed", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("counters", C.c_void_p), ("plist", C.c_void_p), ("prod_scratch", C.c_void_p),
-                ("plist_bytes", C.c_int64), ("w_bf3", C.c_void_p)]
+                ("plist_bytes", C.c_int64), ("w_bf3", C.c_void_p),
+                ("os_pairs", C.c_void_p), ("os_rows", C.c_int64), ("os_build_bytes", C.c_int64),
+                ("os_n_in", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
@@ -70,6 +72,10 @@ PROTOTYPES = {
     "apr_norm_params": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _p, _p, _sz, _p]),
     "apr_bn_stats_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_instance_norm_act": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _sz, _p]),
+    "apr_spconv_os_tile_rows": (_i32, [_i64, _i32, _i32]),
+    "apr_spconv_os_pairs_bytes": (_sz, [_i64, _i32, _i32]),
+    "apr_spconv_os_pairs_build": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "apr_spconv_os_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_dense_gemm_bf3": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_weighted_choice_round": (C.c_int64, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i32]),
     "apr_instance_norm_act_seg": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _i32, _p, _sz, _p]),

@@ -634,7 +634,17 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
 
 static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e0, hipEvent_t e1) {
   hipStream_t st = (hipStream_t)stream;
-  if (d.plist) {
+  if (d.os_pairs && d.w_bf3) {   // output-stationary path (spconv_os.hip): tile lists built on first use of the map
+    if (d.os_build_bytes > 0) {
+      int rcb = apr_spconv_os_pairs_build(d.nbr, d.n_out, d.os_n_in, d.K, (int32_t)d.os_rows, d.os_pairs,
+                                          (size_t)d.os_build_bytes, stream);
+      if (rcb != APR_OK) return rcb;
+    }
+    if (e0) APR_HIP(hipEventRecord(e0, st));
+    int rco = apr_spconv_os_fwd(d.in, d.ldi, d.os_pairs, d.n_out, d.K, (int32_t)d.os_rows, d.cin, d.cout, d.w_bf3, d.scale,
+                                d.shift, d.residual, d.ldr, d.relu, d.out, d.ldo, stream);
+    if (rco != APR_OK) return rco;
+  } else if (d.plist) {
     if (d.plist_bytes > 0) {   // the pair-list build is per map, not part of the timed conv layer
       int rcb = apr_pairlist_build(d.nbr, d.n_out, d.K, d.counters, d.plist, (size_t)d.plist_bytes, stream);
       if (rcb != APR_OK) return rcb;

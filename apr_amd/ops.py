@@ -334,6 +334,64 @@ def build_pairlist(nbr, lazy=False, counters=None):
     return pl if lazy else pl.build()
 
 
+class OsPairs:
+    """Per-tile pair lists of one kernel map for the output-stationary conv (apr_spconv_os_pairs_build): tiles of `R`
+    consecutive output rows, K compact lists each.  `built` False: allocated only; the first launch of a SpconvBatch that
+    uses it builds it inside the same library call."""
+
+    def __init__(self, nbr, n_in, R):
+        self.nbr, self.n_in, self.R = nbr, int(n_in), int(R)
+        self.n_out, self.K = nbr.shape
+        nb = int(_lib_().apr_spconv_os_pairs_bytes(self.n_out, self.K, self.R))
+        self.blob = torch.empty(nb, dtype=torch.uint8, device=nbr.device)
+        self.built = False
+
+    def build(self):
+        if not self.built:
+            check(_lib_().apr_spconv_os_pairs_build(ptr(self.nbr), self.n_out, self.n_in, self.K, self.R, ptr(self.blob),
+                                                    self.blob.numel(), stream()))
+            self.built = True
+        return self
+
+
+def os_tile_rows(n_out, cin, cout):
+    """Rows per tile of the output-stationary conv for this layer shape; 0 = shape not covered."""
+    return int(_lib_().apr_spconv_os_tile_rows(n_out, cin, cout))
+
+
+def build_os_pairs(nbr, n_in, R, lazy=False):
+    if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2:
+        raise _lib.AprHipError("build_os_pairs: nbr must be a contiguous int32 [n_out, K] tensor")
+    p = OsPairs(nbr, n_in, R)
+    return p if lazy else p.build()
+
+
+def spconv_os(x, os_pairs, cin, cout, w_bf3, scale=None, shift=None, residual=None, relu=False, out=None):
+    """The sparse conv through apr_spconv_os_fwd (output-stationary, accumulators in LDS); os_pairs from build_os_pairs."""
+    x, ldi = _rows(x, "spconv_os.x")
+    if x.shape[1] != cin:
+        raise _lib.AprHipError(f"spconv_os: input has {x.shape[1]} channels, weight expects {cin}")
+    if x.shape[0] > os_pairs.n_in:
+        pass
+    n_out, K = os_pairs.n_out, os_pairs.K
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    out, ldo = _rows(out, "spconv_os.out")
+    if out.shape[0] != n_out or out.shape[1] != cout:
+        raise _lib.AprHipError("spconv_os: output shape mismatch")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "spconv_os.residual")
+        if residual.shape[0] != n_out or residual.shape[1] != cout:
+            raise _lib.AprHipError("spconv_os: residual shape mismatch")
+    if w_bf3 is None:
+        raise _lib.AprHipError("spconv_os: needs the bf16-split weights (pack_weights_bf3)")
+    os_pairs.build()
+    check(_lib_().apr_spconv_os_fwd(ptr(x), ldi, ptr(os_pairs.blob), n_out, K, os_pairs.R, cin, cout, ptr(w_bf3),
+                                    ptr(scale), ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
+    return out
+
+
 def ws_supported(K, cin, cout):
     return K <= 27 and cin % 64 == 0 and cin <= 512 and cout % 64 == 0
 
@@ -462,7 +520,7 @@ class SpconvBatch:
         self.meta = []      # (P, cin, cout, mfma?, path) per launch while a SpconvProfile is active
 
     def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
-            plist=None, w_bf3=None):
+            plist=None, w_bf3=None, os_pairs=None):
         x, ldi = _rows(x, "spconv.x")
         if nbr is not None:
             n_out = nbr.shape[0]
@@ -483,6 +541,13 @@ class SpconvBatch:
         d.residual = residual.data_ptr() if residual is not None else None
         d.ldr, d.out, d.ldo = ldr, out.data_ptr(), ldo
         prod = None
+        if os_pairs is not None and w_bf3 is not None and nbr is not None:
+            if os_pairs.n_out != n_out or os_pairs.K != K:
+                raise _lib.AprHipError("spconv: tile pair lists do not belong to this kernel map")
+            d.os_pairs, d.os_rows, d.os_n_in, d.w_bf3 = os_pairs.blob.data_ptr(), os_pairs.R, os_pairs.n_in, w_bf3.data_ptr()
+            if not os_pairs.built:
+                d.os_build_bytes, os_pairs.built = os_pairs.blob.numel(), True
+            plist = None
         if plist is not None and nbr is not None and ws_supported(K, cin, cout):
             if plist.n_out != n_out or plist.K != K:
                 raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
@@ -498,8 +563,8 @@ class SpconvBatch:
         self.descs.append(d)
         if PROFILE is not None:
             self.meta.append((PROFILE.pairs(nbr, n_out), cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0,
-                              "ws" if prod is not None else "tile"))
-        self.keep += [x, nbr, wp, scale, shift, residual, out, plist, prod, w_bf3]
+                              "os" if d.os_pairs else "ws" if prod is not None else "tile"))
+        self.keep += [x, nbr, wp, scale, shift, residual, out, plist, prod, w_bf3, os_pairs]
         return out
 
     def launch(self):

@@ -169,6 +169,22 @@ int apr_spconv_ws_fwd_bf3(const float* in, int64_t ldi, const int32_t* counters,
                           const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
                           float* out, int64_t ldo, float* prod_scratch, void* stream);
 
+/* Output-stationary form for the 64-channel levels (cin 64 or 128, cout % 64 == 0; same operator as apr_spconv_fwd,
+ * FCGF_APR/model/resunet.py:31-140, model/residual_block.py:23-33): the kernel map is cut into tiles of R consecutive
+ * output rows (R = apr_spconv_os_tile_rows, so that the tiles fill the chip in whole rounds), apr_spconv_os_pairs_build
+ * turns each tile's [R, K] slab into K compact pair lists (deterministic positions, no atomics; input rows < 2^23), and
+ * apr_spconv_os_fwd keeps a tile's fp32 accumulators in LDS while it walks the K offsets with the bf16-split weight
+ * slice of the offset staged by LDS-DMA: no product row ever goes through HBM (apr_spconv_ws_fwd writes and re-reads
+ * one per pair).  bf16 MFMA in the exact 3-way split (fp32-equivalent), sums in ascending offset order: bitwise
+ * reproducible.  w_bf3 = apr_spconv_pack_weights_bf3(w, K, cin, cout). */
+int32_t apr_spconv_os_tile_rows(int64_t n_out, int32_t cin, int32_t cout);
+size_t apr_spconv_os_pairs_bytes(int64_t n_out, int32_t K, int32_t R);
+int apr_spconv_os_pairs_build(const int32_t* nbr, int64_t n_out, int64_t n_in, int32_t K, int32_t R, void* os_pairs,
+                              size_t os_pairs_bytes, void* stream);
+int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs, int64_t n_out, int32_t K, int32_t R,
+                      int32_t cin, int32_t cout, const void* w_bf3, const float* scale, const float* shift,
+                      const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, void* stream);
+
 /* Weight gradient of apr_spconv_fwd (training; replaces what autograd does inside
  * MinkowskiConvolution / MinkowskiConvolutionTranspose, FCGF_APR/lib/trainer.py:454-527):
  *   dw f32[K, cin, cout] (plain layout, not packed) = sum_j [nbr[j,k] >= 0] in[nbr[j,k], :]^T dout[j, :].
@@ -193,6 +209,10 @@ typedef struct apr_spconv_desc {
   float* prod_scratch;    /* ... this product buffer (n_out*K rows); */
   int64_t plist_bytes;    /* > 0: apr_pairlist_build(nbr -> plist) first (first use of the map in the batch) */
   const void* w_bf3;      /* non-NULL (with plist): apr_spconv_ws_fwd_bf3 with these split weights */
+  void* os_pairs;         /* non-NULL (with w_bf3): run this launch through apr_spconv_os_fwd over these tile lists, */
+  int64_t os_rows;        /* ... of os_rows rows per tile; */
+  int64_t os_build_bytes; /* > 0: apr_spconv_os_pairs_build(nbr -> os_pairs, n_in = os_n_in) first */
+  int64_t os_n_in;
 } apr_spconv_desc;
 int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* stream);
 /* Same, with one HIP event pair per launch recorded on `stream` (around the conv kernels only, not a pair-list

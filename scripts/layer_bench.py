@@ -65,4 +65,21 @@ for name, ti, to, cin, cout, tr in layers:
             us3 = batched(pl, out3, w3)
             err3 = float((out3 - out).norm() / out.norm())
             line += f" | ws-bf3 {us3:7.1f} us {2.0*P*cin*cout/us3/1e6:6.1f} TF  (rel diff {err3:.1e})"
+        R = ops.os_tile_rows(cm.size(to), cin, cout) if w3 is not None else 0
+        if R:
+            t_ob = timeit(lambda: ops.build_os_pairs(nbr, cm.size(ti), R))
+            osp = ops.build_os_pairs(nbr, cm.size(ti), R)
+            out4 = torch.empty_like(out)
+            def os_batched():
+                b = ops.SpconvBatch()
+                for _ in range(20):
+                    b.add(x, nbr, 27, cin, cout, wp, out=out4, w_bf3=w3, os_pairs=osp)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); b.launch(); e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1000 / 20
+            os_batched()
+            us4 = os_batched()
+            err4 = float((out4 - out).norm() / out.norm())
+            line += f" | os R={R} {us4:7.1f} us {2.0*P*cin*cout/us4/1e6:6.1f} TF {(4.0*P*(cin+cout)+8*P)/us4/1e3:6.0f} GB/s (build {t_ob:5.1f} us, rel diff {err4:.1e})"
     print(line, flush=True)

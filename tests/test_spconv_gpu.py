@@ -262,3 +262,44 @@ def test_cpu_tensors_fail_loudly():
     from apr_amd._lib import AprHipError
     with pytest.raises(AprHipError):
         ops.affine_act(torch.ones(4, 4))
+
+
+@pytest.mark.parametrize("cin,cout,K,n_in,n_out,density", [
+    (64, 64, 27, 5000, 5000, 0.27), (64, 64, 27, 70001, 70001, 0.27), (64, 128, 27, 3000, 1100, 0.3),
+    (128, 64, 27, 1000, 9000, 0.12), (128, 128, 27, 2500, 2500, 0.3), (64, 64, 8, 700, 257, 0.5),
+    (64, 64, 27, 31, 31, 0.3), (64, 64, 27, 500, 500, 0.0), (128, 64, 27, 100, 1000, 1.0), (64, 64, 27, 40, 2000, 0.02),
+])
+def test_output_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, density):
+    """apr_spconv_os_pairs_build + apr_spconv_os_fwd (accumulators in LDS, no product rows) against the fp64 oracle:
+    fused epilogue, strided in / out / residual rows, row magnitudes over 8 decades (fp32 accuracy row by row), ragged
+    last tile, empty offsets / empty map, more than 8 groups per (tile, offset) (density 1.0), and bit-stable run to run."""
+    rng = np.random.default_rng(cin * 977 + cout + K + n_out)
+    xw = torch.from_numpy(rng.standard_normal((n_in, cin + 32)).astype(np.float32))
+    xw = xw * torch.from_numpy(np.exp(rng.uniform(-9.2, 9.2, (n_in, 1))).astype(np.float32))
+    x = xw[:, 32:]
+    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32))
+    nbr = _random_map(rng, n_in, n_out, K, density)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    resw = torch.from_numpy(rng.standard_normal((n_out, cout + 64)).astype(np.float32))
+    res = resw[:, :cout]
+    w3 = ops.pack_weights_bf3(W.to(dev))
+    nbr_d = torch.from_numpy(nbr).to(dev)
+    R = ops.os_tile_rows(n_out, cin, cout)
+    assert R > 0 and R % 16 == 0
+    for rows in sorted({R, 64}):
+        pairs = ops.build_os_pairs(nbr_d, n_in, rows)
+        outw = torch.zeros(n_out, cout + 32, device=dev)
+        xd, resd = xw.to(dev)[:, 32:], resw.to(dev)[:, :cout]
+        out = ops.spconv_os(xd, pairs, cin, cout, w3, scale=scale.to(dev), shift=shift.to(dev), residual=resd, relu=True,
+                            out=outw[:, 32:])
+        ref = _oracle_conv(x, nbr, W, scale, shift, res, relu=True)
+        assert rel_l2(out.cpu(), ref) < 2e-6
+        assert float(outw[:, :32].abs().max()) == 0.0          # neighbouring columns untouched
+        bare = ops.spconv_os(xd, pairs, cin, cout, w3).cpu().double()
+        ref0 = _oracle_conv(x, nbr, W)
+        mag = _oracle_conv(x.abs(), nbr, W.abs()).norm(dim=1).clamp_min(1e-300)
+        assert float(((bare - ref0).norm(dim=1) / mag).max()) < 5e-6
+        again = ops.spconv_os(xd, ops.build_os_pairs(nbr_d, n_in, rows), cin, cout, w3, scale=scale.to(dev),
+                              shift=shift.to(dev), residual=resd, relu=True)
+        assert torch.equal(again, out)
