@@ -169,6 +169,21 @@ class CoordinateManager:
         return pl
 
 
+    def os_pair_list(self, ts_in, ts_out, kernel_size, transpose, cin, cout):
+        """Per-tile pair lists of kernel_map(...) for the output-stationary conv path (ops.OsPairs, cached per map and
+        tile height), or None when the layer shape is not covered (apr_spconv_os_tile_rows)."""
+        nbr = self.kernel_map(ts_in, ts_out, kernel_size, transpose)
+        n_in = self.size(ts_in)
+        rows = ops.os_tile_rows(nbr.shape[0], cin, cout) if n_in < (1 << 23) and nbr.shape[1] <= 27 else 0
+        if rows <= 0:
+            return None
+        key = ("os", ts_in, ts_out, kernel_size, transpose, rows)
+        pl = self._plists.get(key)
+        if pl is None:
+            pl = self._plists[key] = ops.build_os_pairs(nbr, n_in, rows, lazy=True)
+        return pl
+
+
 class SparseTensor:
     def __init__(self, features, coordinates=None, coordinate_map_key=None, coordinate_manager=None,
                  device=None, **unused):
@@ -372,10 +387,11 @@ class _ConvBase(nn.Module):
         if shift is None and self.bias is not None:
             shift = self.bias.view(-1)
         fn = ops.spconv if batch is None else batch.add
+        os_pairs = plist if isinstance(plist, ops.OsPairs) else None     # output-stationary tile lists
         return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
                   self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
-                  relu=relu, out=out, n_out=n_out, plist=plist,
-                  w_bf3=self.packed_weight_bf3() if plist is not None else None)
+                  relu=relu, out=out, n_out=n_out, plist=None if os_pairs is not None else plist,
+                  w_bf3=self.packed_weight_bf3() if plist is not None else None, os_pairs=os_pairs)
 
     def _reverse_map(self, x: SparseTensor, nbr_fwd, ts_out):
         """Map of the input gradient: (table, mirrored offsets?)  (backward)."""

@@ -62,7 +62,78 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print("[apr_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if any(os.path.basename(src) == "spconv_os.hip" for src, _ in jobs):
+        check_os_pipeline(verbose)
     return LIB
+
+
+def check_os_pipeline(verbose: bool = True) -> None:
+    """spconv_os.hip keeps gathered rows in flight in registers across the item loop's back edge (inline-asm loads +
+    counted s_waitcnt).  A register copy of such a value made by the compiler BEFORE its wait would read stale data, and
+    nothing at run time would say so: compile the file to assembly and refuse the build if any move / spill instruction
+    inside k_os_conv reads a register that an inline-asm global_load_dwordx4 writes."""
+    import re
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(CSRC, "spconv_os.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "os.s")
+        subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               "-Wno-unused-command-line-argument", "-o", out, src], stderr=subprocess.DEVNULL)
+        text = open(out).read().splitlines()
+
+    def regs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    # per kernel: the lines of the item loop = from the first counted wait of the pipeline to the last one
+    bodies, kernel = {}, None
+    for ln in text:
+        m = re.match(r"^(_Z\S*k_os_conv\S*):", ln)
+        if m:
+            kernel = m.group(1)
+            bodies[kernel] = []
+        elif ln.strip().startswith(".Lfunc_end"):
+            kernel = None
+        elif kernel is not None:
+            bodies[kernel].append(ln.strip())
+    loaded, bad = {}, []
+    for k, lines in bodies.items():
+        marks = [i for i, t in enumerate(lines) if t.startswith("s_waitcnt vmcnt(5)")]
+        loaded[k] = set()
+        if not marks:
+            continue
+        body = lines[marks[0]:marks[-1] + 1]
+        in_asm, moves = False, []
+        for t in body:
+            if "#ASMSTART" in t:
+                in_asm = True
+            elif "#ASMEND" in t:
+                in_asm = False
+            ops = t.replace(",", " ").split()
+            if not ops:
+                continue
+            if in_asm and ops[0] == "global_load_dwordx4":
+                loaded[k] |= regs(ops[1])
+            elif not in_asm and ops[0] in ("v_mov_b32_e32", "v_mov_b64_e32", "v_accvgpr_write_b32", "v_accvgpr_mov_b32"):
+                moves.append((ops, t))
+        for ops, t in moves:
+            src_regs = set()
+            for tok in ops[2:]:
+                src_regs |= regs(tok)
+            if src_regs & loaded[k]:
+                bad.append(t)
+    if not loaded or not all(loaded.values()):
+        raise RuntimeError("check_os_pipeline: found no inline-asm row loads in k_os_conv (the check is out of date)")
+    if bad:
+        raise RuntimeError("spconv_os.hip: the compiler copies registers of the in-flight row pipeline:\n  " +
+                           "\n  ".join(bad[:8]))
+    if verbose:
+        print(f"[apr_amd.build] spconv_os pipeline check: {sum(len(v) for v in loaded.values())} row registers, "
+              "no copies", flush=True)
 
 
 if __name__ == "__main__":

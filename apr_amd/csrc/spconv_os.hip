@@ -30,10 +30,16 @@ constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kInBits = 23;                      // input row in the low 23 bits of a pair word, local output row above
 constexpr unsigned kInMask = (1u << kInBits) - 1u;
+constexpr int kSched = 128;                      // schedule words per tile (27 offsets x <= 4 slots)
+constexpr int kSlice = 24576;                    // bf16-split slice W[k][:, 64 columns] of a 64-channel input: 3 x 8 KB
+constexpr int kRing = 8;                         // pair-word ring: slots of 64 B per wave
 
+// schedule word of one ITEM = (offset k, slot s): in slot s wave w owns the 16-pair group w + 8 s of the offset's list
+//   bits 0-4 k | 5-7 s | 8 last slot of the offset | 9-13 next live offset (31: none) | 16-31 pairs of the offset
 struct OsViews {
-  int* cnt;         // [ntiles][32]  pairs of (tile, offset)
-  unsigned* pair;   // [ntiles][K][R]
+  int* cnt;          // [ntiles][32]  pairs of (tile, offset); entry 31 = items of the tile
+  unsigned* sched;   // [ntiles][kSched]
+  unsigned* pair;    // [ntiles][K][R]
 };
 
 __host__ __device__ inline size_t os_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -41,14 +47,17 @@ __host__ __device__ inline size_t os_align256(size_t x) { return (x + 255) & ~(s
 __host__ __device__ inline OsViews os_carve(void* blob, int64_t ntiles) {
   OsViews v;
   v.cnt = (int*)blob;
-  v.pair = (unsigned*)((char*)blob + os_align256((size_t)ntiles * 32 * 4));
+  v.sched = (unsigned*)((char*)blob + os_align256((size_t)ntiles * 32 * 4));
+  v.pair = (unsigned*)((char*)v.sched + os_align256((size_t)ntiles * kSched * 4));
   return v;
 }
 
 // One workgroup per tile: the [rows, K] slab through LDS (coalesced), wave w ranks offsets w, w + 8, ... by ballot +
-// popcount over 64-row chunks and writes the compact list of (tile, offset) in row order.
+// popcount over 64-row chunks and writes the compact list of (tile, offset) in row order; wave 0 then lays out the
+// tile's item schedule.
 __global__ __launch_bounds__(kThreads) void k_os_build(const int* __restrict__ nbr, int n_out, int K, int R, OsViews v) {
-  extern __shared__ int s_nbr[];   // [R][K]
+  extern __shared__ int s_nbr[];   // [R][K] + 32 counts
+  int* const s_cnt = s_nbr + R * K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int row0 = tile * R;
@@ -81,176 +90,242 @@ __global__ __launch_bounds__(kThreads) void k_os_build(const int* __restrict__ n
         run += __popcll(m);
       }
     }
-    if (lane == 0) v.cnt[tile * 32 + k] = run;
+    if (lane == 0) s_cnt[k] = run;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int c = (lane < 32) ? s_cnt[lane] : 0;
+    const unsigned long long live = __ballot(c > 0);
+    const int ns = (((c + 15) >> 4) + kWaves - 1) / kWaves;      // slots of this offset (0: no pairs)
+    int first = apr_wave_incl_scan(ns) - ns;
+    const int items = __shfl(first + ns, 63);
+    const unsigned long long above = (lane >= 63) ? 0ull : (live & ~((2ull << lane) - 1ull));
+    const unsigned knext = above ? (unsigned)__builtin_ctzll(above) : 31u;
+    for (int s2 = 0; s2 < ns; ++s2)
+      v.sched[(int64_t)tile * kSched + first + s2] =
+          (unsigned)lane | ((unsigned)s2 << 5) | ((s2 == ns - 1) ? 256u : 0u) | (knext << 9) | ((unsigned)c << 16);
+    if (lane < 31) v.cnt[tile * 32 + lane] = c;
+    if (lane == 31) v.cnt[tile * 32 + 31] = items;
   }
 }
 
-// workgroup-uniform position in the item sequence: (offset k, slot g); k = 64: past the end
-struct OsIt {
-  int k, g;
-};
+// ---- the row pipeline: loads issued and waited for by hand (inline asm, counted s_waitcnt).  Left to the compiler, the
+// merge of its load scoreboard over the paths of the item loop ends in vmcnt(0) at the top of two items out of three.  The
+// destination registers are ordinary values (three buffers used in turn, the loop body written three times): the wait
+// statement takes them as in/out operands, so every use of a row is ordered behind its wait.  apr_amd/build.py checks the
+// disassembly for register copies out of these buffers (a copy made while the load is in flight would read stale data).
+#define APR_OS_LOAD16(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR))
+#define APR_OS_ROWS(BUF, PTR)                                                                                       \
+  {                                                                                                                \
+    APR_OS_LOAD16(BUF[0], PTR, 0);                                                                                 \
+    APR_OS_LOAD16(BUF[1], PTR, 16);                                                                                \
+    APR_OS_LOAD16(BUF[2], PTR, 128);                                                                               \
+    APR_OS_LOAD16(BUF[3], PTR, 144);                                                                               \
+  }
+#define APR_OS_WAIT5(BUF) \
+  asm volatile("s_waitcnt vmcnt(5)" : "+v"(BUF[0]), "+v"(BUF[1]), "+v"(BUF[2]), "+v"(BUF[3])::"memory")
 
-template <int NCH>   // cin / 64: 1 or 2
+// cin = 64.  LDS: two weight slices (48 KB) | pair-word ring (4 KB) | accumulators [R][64] f32.  DBG: the diagnostics build
+// (timeline stamps, ablation switches); the production instantiation carries neither.
+template <bool DBG>
 __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict__ in, int64_t ldi, OsViews v, int n_out,
                                                          int R, int K, int cout, const unsigned char* __restrict__ wp3,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ residual, int64_t ldr, int relu,
-                                                         float* __restrict__ out, int64_t ldo) {
+                                                         float* __restrict__ out, int64_t ldo, int ablate_arg,
+                                                         unsigned long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  constexpr int nstep = NCH * 2;                      // 32-channel steps
-  constexpr int plane_bytes = nstep * 4096;           // one split plane of a slice: [step][col 64][quad 4][8 bf16]
-  constexpr int slice_bytes = 3 * plane_bytes;        // 24 KB x NCH
-  constexpr int npiece = slice_bytes / 1024 / kWaves; // 1-KB LDS-DMA pieces per wave and slice
-  unsigned char* const s_w = s_raw;                                  // two slices
-  unsigned char* const s_acc = s_raw + 2 * slice_bytes;              // [R][16 chunks of 16 B], chunk c at c ^ (row & 15)
+  const int ablate = DBG ? ablate_arg : 0;
+  constexpr int plane_bytes = 2 * 4096;               // one split plane of a slice: [step 2][col 64][quad 4][8 bf16]
+  unsigned char* const s_w = s_raw;                                        // two slices
+  unsigned char* const s_ring = s_raw + 2 * kSlice;                        // [wave][kRing][16 words]
+  unsigned* const s_sched = reinterpret_cast<unsigned*>(s_ring + kWaves * kRing * 64);   // the tile's schedule words
+  unsigned char* const s_acc = s_ring + kWaves * kRing * 64 + kSched * 4;  // [R][16 chunks of 16 B], chunk c at c ^ (row & 15)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q = lane >> 4;
   const int tile = blockIdx.x, cblk = blockIdx.y;
   const int row0 = tile * R;
   const int rows = min(R, n_out - row0);
-  const int cnt_l = (lane < K) ? v.cnt[tile * 32 + lane] : 0;
-  const unsigned long long live = __ballot(cnt_l > 0);
+  const int nitems = __builtin_amdgcn_readfirstlane(v.cnt[tile * 32 + 31]);
+  if (tid < kSched) s_sched[tid] = (tid < nitems) ? v.sched[(int64_t)tile * kSched + tid] : 0u;
   const unsigned* const lists = v.pair + (int64_t)tile * K * R;
   const unsigned ldi32 = (unsigned)ldi;
   const int frag_off = (r16 * 4 + ((r16 & 8) ? (q ^ 3) : q)) * 16;
+  unsigned char* const my_ring = s_ring + wave * (kRing * 64);
 
+  // diagnostics (APR_OS_TRACE=1): one workgroup stamps s_memtime at fixed points of every wave's timeline
+  const bool tracing = DBG && trace != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0;
+  int tr_n = 0;
+  auto stamp = [&](int tag) {
+    if (DBG && tracing && lane == 0 && tr_n < 510) {
+      trace[wave * 512 + tr_n] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull);
+      ++tr_n;
+      trace[wave * 512 + 511] = tr_n;
+    }
+  };
+  stamp(0);
   for (int o = tid * 16; o < R * 256; o += kThreads * 16) *reinterpret_cast<f32x4*>(s_acc + o) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // The item sequence is the SAME for all 8 waves: (offset k, slot s), s < ceil(groups(k) / 8); in slot s wave w owns group
-  // w + 8 s of the offset, or nothing (it still issues the item's loads, from a clamped address: every path through the
-  // loop then carries the same number of vector-memory operations and the waits are counted, never vmcnt(0)).
-  auto cnt_of = [&](int k) { return __builtin_amdgcn_readlane(cnt_l, k); };
-  auto next_live = [&](int k) {   // first live offset above k, or 64
-    const unsigned long long m = (k >= 63) ? 0ull : (live & ~((2ull << k) - 1ull));
-    return m ? (int)__builtin_ctzll(m) : 64;
+  // schedule word of item i; past the end: an empty slot of the last item's offset (no group, no slice, no barrier)
+  // (read from LDS five items ahead of its use; the value is the same in every lane)
+  auto item = [&](int i) {
+    const unsigned w = __builtin_amdgcn_readfirstlane(s_sched[i < nitems ? i : nitems - 1]);
+    return i < nitems ? w : (w & 31u);
   };
-  auto advance = [&](OsIt it) {
-    if (it.k >= 64) return it;
-    const int ng = (cnt_of(it.k) + 15) >> 4;
-    if ((it.g + 1) * kWaves < ng) return OsIt{it.k, it.g + 1};
-    return OsIt{next_live(it.k), 0};
+  // this wave's 16 pair words of an item -> ring slot (LDS-DMA, lanes 0-15); lanes past the list's end (and waves without a
+  // group in the slot) fetch the offset's first word: a valid pair, masked at the accumulator write-back
+  auto fetch_words = [&](unsigned w, int ring_slot) {
+    const int k = (int)(w & 31u), cnt = (int)(w >> 16);
+    const int p = (wave + kWaves * (int)((w >> 5) & 7u)) * 16 + r16;
+    const unsigned* src = lists + (int64_t)k * R + (p < cnt ? p : 0);
+    if (lane < 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(my_ring + ring_slot * 64), 4, 0, 0);
   };
-  const int k_first = live ? (int)__builtin_ctzll(live) : 64;
-  // pair word of item `it` for this lane; lanes past the list's end (and items past the end) read a valid word and are
-  // masked at the accumulator write-back
-  auto word_ptr = [&](OsIt it) {
-    const int k = it.k < 64 ? it.k : k_first;
-    const int slot = (wave + kWaves * it.g) * 16 + r16;
-    return lists + (int64_t)k * R + ((it.k < 64 && slot < cnt_of(k)) ? slot : 0);
+  auto stage_piece = [&](int k, int buf, int piece) {   // 1 KB of the slice of offset k -> LDS buffer `buf`
+    const unsigned char* src = wp3 + ((int64_t)k * (cout >> 6) + cblk) * kSlice + piece * 1024 + lane * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(s_w + buf * kSlice + piece * 1024), 16, 0, 0);
   };
-  auto stage = [&](int k, int buf) {   // slice of offset k -> LDS buffer `buf`, this wave's pieces
-    const unsigned char* src = wp3 + ((int64_t)k * (cout >> 6) + cblk) * slice_bytes + lane * 16;
-#pragma unroll
-    for (int u = 0; u < npiece; ++u) {
-      const int piece = wave + kWaves * u;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                       (__attribute__((address_space(3))) void*)(s_w + buf * slice_bytes + piece * 1024),
-                                       16, 0, 0);
-    }
-  };
+  auto ring_word = [&](int ring_slot) { return *reinterpret_cast<const unsigned*>(my_ring + ring_slot * 64 + r16 * 4); };
+  auto row_ptr = [&](unsigned word) { return in + (uint64_t)((ablate & 1) ? 0u : (word & kInMask)) * ldi32 + q * 8; };
 
-  if (live) {
-    stage(k_first, 0);
-    OsIt it0 = OsIt{k_first, 0};
-    OsIt it1 = advance(it0);
-    unsigned pw0 = *word_ptr(it0);
-    unsigned pw1 = *word_ptr(it1);
-    f32x4 raw[4 * NCH];
+  __syncthreads();   // schedule in LDS
+  if (nitems > 0) {
+    unsigned w0 = item(0), w1 = item(1), w2 = item(2), w3 = item(3), w4 = item(4), w5 = item(5);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) stage_piece((int)(w0 & 31u), 0, wave + kWaves * u);
+    fetch_words(w0, 0);
+    fetch_words(w1, 1);
+    fetch_words(w2, 2);
+    fetch_words(w3, 3);
+    fetch_words(w4, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4 rowA[4], rowB[4], rowC[4];
     {
-      const float* ab = in + (uint64_t)(pw0 & kInMask) * ldi32 + q * 8;
-#pragma unroll
-      for (int j = 0; j < 4 * NCH; ++j) raw[j] = *reinterpret_cast<const f32x4*>(ab + (j >> 2) * 64 + ((j >> 1) & 1) * 32 + (j & 1) * 4);
+      const float* p0 = row_ptr(ring_word(0));
+      const float* p1 = row_ptr(ring_word(1));
+      APR_OS_ROWS(rowA, p0)
+      APR_OS_ROWS(rowB, p1)
+      APR_OS_ROWS(rowC, p1)      // defined on every path into the loop
     }
-    __syncthreads();   // accumulators zeroed, first slice landed (vmcnt(0))
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(rowA[0]), "+v"(rowA[1]), "+v"(rowA[2]), "+v"(rowA[3]), "+v"(rowB[0]), "+v"(rowB[1]), "+v"(rowB[2]),
+                   "+v"(rowB[3]), "+v"(rowC[0]), "+v"(rowC[1]), "+v"(rowC[2]), "+v"(rowC[3])::"memory");
+    __syncthreads();   // accumulators zeroed, first slice landed
+    stamp(1);
 
-    int buf = 0;
-    while (it0.k < 64) {
-      const int kcur = it0.k;
-      const OsIt it2 = advance(it1);
-      const bool last = it1.k != kcur;
-      const int cnt_k = cnt_of(kcur);
-      const bool real = (wave + kWaves * it0.g) * 16 < cnt_k;           // this wave has a group in this slot
-      const unsigned char* const wbuf = s_w + buf * slice_bytes + frag_off;
-      const int orow = (int)(pw0 >> kInBits);
-      const bool valid = (wave + kWaves * it0.g) * 16 + r16 < cnt_k;
-      unsigned char* const arow = s_acc + orow * 256;
-      const int sw = orow & 15;
-      bf16x8 ah[nstep], am[nstep], al[nstep];
-      f32x4 acc[4];
-      if (real) {
-        // ---- operands of this item: split the gathered rows, accumulator rows as the MFMA C operand
-#pragma unroll
-        for (int s = 0; s < nstep; ++s) apr_split3(raw[2 * s], raw[2 * s + 1], ah[s], am[s], al[s]);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = *reinterpret_cast<const f32x4*>(arow + (((cb * 4 + q) ^ sw) << 4));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- next offset's slice (first slot of the offset), next item's rows, the word of the item after next
-      if (it0.g == 0) {
-        const int knext = next_live(kcur);
-        if (knext < 64) stage(knext, buf ^ 1);
-      }
-      {
-        const float* ab = in + (uint64_t)(pw1 & kInMask) * ldi32 + q * 8;
-#pragma unroll
-        for (int j = 0; j < 4 * NCH; ++j)
-          raw[j] = *reinterpret_cast<const f32x4*>(ab + (j >> 2) * 64 + ((j >> 1) & 1) * 32 + (j & 1) * 4);
-      }
-      const unsigned pw2 = *word_ptr(it2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (real) {
-        // ---- 48 x NCH MFMAs; W fragments of (step s, 16-column block cb) fetched two (s, cb) ahead
-        bf16x8 wf[3][3];
-#pragma unroll
-        for (int i0 = 0; i0 < 2; ++i0)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            wf[i0][pl] = *reinterpret_cast<const bf16x8*>(wbuf + (i0 * 16) * 64 + pl * plane_bytes);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4 * nstep; ++i) {
-          const int s = i >> 2, cb = i & 3;
-          if (i + 2 < 4 * nstep) {
-            const int s2 = (i + 2) >> 2, cb2 = (i + 2) & 3;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-              wf[(i + 2) % 3][pl] = *reinterpret_cast<const bf16x8*>(wbuf + (s2 * 64 + cb2 * 16) * 64 + pl * plane_bytes);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          const bf16x8 wh = wf[i % 3][0], wm = wf[i % 3][1], wl = wf[i % 3][2];
-          f32x4 t = acc[cb];
-          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[s], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[s], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[s], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[s], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[s], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[s], t, 0, 0, 0);
-          acc[cb] = t;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (valid) {
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(arow + (((cb * 4 + q) ^ sw) << 4)) = acc[cb];
-        }
-      }
-      if (last) {
-        // The wave's pieces of the next slice (issued in the offset's first slot, before that item's 4 * NCH + 1 prefetch
-        // loads) must have landed before the barrier lets anyone read them; the prefetch loads may stay in flight.
-        // Accumulator write-backs: lgkmcnt(0).  The barrier also orders this offset's updates before the next one's.
-        if (NCH == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        buf ^= 1;
-      }
-      it0 = it1;
-      it1 = it2;
-      pw0 = pw1;
-      pw1 = pw2;
+    int buf = 0, i = 0;
+    // Item i: its rows sit in buffer CUR (requested two items ago); the rows of item i + 2 go to buffer NXT2; the pair words
+    // of item i + 5 go to ring slot (i + 5) & 7.  Issue order inside an item: slice pieces, pair words, 4 row loads --
+    // so "all but the 5 youngest" = everything up to and including the previous item's slice pieces.
+#define APR_OS_ITEM(CUR, NXT2)                                                                                      \
+    {                                                                                                              \
+      const int slot = (int)((w0 >> 5) & 7u), cnt_k = (int)(w0 >> 16);                     \
+      const bool last = (w0 & 256u) != 0;                                                                          \
+      const int g16 = (wave + kWaves * slot) * 16;                                                                 \
+      const bool real = g16 < cnt_k;            /* this wave has a group in this slot */                           \
+      const bool valid = g16 + r16 < cnt_k;                                                                        \
+      const unsigned char* const wbuf = s_w + buf * kSlice + frag_off;                                             \
+      stamp(4);                                                                                                    \
+      APR_OS_WAIT5(CUR);                                                                                           \
+      const unsigned wd_i = ring_word(i & 7), wd_i2 = ring_word((i + 2) & 7);                                      \
+      const int orow = (int)(wd_i >> kInBits);                                                                     \
+      unsigned char* const arow = s_acc + orow * 256;                                                              \
+      const int sw = orow & 15;                                                                                    \
+      bf16x8 ah[2], am[2], al[2];                                                                                  \
+      f32x4 acc[4];                                                                                                \
+      if (real) {                                                                                                  \
+        apr_split3(CUR[0], CUR[1], ah[0], am[0], al[0]);                                                           \
+        apr_split3(CUR[2], CUR[3], ah[1], am[1], al[1]);                                                           \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                           \
+          acc[cb] = *reinterpret_cast<const f32x4*>(arow + (((cb * 4 + q) ^ sw) << 4));                            \
+      }                                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      stamp(5);                                                                                                    \
+      /* ---- issue: the next offset's slice (first slot of an offset: by the waves that have no group in it when   \
+         there are at least two of them, else by everybody), the pair words of item + 5, the rows of item + 2 */    \
+      if (slot == 0 && !(ablate & 2)) {                                                                            \
+        const int knext = (int)((w0 >> 9) & 31u);                                                                  \
+        if (knext < 31) {                                                                                          \
+          const int ng = (cnt_k + 15) >> 4;                                                                        \
+          const int nbusy = ng < kWaves ? ng : kWaves;                                                             \
+          const int nidle = kWaves - nbusy;                                                                        \
+          if (nidle >= 2) {                                                                                        \
+            if (wave >= nbusy)                                                                                     \
+              for (int pc = wave - nbusy; pc < kSlice / 1024; pc += nidle) stage_piece(knext, buf ^ 1, pc);        \
+          } else {                                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < 3; ++u) stage_piece(knext, buf ^ 1, wave + kWaves * u);          \
+          }                                                                                                        \
+        }                                                                                                          \
+      }                                                                                                            \
+      fetch_words(w5, (i + 5) & 7);                                                                                \
+      {                                                                                                            \
+        const float* pr = row_ptr(wd_i2);                                                                          \
+        APR_OS_ROWS(NXT2, pr)                                                                                      \
+      }                                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      stamp(6);                                                                                                    \
+      if (real && !(ablate & 4)) {                                                                                 \
+        /* 48 MFMAs; W fragments of (step s, 16-column block cb) fetched two (s, cb) ahead */                      \
+        bf16x8 wf[3][3];                                                                                           \
+        _Pragma("unroll") for (int i0 = 0; i0 < 2; ++i0)                                                           \
+          _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                         \
+            wf[i0][pl] = *reinterpret_cast<const bf16x8*>(wbuf + (i0 * 16) * 64 + pl * plane_bytes);               \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        _Pragma("unroll") for (int ii = 0; ii < 8; ++ii) {                                                         \
+          const int s2 = ii >> 2, cb = ii & 3;                                                                     \
+          if (ii + 2 < 8) {                                                                                        \
+            const int s3 = (ii + 2) >> 2, cb3 = (ii + 2) & 3;                                                      \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                       \
+              wf[(ii + 2) % 3][pl] =                                                                               \
+                  *reinterpret_cast<const bf16x8*>(wbuf + (s3 * 64 + cb3 * 16) * 64 + pl * plane_bytes);           \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+          }                                                                                                        \
+          const bf16x8 wh = wf[ii % 3][0], wm = wf[ii % 3][1], wl = wf[ii % 3][2];                                 \
+          f32x4 t = acc[cb];                                                                                       \
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[s2], t, 0, 0, 0);                                     \
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[s2], t, 0, 0, 0);                                     \
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[s2], t, 0, 0, 0);                                     \
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[s2], t, 0, 0, 0);                                     \
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[s2], t, 0, 0, 0);                                     \
+          t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[s2], t, 0, 0, 0);                                     \
+          acc[cb] = t;                                                                                             \
+          __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                          \
+        if (valid && !(ablate & 8)) {                                                                              \
+          _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                         \
+            *reinterpret_cast<f32x4*>(arow + (((cb * 4 + q) ^ sw) << 4)) = acc[cb];                                \
+        }                                                                                                          \
+      }                                                                                                            \
+      stamp(7);                                                                                                    \
+      if (last) {                                                                                                  \
+        /* the pieces of the next slice this wave issued (in the offset's first slot, before that item's 5 younger  \
+           loads) have landed; accumulator write-backs are done; then the barrier orders this offset's updates      \
+           before the next one's and publishes the slice */                                                         \
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                   \
+        buf ^= 1;                                                                                                  \
+        stamp(8);                                                                                                  \
+      }                                                                                                            \
+      w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5;                                                                 \
+      ++i;                                                                                                         \
+      w5 = item(i + 5);                                                                                            \
     }
+    do {      // items past the end are empty slots: one exit, at the bottom
+      APR_OS_ITEM(rowA, rowC)
+      APR_OS_ITEM(rowB, rowA)
+      APR_OS_ITEM(rowC, rowB)
+    } while (i < nitems);
+#undef APR_OS_ITEM
+    asm volatile("s_waitcnt vmcnt(0)"      // nothing of the pipeline may outlive the loop
+                 : "+v"(rowA[0]), "+v"(rowA[1]), "+v"(rowA[2]), "+v"(rowA[3]), "+v"(rowB[0]), "+v"(rowB[1]), "+v"(rowB[2]),
+                   "+v"(rowB[3]), "+v"(rowC[0]), "+v"(rowC[1]), "+v"(rowC[2]), "+v"(rowC[3])::"memory");
   } else {
     __syncthreads();
   }
 
+  stamp(9);
   // epilogue: lane -> logical chunk c of row r (stored at c ^ (r & 15)); 16 lanes = one 256-B output row segment
   const int col = cblk * 64 + (tid & 15) * 4;
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -266,19 +341,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
     }
     *reinterpret_cast<f32x4*>(out + row * ldo + col) = s;
   }
+  stamp(10);
 }
 
-inline int os_rmax(int cin) { return cin == 64 ? 432 : 240; }
+unsigned long long* g_trace = nullptr;   // device buffer of the diagnostics trace (8 waves x 512 stamps)
+
+// LDS: two slices (48 KB) + the pair-word ring (4 KB) + the schedule (512 B) + 256 B per accumulator row, <= 156 KB
+inline int os_rmax(int cin) { return cin == 64 ? ((156 * 1024 - 2 * kSlice - kWaves * kRing * 64 - kSched * 4) / 256) / 16 * 16 : 0; }
 
 }  // namespace
 
 // Rows per tile for an [n_out]-row map feeding a cin -> cout layer: the smallest whole number m of rounds of 256
 // workgroups (one per CU: the tile's accumulators + two weight slices take most of the 160 KB of LDS) whose tiles fit.
 APR_API int32_t apr_spconv_os_tile_rows(int64_t n_out, int32_t cin, int32_t cout) {
-  if (n_out <= 0 || (cin != 64 && cin != 128) || cout < 64 || cout % 64 != 0) return 0;
+  if (n_out <= 0 || cin != 64 || cout < 64 || cout % 64 != 0) return 0;
   static const int s_cus = env_int("APR_OS_CUS", 256);
   const int64_t ncol = cout / 64;
   const int rmax = os_rmax(cin);
+  if (rmax < 64) return 0;
   for (int64_t m = 1;; ++m) {
     int64_t r = cdiv64(n_out * ncol, s_cus * m);
     r = (r + 15) / 16 * 16;
@@ -290,7 +370,7 @@ APR_API int32_t apr_spconv_os_tile_rows(int64_t n_out, int32_t cin, int32_t cout
 APR_API size_t apr_spconv_os_pairs_bytes(int64_t n_out, int32_t K, int32_t R) {
   if (n_out <= 0 || R <= 0 || K <= 0) return 0;
   const int64_t ntiles = cdiv64(n_out, R);
-  return os_align256((size_t)ntiles * 32 * 4) + (size_t)ntiles * K * R * 4 + 256;
+  return os_align256((size_t)ntiles * 32 * 4) + os_align256((size_t)ntiles * kSched * 4) + (size_t)ntiles * K * R * 4 + 256;
 }
 
 // nbr [n_out, K] (input rows < n_in < 2^23) -> per-tile pair lists in `blob` (apr_spconv_os_pairs_bytes)
@@ -303,7 +383,7 @@ APR_API int apr_spconv_os_pairs_build(const int32_t* nbr, int64_t n_out, int64_t
   APR_CHECK_ARG(blob_bytes >= apr_spconv_os_pairs_bytes(n_out, K, R), "apr_spconv_os_pairs_build: blob too small");
   const int64_t ntiles = cdiv64(n_out, R);
   OsViews v = os_carve(blob, ntiles);
-  hipLaunchKernelGGL(k_os_build, dim3((unsigned)ntiles), dim3(kThreads), (size_t)R * K * 4, (hipStream_t)stream, nbr,
+  hipLaunchKernelGGL(k_os_build, dim3((unsigned)ntiles), dim3(kThreads), (size_t)(R * K + 32) * 4, (hipStream_t)stream, nbr,
                      (int)n_out, K, R, v);
   APR_LAUNCH_CHECK();
   return APR_OK;
@@ -317,7 +397,7 @@ APR_API int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(in && os_pairs && w_bf3 && out && n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 27,
                 "apr_spconv_os_fwd: bad n_out / K / null argument");
-  APR_CHECK_ARG((cin == 64 || cin == 128) && cout >= 64 && cout % 64 == 0, "apr_spconv_os_fwd: needs cin 64 or 128 and cout %% 64 == 0");
+  APR_CHECK_ARG(cin == 64 && cout >= 64 && cout % 64 == 0, "apr_spconv_os_fwd: needs cin == 64 and cout %% 64 == 0");
   APR_CHECK_ARG(R >= 16 && R % 16 == 0 && R <= os_rmax(cin), "apr_spconv_os_fwd: tile rows out of range for this cin");
   APR_CHECK_ARG(ldi > 0 && ldi < (1ll << 31) && ldi % 4 == 0 && ldo % 4 == 0 &&
                     ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0,
@@ -332,21 +412,38 @@ APR_API int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs
     APR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(s_mu);
     if (dev >= 0 && dev < 64 && !s_attr[dev]) {
-      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s_attr[dev] = true;
     }
   }
   const int64_t ntiles = cdiv64(n_out, R);
   OsViews v = os_carve(const_cast<void*>(os_pairs), ntiles);
-  const size_t lds = (size_t)2 * 3 * (cin / 32) * 4096 + (size_t)R * 256;
+  static const int s_ablate = env_int("APR_OS_ABLATE", 0);   // timing experiments only (wrong results when non-zero)
+  const size_t lds = (size_t)2 * kSlice + kWaves * kRing * 64 + kSched * 4 + (size_t)R * 256;
   const dim3 grid((unsigned)ntiles, (unsigned)(cout / 64));
-  if (cin == 64)
-    hipLaunchKernelGGL(k_os_conv<1>, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout,
-                       (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo);
+  static const int s_trace = env_int("APR_OS_TRACE", 0);
+  if (s_trace && !g_trace) {
+    APR_HIP(hipMalloc(&g_trace, 8 * 512 * sizeof(unsigned long long)));
+    APR_HIP(hipMemset(g_trace, 0, 8 * 512 * sizeof(unsigned long long)));
+  }
+  if (s_trace || s_ablate)
+    hipLaunchKernelGGL(k_os_conv<true>, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout,
+                       (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, s_ablate,
+                       s_trace ? g_trace : nullptr);
   else
-    hipLaunchKernelGGL(k_os_conv<2>, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout,
-                       (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo);
+    hipLaunchKernelGGL(k_os_conv<false>, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout,
+                       (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, 0, nullptr);
   APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// Diagnostics: with APR_OS_TRACE=1 in the environment, the middle workgroup of every apr_spconv_os_fwd launch stamps
+// s_memtime (tag << 56 | cycles) at fixed points of each wave's timeline; this copies the last launch's stamps
+// (8 waves x 512 entries, entry 511 = count) to the host.  Returns APR_EINVAL when tracing is off.
+APR_API int apr_spconv_os_trace(uint64_t* host_out, int32_t n) {
+  APR_CHECK_ARG(g_trace != nullptr && host_out != nullptr && n == 8 * 512, "apr_spconv_os_trace: tracing is off (APR_OS_TRACE=1) or bad buffer");
+  APR_HIP(hipDeviceSynchronize());
+  APR_HIP(hipMemcpy(host_out, g_trace, 8 * 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return APR_OK;
 }

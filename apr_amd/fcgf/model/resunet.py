@@ -39,6 +39,20 @@ WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", 
              "conv2_tr", "block2_tr")
 
 
+# Round 3: the residual blocks of the 64-channel levels (two 64 -> 64 convolutions on one same-level map each) run
+# output-stationary (spconv_os.hip: tile accumulators in LDS, no product rows): block2_tr 2 x 189 -> 2 x 126 us, block2 /
+# block3_tr 2 x 79 -> 2 x 57 us at 12 frames per call.  Only taken where the layer has 64 input channels
+# (apr_spconv_os_tile_rows); elsewhere the stage keeps its entry in WS_STAGES.  APR_OS_STAGES overrides ("none": off).
+OS_STAGES = ("block2", "block3_tr", "block2_tr")
+
+
+def _os_stages():
+    env = os.environ.get("APR_OS_STAGES")
+    if env is None:
+        return set(OS_STAGES)
+    return set() if env in ("", "none") else set(env.split(","))
+
+
 def _ws_stages():
     env = os.environ.get("APR_WS_STAGES")
     if env is None:
@@ -156,7 +170,7 @@ class ResUNet2(ME.MinkowskiNetwork):
 
         batch = ops.SpconvBatch()   # the 23 conv launches leave through ONE library call
 
-        ws = _ws_stages()
+        ws, osn = _ws_stages(), _os_stages()
 
         def stage(name, feats, cmap, n_out, bmap, out):
             """conv -> folded BN -> residual block; cmap / bmap = (ts_in, ts_out, kernel, transpose)."""
@@ -164,8 +178,12 @@ class ResUNet2(ME.MinkowskiNetwork):
             sc, sh = norm.folded()
             a = conv.run(feats, cm.kernel_map(*cmap), n_out, scale=sc, shift=sh, batch=batch,
                          plist=cm.pair_list(*cmap) if "conv" + name in ws else None)
-            return blk.fused_eval(a, cm.kernel_map(*bmap), out, batch=batch,
-                                  plist=cm.pair_list(*bmap) if "block" + name in ws else None)
+            bl = None
+            if "block" + name in osn and blk.conv1.packed_weight_bf3() is not None:
+                bl = cm.os_pair_list(*bmap, blk.conv1.in_channels, blk.conv1.out_channels)
+            if bl is None and "block" + name in ws:
+                bl = cm.pair_list(*bmap)
+            return blk.fused_eval(a, cm.kernel_map(*bmap), out, batch=batch, plist=bl)
 
         stage("1", x.F, (1, 1, k1, False), N1, (1, 1, 3, False), s1)
         stage("2", s1, (1, 2, 3, False), N2, (2, 2, 3, False), s2)

@@ -397,12 +397,15 @@ def ws_supported(K, cin, cout):
 
 
 def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
-           plist=None, w_bf3=None):
+           plist=None, w_bf3=None, os_pairs=None):
     """out[j] = act((sum_o x[nbr[j,o]] @ W[o]) * scale + shift + residual[j]).
 
     x / residual / out may be column slices of wider row-major buffers.  With `plist` (the PairList of `nbr`)
-    the launch takes the weight-stationary path (apr_spconv_ws_fwd).
+    the launch takes the weight-stationary path (apr_spconv_ws_fwd); with `os_pairs` (the OsPairs of `nbr`) and the
+    split weights the output-stationary one (apr_spconv_os_fwd).
     """
+    if os_pairs is not None and w_bf3 is not None and nbr is not None:
+        return spconv_os(x, os_pairs, cin, cout, w_bf3, scale=scale, shift=shift, residual=residual, relu=relu, out=out)
     x, ldi = _rows(x, "spconv.x")
     if x.shape[1] != cin:
         raise _lib.AprHipError(f"spconv: input has {x.shape[1]} channels, weight expects {cin}")

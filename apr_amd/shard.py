@@ -47,3 +47,29 @@ def aggregate_throughput(stats_matrix):
     pairs = float(stats_matrix[:, 0].sum())
     secs = float(stats_matrix[:, 1].max())
     return pairs / secs if secs > 0 else 0.0
+
+
+def gather_poses(poses, n_total: int, device):
+    """Poses [n_rank, 4, 4] of this rank's block of the pair list -> [n_total, 4, 4] float64 on EVERY rank, in pair-list
+    order ("optional gather of poses [64,4,4] to rank 0"; BASELINE config 4).  Blocks follow shard_range,
+    so their sizes differ by at most one: each rank pads its block to the largest one and a single all_gather moves
+    world x ceil(n_total / world) x 16 doubles."""
+    poses = torch.as_tensor(poses, dtype=torch.float64).reshape(-1, 4, 4)
+    if not (dist.is_available() and dist.is_initialized()):
+        if poses.shape[0] != n_total:
+            raise ValueError("gather_poses: a world of one holds the whole pair list")
+        return poses.cpu()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(n_total, rank, world)
+    if poses.shape[0] != hi - lo:
+        raise ValueError(f"gather_poses: rank {rank} owns pairs [{lo}, {hi}) but passed {poses.shape[0]} poses")
+    width = -(-n_total // world)
+    mine = torch.zeros((width, 4, 4), dtype=torch.float64, device=device)
+    mine[:hi - lo] = poses.to(device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    parts = []
+    for r in range(world):
+        a, b = shard_range(n_total, r, world)
+        parts.append(out[r][:b - a].cpu())
+    return torch.cat(parts)

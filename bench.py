@@ -55,6 +55,11 @@ def parse():
                          "headline loop")
     ap.add_argument("--pairs-per-step", type=int, default=1,
                     help="independent pairs batched into one encoder call per step (value counts pairs, not steps)")
+    ap.add_argument("--pairs-total", type=int, default=0,
+                    help="BASELINE config 4: register THIS MANY distinct pairs in all (seeds = global pair index), the pair "
+                         "list cut into contiguous blocks over the ranks (shard.shard_range), poses gathered to every "
+                         "rank at the end; value = pairs_total / max-over-ranks seconds, strong scaling.  --steps is "
+                         "ignored (a rank runs ceil(block / pairs-per-step) steps)")
     ap.set_defaults(pairs_per_step=6)
     return ap.parse_args()
 
@@ -73,22 +78,25 @@ def build_model(name, n_out, dev):
 
 
 def pmc_traffic(path):
-    """HBM bytes per launch of the dominant kernel (`path` = "tile" | "ws") from the committed PMC run of this same
-    command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 fetch correction; produced by
-    scripts/profile_round.sh): the counters cannot be collected from inside the process, so bench.py reports the
-    profiled value."""
+    """(HBM bytes per launch of the kernel family `path` = "tile" | "ws" | "os", source file) from the committed PMC run of
+    this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 fetch correction; produced
+    by scripts/profile_round.sh): the counters cannot be collected from inside the process, so bench.py reports the
+    profiled value and names the file it came from."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spconv_summary.json")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         ks = json.load(f).get("kernels", {})
+    src = os.path.relpath(files[-1], ROOT)
     try:
         if path == "tile":
-            return ks["k_spconv_pairs"]["hbm_bytes_per_launch"]
-        return ks["k_ws_gemm"]["hbm_bytes_per_launch"] + ks["k_ws_reduce"]["hbm_bytes_per_launch"]
+            return ks["k_spconv_pairs"]["hbm_bytes_per_launch"], src
+        if path == "os":
+            return ks["k_os_conv"]["hbm_bytes_per_launch"], src
+        return ks["k_ws_gemm"]["hbm_bytes_per_launch"] + ks["k_ws_reduce"]["hbm_bytes_per_launch"], src
     except KeyError:
-        return None
+        return None, src
 
 
 def cpu_baseline(state_dict, name, n_out, pairs, ransac_iters):
@@ -350,8 +358,14 @@ def main():
     # synthetic pairs of this rank (seeds 64*rank + i); upload before timing.  The pool size does NOT
     # depend on --warmup: every distinct batch composition is run on every worker stream during the untimed setup
     # below, whatever the driver passes.
-    npool = max(1, args.pool)
-    host_pairs = [synth.make_pair(s)[:2] for s in shard.rank_seeds(rank, npool)]
+    cfg4 = args.pairs_total > 0
+    if cfg4:     # config 4: this rank's contiguous block of the global pair list, every pair distinct
+        blk_lo, blk_hi = shard.shard_range(args.pairs_total, rank, world)
+        seeds4 = list(range(blk_lo, blk_hi))
+        if not seeds4:
+            raise SystemExit("--pairs-total smaller than the number of ranks")
+    npool = len(seeds4) if cfg4 else max(1, args.pool)
+    host_pairs = [synth.make_pair(s)[:2] for s in (seeds4 if cfg4 else shard.rank_seeds(rank, npool))]
     pairs = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in host_pairs]
     n_pts = float(np.mean([len(a) + len(b) for a, b in host_pairs])) / 2
 
@@ -372,7 +386,18 @@ def main():
 
     B = max(1, args.pairs_per_step)
 
+    poses4 = {}        # config 4: local pair index -> 4x4 pose
+
     def step(i):
+        if cfg4:        # step i of the block: pairs [i B, min((i + 1) B, block)); priming / warm-up steps wrap around
+            n4 = len(pairs)
+            nsteps4 = -(-n4 // B)
+            j0 = (i % nsteps4) * B
+            idx = list(range(j0, min(j0 + B, n4)))
+            res = pipe.register_batch([pairs[j] for j in idx], seeds=[seeds4[j] for j in idx])
+            for j, (T_, _) in zip(idx, res):
+                poses4[j] = T_
+            return res[-1]
         if B == 1:
             a, b = pairs[i % len(pairs)]
             return pipe(a, b, seed=i)
@@ -416,7 +441,9 @@ def main():
                     job["err"] = e
                 done.wait()
 
-    pipelined = args.host == "pipelined" and B > 1
+    if cfg4:
+        args.steps = -(-len(pairs) // B)
+    pipelined = args.host == "pipelined" and B > 1 and not cfg4
     threads = [] if pipelined else [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(nstreams)]
     [t.start() for t in threads]
 
@@ -448,7 +475,10 @@ def main():
     step(0)
     torch.cuda.synchronize()
     ncomp = max(1, npool // int(np.gcd(B, npool)))
-    nprime = 2 * nstreams * ncomp
+    nprime = 2 * nstreams * (min(ncomp, 2) if cfg4 else ncomp)
+    if cfg4:            # the timed region must start at step 0 of the block: whole passes over the block before it
+        nprime = -(-nprime // args.steps) * args.steps
+        args.warmup = -(-args.warmup // args.steps) * args.steps if args.warmup else 0
     tp = time.perf_counter()
     run_steps(0, nprime)
     log(f"setup: {nprime} priming steps on {nstreams} worker stream(s) in {time.perf_counter() - tp:.3f}s")
@@ -463,6 +493,7 @@ def main():
         torch.cuda.synchronize()
 
     first = nprime + args.warmup
+    poses4.clear()
     barrier()
     t0 = time.perf_counter()
     run_steps(first, first + args.steps)     # EXACTLY `steps` steps, `streams` in flight
@@ -476,6 +507,11 @@ def main():
         go.wait()
 
     log(f"timed loop: {args.steps} steps in {elapsed:.3f}s with {nstreams} stream(s)")
+    all_poses = None
+    if cfg4:            # poses of the whole pair list on every rank (one all_gather of [ceil(N / world), 4, 4] per rank)
+        mine = np.stack([np.asarray(poses4[j], dtype=np.float64) for j in range(len(pairs))])
+        all_poses = shard.gather_poses(mine, args.pairs_total, dev if backend == "nccl" else torch.device("cpu"))
+        assert tuple(all_poses.shape) == (args.pairs_total, 4, 4)
     # steady state: median interval between step completions (each completion = one step of B pairs), next to the
     # mean over the whole timed region that `ms_per_step` reports
     ends = sorted(tb for _, _, _, tb in step_log)
@@ -486,11 +522,11 @@ def main():
             log(f"  step {i - first:4d} worker {w} start {1e3 * (ta - t0):8.2f} ms  host {1e3 * (tb - ta):7.2f} ms")
     log(f"steady state: median step-completion interval {steady_ms:.3f} ms vs mean {1e3 * elapsed / args.steps:.3f} ms")
     # end-of-run stats of every rank: one all_gather of a few floats
-    stats = shard.gather_stats([args.steps * B, elapsed_local, float(info["n_valid"])],
+    stats = shard.gather_stats([len(pairs) if cfg4 else args.steps * B, elapsed_local, float(info["n_valid"])],
                                dev if backend == "nccl" else torch.device("cpu"))
     out = {
         "metric": "point-cloud pairs/sec (120k-pt KITTI frame, FCGF encode+match+SVD)",
-        "value": world * args.steps * B / elapsed,
+        "value": (args.pairs_total if cfg4 else world * args.steps * B) / elapsed,
         "unit": "pairs/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -498,7 +534,7 @@ def main():
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "steady_ms_per_step": steady_ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if cfg4 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -512,6 +548,10 @@ def main():
                    "host_enqueue_ms_per_step": (None if host_busy["s"] is None
                                                 else 1e3 * host_busy["s"] / max(host_busy["steps"], 1)),
                    "pool_pairs": npool, "ransac_valid_hypotheses_last_pair": int(info["n_valid"]),
+                   **({"pairs_total": args.pairs_total, "pairs_this_rank": len(pairs),
+                       "poses_gathered": list(all_poses.shape),
+                       "mode": "BASELINE config 4: the pair list cut into contiguous blocks over the ranks, seeds = global "
+                               "pair index, every pair registered once, poses gathered at the end"} if cfg4 else {}),
                    "per_rank_pairs_per_s": [float(r[0] / r[1]) for r in stats.tolist()]},
     }
 
@@ -536,38 +576,59 @@ def main():
                     "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
                     "mfma_tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12}
 
-        names = {"tile": "k_spconv_pairs", "ws": "k_ws_gemm_bf3+k_ws_reduce"}
-        what = {"tile": "pair-compacted gather -> MFMA -> fused epilogue, one kernel",
-                "ws": "weight-stationary gather -> bf16 MFMA in an exact 3-way split, fp32-equivalent FLOP priced against "
-                      "the fp32-MFMA peak (k_ws_gemm_bf3), then per-row sum + fused epilogue (k_ws_reduce)"}
+        names = {"tile": "k_spconv_pairs", "ws": "k_ws_gemm_bf3+k_ws_reduce", "os": "k_os_conv"}
+        what = {"tile": "pair-compacted gather -> fp32 MFMA -> fused epilogue, one kernel",
+                "ws": "weight-stationary gather -> bf16 MFMA in an exact 3-way split (k_ws_gemm_bf3), product rows through "
+                      "HBM, then per-row sum + fused epilogue (k_ws_reduce)",
+                "os": "output-stationary: tile accumulators in LDS, gather -> bf16 MFMA in an exact 3-way split -> fused "
+                      "epilogue, no product rows"}
+        # the instructions a family issues decide which roof prices it: the tile kernel runs exact-fp32 MFMA (157.3 TFLOP/s
+        # dense), the ws / os families bf16 MFMA (6 per fp32 product in the split: 2.5 PFLOP/s / 6 = 417 fp32-equivalent
+        # TFLOP/s, never the binding roof at these channel counts) -> they are priced against HBM
+        mfma_peak = {"tile": MFMA_F32_PEAK_TFLOPS, "ws": 2500.0 / 6.0, "os": 2500.0 / 6.0}
         legs = {k: leg(d) for k, d in s["by_path"].items()}
-        dom = max(s["by_path"], key=lambda k: s["by_path"][k]["ms"])      # dominant kernel by summed time
+        dom = max(s["by_path"], key=lambda k: s["by_path"][k]["ms"])      # dominant kernel family by summed time
         dd, dl = s["by_path"][dom], legs[dom]
-        # which roof is the tighter one for the dominant kernel: algorithmic bytes at HBM peak or exact-fp32 flops
-        # at the dense f32 MFMA peak (v_mfma_f32_16x16x4_f32, 256 FLOP/clk/CU)
         t_hbm = dd["bytes"] / (HBM_PEAK_GBS * 1e9)
-        t_mfma = dd["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        t_mfma = dd["flops"] / (mfma_peak[dom] * 1e12)
         if t_mfma > t_hbm:
-            roof = {"bound": "mfma", "achieved": dl["mfma_tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": dl["mfma_tflops"] / MFMA_F32_PEAK_TFLOPS}
+            roof = {"bound": "mfma", "achieved": dl["mfma_tflops"], "peak": mfma_peak[dom], "unit": "TFLOP/s",
+                    "frac": dl["mfma_tflops"] / mfma_peak[dom]}
         else:
             roof = {"bound": "hbm", "achieved": dl["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dl["frac"]}
+        traffic, traffic_src = pmc_traffic(dom)
+
+        def all_layers(d, n):
+            g = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            return {"launches_per_encode": d["launches"] // n, "hbm_gbs": g, "hbm_frac": g / HBM_PEAK_GBS,
+                    "mfma_tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12, "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
+                    "encode_conv_us": 1000.0 * d["ms"] / n}
+
+        # the same aggregate at other batch sizes (roofline per batch size): one pair and the bench's B pairs
+        by_batch = {}
+        for nb in sorted({1, B}):
+            pb = ops.SpconvProfile()
+            ops.PROFILE = pb
+            for i in range(3):
+                batch = [pairs[(i * nb + j) % len(pairs)] for j in range(nb)]
+                pipe.encode_batch(pipe.voxelize_batch([c for p in batch for c in p])[0])
+            ops.PROFILE = None
+            sb = pb.summary()
+            by_batch[f"{nb}_pairs_per_launch"] = dict(all_layers(sb, 3), frames_per_launch=2 * nb)
         out["roofline"] = {
             "kernel": f"{names[dom]} ({what[dom]}); {dl['launches_per_encode']} of the {s['launches'] // nprof} "
                       f"MFMA conv layers of one encode",
             **roof,
-            "traffic": pmc_traffic(dom),
+            "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_encode": dl["launches_per_encode"],
             "algorithmic_bytes_per_launch": dl["algorithmic_bytes_per_launch"],
             "algorithmic_flops_per_launch": dd["flops"] / dd["launches"],
             "avg_launch_us": dl["avg_launch_us"],
             "hbm_gbs": dl["achieved"], "hbm_frac": dl["frac"],
             "mfma_tflops": dl["mfma_tflops"], "mfma_frac_of_f32_peak": dl["mfma_tflops"] / MFMA_F32_PEAK_TFLOPS,
-            "all_conv_layers": {"launches_per_encode": s["launches"] // nprof, "hbm_gbs": gbs,
-                                "hbm_frac": gbs / HBM_PEAK_GBS,
-                                "mfma_tflops": s["flops"] / (s["ms"] * 1e-3) / 1e12,
-                                "avg_launch_us": 1000.0 * s["ms"] / s["launches"]},
+            "all_conv_layers": all_layers(s, nprof),
+            "by_batch": by_batch,
             "by_kernel": {names[k]: v for k, v in sorted(legs.items())},
         }
     if rank == 0 and world == 1 and not args.no_workloads:

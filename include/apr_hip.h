@@ -181,6 +181,9 @@ int32_t apr_spconv_os_tile_rows(int64_t n_out, int32_t cin, int32_t cout);
 size_t apr_spconv_os_pairs_bytes(int64_t n_out, int32_t K, int32_t R);
 int apr_spconv_os_pairs_build(const int32_t* nbr, int64_t n_out, int64_t n_in, int32_t K, int32_t R, void* os_pairs,
                               size_t os_pairs_bytes, void* stream);
+/* Diagnostics for apr_spconv_os_fwd (APR_OS_TRACE=1 in the environment): per-wave s_memtime stamps of one workgroup of
+ * the last launch, host_out[8 * 512] (tag << 56 | cycles; entry 511 of each wave = count). */
+int apr_spconv_os_trace(uint64_t* host_out, int32_t n);
 int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs, int64_t n_out, int32_t K, int32_t R,
                       int32_t cin, int32_t cout, const void* w_bf3, const float* scale, const float* shift,
                       const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, void* stream);

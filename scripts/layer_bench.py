@@ -32,7 +32,10 @@ def timeit(fn):
     return e0.elapsed_time(e1) * 1000 / 20
 
 
+ONLY = os.environ.get("ONLY")
 for name, ti, to, cin, cout, tr in layers:
+    if ONLY and name.split()[0] not in ONLY.split(","):
+        continue
     nbr = cm.kernel_map(ti, to, 3, tr)
     P = int((nbr >= 0).sum())
     x = torch.randn(cm.size(ti), cin, device=dev)

@@ -22,6 +22,12 @@ def _worker(rank, world, port, q):
     secs = 1.0 + rank                       # rank 1 is slower
     m = shard.gather_stats([hi - lo, secs, 1e-6 * (rank + 1)], torch.device("cpu"))
     t = shard.max_over_ranks(secs, torch.device("cpu"))
+    # config-4 pose gather: every pose carries its GLOBAL pair index, blocks of unequal size (6 and 5)
+    mine = torch.eye(4, dtype=torch.float64).repeat(hi - lo, 1, 1)
+    mine[:, 0, 3] = torch.arange(lo, hi, dtype=torch.float64)
+    allp = shard.gather_poses(mine, 11, torch.device("cpu"))
+    assert allp.shape == (11, 4, 4) and allp[:, 0, 3].tolist() == [float(i) for i in range(11)]
+    assert torch.equal(allp[:, :3, :3], torch.eye(3, dtype=torch.float64).expand(11, 3, 3))
     dist.barrier()
     q.put((rank, lo, hi, seeds, m.tolist(), t, shard.aggregate_throughput(m)))
     dist.destroy_process_group()
@@ -50,3 +56,4 @@ def test_shard_range_edge_cases():
     assert got == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard.shard_range(512, 7, 8) == (448, 512)
     assert shard.gather_stats([1, 2], torch.device("cpu")).shape == (1, 2)   # no process group: world of one
+    assert shard.gather_poses(torch.eye(4).repeat(3, 1, 1), 3, torch.device("cpu")).shape == (3, 4, 4)
