@@ -144,15 +144,33 @@ __device__ inline void kabsch4(const double s[4][3], const double t[4][3], doubl
 }
 
 // rec[2i] = (source_i, 0), rec[2i+1] = (target_i = xyz1[corr[i]], 0): one 32-B record per correspondence, so a
-// random sample costs two 16-B loads from one cache line instead of six scattered dwords
+// random sample costs two 16-B loads from one cache line instead of six scattered dwords.
+// rec2: the same correspondences for the count kernel's SCALAR loads, two per 48-B row, structure of arrays:
+//   [sx0 sx1 | sy0 sy1 | sz0 sz1 | tx0 tx1 | ty0 ty1 | tz0 tz1], padded to whole mini-chunks of kMini rows with a
+// correspondence that no transform maps within reach (target at 3e18).  maxn2: bits of max(|s|^2, |t|^2) (fp32, >= 0).
+constexpr int kMini = 32;                        // rows of rec2 (= 64 correspondences) per mini-chunk
+__host__ __device__ inline int64_t rec2_rows(int64_t n0) { return ((n0 + 1) / 2 + kMini - 1) / kMini * kMini; }
+
 __global__ void k_pack_pairs(const float* __restrict__ xyz0, const float* __restrict__ xyz1, int64_t n1,
-                             const long long* __restrict__ corr, int64_t n0, float4* __restrict__ rec) {
+                             const long long* __restrict__ corr, int64_t n0, float4* __restrict__ rec,
+                             float* __restrict__ rec2, unsigned* __restrict__ maxn2) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n0) return;
-  long long j = corr[i];
-  if (j < 0 || j >= n1) j = 0;
-  rec[2 * i] = make_float4(xyz0[3 * i], xyz0[3 * i + 1], xyz0[3 * i + 2], 0.f);
-  rec[2 * i + 1] = make_float4(xyz1[3 * j], xyz1[3 * j + 1], xyz1[3 * j + 2], 0.f);
+  float sx = 0.f, sy = 0.f, sz = 0.f, tx = 3e18f, ty = 3e18f, tz = 3e18f, m = 0.f;
+  if (i < n0) {
+    long long j = corr[i];
+    if (j < 0 || j >= n1) j = 0;
+    sx = xyz0[3 * i]; sy = xyz0[3 * i + 1]; sz = xyz0[3 * i + 2];
+    tx = xyz1[3 * j]; ty = xyz1[3 * j + 1]; tz = xyz1[3 * j + 2];
+    rec[2 * i] = make_float4(sx, sy, sz, 0.f);
+    rec[2 * i + 1] = make_float4(tx, ty, tz, 0.f);
+    m = fmaxf(sx * sx + sy * sy + sz * sz, tx * tx + ty * ty + tz * tz);
+  }
+  if (i < 2 * rec2_rows(n0)) {
+    float* row = rec2 + (i >> 1) * 12 + (i & 1);
+    row[0] = sx; row[2] = sy; row[4] = sz; row[6] = tx; row[8] = ty; row[10] = tz;
+  }
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxn2, __float_as_uint(m));
 }
 
 __device__ inline void load_samples(const float4* __restrict__ rec, uint64_t seed, long long it, uint32_t n0,
@@ -175,9 +193,12 @@ __device__ inline bool edge_reject(double a2, double b2, double r, double r2) {
   return sqrt(a2) < sqrt(b2) * r;
 }
 
+constexpr int kCandLists = 64;     // candidate sub-lists (power of two)
+
 __global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__ rec, uint32_t n0, double edge_ratio,
                                                       long long it0, long long it1, uint64_t seed,
-                                                      long long* __restrict__ cand, int* __restrict__ n_cand) {
+                                                      long long* __restrict__ cand, int* __restrict__ n_cand,
+                                                      int sub_cap) {
   const long long it = it0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = it < it1;
   // Staged: the checker is a conjunction over the 6 edges, so its value does not depend on the order they are
@@ -212,25 +233,42 @@ __global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__
     fetch(3);
     ok = edge_ok(0, 3) && edge_ok(1, 3) && edge_ok(2, 3);
   }
-  // wave-aggregated append of the survivors' iteration numbers
+  // wave-aggregated append of the survivors' iteration numbers.  kCandLists sub-lists, each with its own counter (one
+  // per 4 B of a 256-B block: different L2 atomic slots are not needed, different ADDRESSES are): with trained
+  // descriptors nearly every wave has a survivor, and 62 k reservations on ONE counter serialise at ~10 ns each
+  // (0.63 ms of a 0.70 ms kernel at 50 % true matches).  Workgroup b appends to sub-list b % kCandLists, which can
+  // receive at most sub_cap = ceil(#workgroups / kCandLists) * 256 entries.
   const unsigned long long m = __ballot(ok);
   if (m) {
     const int lane = threadIdx.x & 63;
+    const int list = blockIdx.x & (kCandLists - 1);
     int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_cand, __popcll(m));
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_cand + list, __popcll(m));
     base = __shfl(base, __ffsll((long long)m) - 1);
-    if (ok) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = it;
+    if (ok) cand[(int64_t)list * sub_cap + base + __popcll(m & ((1ull << lane) - 1ull))] = it;
   }
 }
 
 // dense over the compacted candidates (grid-stride: the count only exists on the device)
 __global__ __launch_bounds__(256) void k_fit_check(const float4* __restrict__ rec, uint32_t n0, double thr_gt,
                                                    uint64_t seed, const long long* __restrict__ cand,
-                                                   const int* __restrict__ n_cand, Hyp* __restrict__ hyps,
-                                                   int* __restrict__ n_valid, int cap) {
-  const int nc = *n_cand;
+                                                   const int* __restrict__ n_cand, int sub_cap,
+                                                   Hyp* __restrict__ hyps, int* __restrict__ n_valid, int cap) {
+  __shared__ int s_off[kCandLists + 1];      // exclusive offsets of the sub-lists in the concatenated candidate order
+  if (threadIdx.x < 64) {
+    const int c = n_cand[threadIdx.x];
+    const int incl = apr_wave_incl_scan(c);
+    s_off[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) s_off[0] = 0;
+  }
+  __syncthreads();
+  const int nc = s_off[kCandLists];
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
-    const long long it = cand[c];
+    int list = 0;
+#pragma unroll
+    for (int step = kCandLists / 2; step >= 1; step >>= 1)
+      if (s_off[list + step] <= c) list += step;
+    const long long it = cand[(int64_t)list * sub_cap + (c - s_off[list])];
     double s[4][3], t[4][3];
     load_samples(rec, seed, it, n0, s, t);
     double T[12];
@@ -287,18 +325,20 @@ __device__ inline int score_parts(int nv, int64_t n0) {
   return S < 1 ? 1 : S;
 }
 
+// The hypotheses scored are the picked ones: sel[0 .. sel_hdr[0]) (k_pick: all of them, or those at the maximum count).
 __global__ __launch_bounds__(kScoreThreads) void k_score(const float4* __restrict__ rec, int64_t n0, double thr_lt,
-                                               Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
-                                               GeoPart* __restrict__ part) {
+                                               Hyp* __restrict__ hyps, const int* __restrict__ sel_hdr,
+                                               const int* __restrict__ sel, GeoPart* __restrict__ part) {
   constexpr int NW = kScoreThreads / 64;
   __shared__ int s_cnt[NW];
   __shared__ double s_e2[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nv = min(*n_valid, cap);
+  const int nv = sel_hdr[0];
   const int S = score_parts(nv, n0);
   const int64_t nblk = (n0 + 4 * kScoreThreads - 1) / (4 * kScoreThreads);
   for (int64_t item = blockIdx.x; item < (int64_t)nv * S; item += gridDim.x) {
-    const int h = (int)(item / S), pp = (int)(item - (int64_t)h * S);
+    const int hs = (int)(item / S), pp = (int)(item - (int64_t)hs * S);
+    const int h = sel[hs];
     const int64_t i_begin = (nblk * pp / S) * (4 * kScoreThreads);
     const int64_t i_end = min((long long)((nblk * (pp + 1) / S) * (4 * kScoreThreads)), (long long)n0);
     double T[12];
@@ -358,20 +398,181 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(const float4* __restric
   }
 }
 
-__global__ void k_score_finish(Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int64_t n0,
-                               const GeoPart* __restrict__ part) {
-  const int nv = min(*n_valid, cap);
+__global__ void k_score_finish(Hyp* __restrict__ hyps, const int* __restrict__ sel_hdr, const int* __restrict__ sel,
+                               int64_t n0, const GeoPart* __restrict__ part) {
+  const int nv = sel_hdr[0];
   const int S = score_parts(nv, n0);
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (S == 1 || h >= nv) return;          // S > 1 only when nv <= kGeoGrid
+  const int hs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (S == 1 || hs >= nv) return;          // S > 1 only when nv <= kGeoGrid
   int c = 0;
   double e = 0.0;
   for (int p = 0; p < S; ++p) {
-    c += part[(int64_t)h * S + p].cnt;
-    e += part[(int64_t)h * S + p].e2;
+    c += part[(int64_t)hs * S + p].cnt;
+    e += part[(int64_t)hs * S + p].e2;
   }
+  const int h = sel[hs];
   hyps[h].inliers = c;
   hyps[h].err2 = e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Many survivors (trained descriptors: 10^4 ... 10^6 valid hypotheses of 4 M).  Scoring every hypothesis in fp64 over
+// all correspondences is survivors x n0 x ~30 fp64 operations and survivors x n0 x 32 B of L2 reads (6.4 ms per pair
+// at 243 k survivors).  But the winner is decided by the INLIER COUNT; the rmse only orders hypotheses that tie on it.  So:
+//   k_count      one THREAD per hypothesis, its transform in fp32 registers; the correspondences arrive through SCALAR
+//                loads (the index is wave-uniform), two per row, and feed packed fp32 FMAs as SGPR operands: no LDS, no
+//                reduction, no re-read per hypothesis beyond the scalar cache.  d2 is compared with lo = thr - b and
+//                hi = thr + b, where b bounds |d2_fp32 - d2_exact| rigorously (below); per mini-chunk of 64
+//                correspondences, equal counts under lo and hi prove that no correspondence sits in the band, and the
+//                count is exact.  A mini-chunk with a band hit is flagged in a bit mask instead of being counted.
+//   k_count_fix  the flagged (hypothesis, mini-chunk) cells again, in fp64 exactly as k_score does, a wave per cell
+//                (lane = correspondence), added to the hypothesis' count with an integer atomic.
+//   k_count_max / k_pick   the hypotheses that reach the maximum count: only they get their squared error summed
+//                (k_score over the picked list, fp64, fixed order) -- usually one or two of 10^5.
+// Integer counts and integer atomics only: the result (best transform, its inliers, its rmse) is bit-identical to
+// scoring everything in fp64.  Up to kGeoGrid survivors the kernels return at once and everything is scored in fp64.
+//
+// The band.  x_f = fl(fl(T0f sx + fl(T1f sy + fl(T2f sz + T3f))) - tx) against x = T0 sx + T1 sy + T2 sz + T3 - tx in
+// fp64: rounding T costs u (|s| + |T3|) (a rotation row has unit length), each of the four operations u times the size
+// of its result <= |s| + |T3| + |tx|: |x_f - x| <= 5 u (2 Mn + tn) with Mn = max point norm, tn = max |translation|,
+// u = 2^-24; taken as e1 = 8 u (2 Mn + tn).  |d2_f - d2| <= 2 sqrt(3 d2) e1 + 3 e1^2 + 4 u d2, increasing in d2 slower
+// than d2 itself: d2_f < thr - b(thr) implies d2 < thr, d2_f >= thr + b(thr) implies d2 >= thr.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ inline int count_parts(int nblk, int nwords) {
+  int S = (4096 + nblk - 1) / nblk;
+  if (S > nwords) S = nwords;
+  return S < 1 ? 1 : S;
+}
+
+__global__ __launch_bounds__(256) void k_count(const float* __restrict__ rec2, int nwords, int nmini, double thr_lt,
+                                               const unsigned* __restrict__ maxn2, Hyp* __restrict__ hyps,
+                                               const int* __restrict__ n_valid, int cap, unsigned* __restrict__ band,
+                                               int few) {
+  const int nv = min(*n_valid, cap);
+  if (nv <= few) return;
+  const int nblk = (nv + 255) >> 8;
+  const int S = count_parts(nblk, nwords);
+  const float Mn = sqrtf(__uint_as_float(*maxn2)) * 1.000001f;
+  const float thr = (float)thr_lt;
+  for (int item = blockIdx.x; item < nblk * S; item += gridDim.x) {
+    const int hb = item / S, part = item - hb * S;
+    const int w_begin = (int)((int64_t)nwords * part / S), w_end = (int)((int64_t)nwords * (part + 1) / S);
+    const int h = hb * 256 + threadIdx.x;
+    const Hyp* hp = hyps + (h < nv ? h : nv - 1);
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = (float)hp->T[k];
+    const float tn = fmaxf(fabsf(T[3]), fmaxf(fabsf(T[7]), fabsf(T[11]))) * 1.000001f;
+    const float e1 = 8.f * 5.9604645e-8f * (2.f * Mn + tn);
+    const float b = (2.f * sqrtf(3.f * thr) * e1 + 3.f * e1 * e1 + 4.f * 5.9604645e-8f * thr) * 1.01f + 1e-30f;
+    const float lo = thr - b, hi = thr + b;
+    const f32x2 t0 = {T[0], T[0]}, t1 = {T[1], T[1]}, t2 = {T[2], T[2]}, t3 = {T[3], T[3]};
+    const f32x2 t4 = {T[4], T[4]}, t5 = {T[5], T[5]}, t6 = {T[6], T[6]}, t7 = {T[7], T[7]};
+    const f32x2 t8 = {T[8], T[8]}, t9 = {T[9], T[9]}, t10 = {T[10], T[10]}, t11 = {T[11], T[11]};
+    int total = 0;
+    for (int w = w_begin; w < w_end; ++w) {
+      unsigned mask = 0;
+      const int m_end = min(32, nmini - w * 32);
+      for (int mc = 0; mc < m_end; ++mc) {
+        const float* __restrict__ row = rec2 + (int64_t)(w * 32 + mc) * (kMini * 12);   // wave-uniform: scalar loads
+        int c_lo = 0, c_hi = 0;
+#pragma unroll 4
+        for (int pp = 0; pp < kMini; ++pp) {
+          const float* __restrict__ q = row + pp * 12;
+          const f32x2 sx = {q[0], q[1]}, sy = {q[2], q[3]}, sz = {q[4], q[5]};
+          const f32x2 tx = {q[6], q[7]}, ty = {q[8], q[9]}, tz = {q[10], q[11]};
+          f32x2 dx = __builtin_elementwise_fma(t2, sz, t3);
+          f32x2 dy = __builtin_elementwise_fma(t6, sz, t7);
+          f32x2 dz = __builtin_elementwise_fma(t10, sz, t11);
+          dx = __builtin_elementwise_fma(t1, sy, dx);
+          dy = __builtin_elementwise_fma(t5, sy, dy);
+          dz = __builtin_elementwise_fma(t9, sy, dz);
+          dx = __builtin_elementwise_fma(t0, sx, dx) - tx;
+          dy = __builtin_elementwise_fma(t4, sx, dy) - ty;
+          dz = __builtin_elementwise_fma(t8, sx, dz) - tz;
+          const f32x2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+          c_lo += (d2[0] < lo) + (d2[1] < lo);
+          c_hi += (d2[0] < hi) + (d2[1] < hi);
+        }
+        if (c_lo == c_hi) total += c_lo;
+        else mask |= 1u << mc;
+      }
+      if (h < nv) band[(int64_t)h * nwords + w] = mask;
+    }
+    if (h < nv && total) atomicAdd(&hyps[h].inliers, total);
+  }
+}
+
+// The flagged cells, exactly: a wave per (hypothesis, mini-chunk), lane = correspondence, the fp64 expression of k_score.
+__global__ __launch_bounds__(256) void k_count_fix(const float4* __restrict__ rec, int64_t n0, double thr_lt,
+                                                   Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                                   const unsigned* __restrict__ band, int nwords, int few) {
+  const int nv = min(*n_valid, cap);
+  if (nv <= few) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)nv * nwords;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t base = wave0 * 64; base < total; base += nwave * 64) {
+    const int64_t idx = base + lane;
+    unsigned mask = idx < total ? band[idx] : 0u;
+    unsigned long long pending = __ballot(mask != 0u);
+    while (pending) {
+      const int L = __builtin_ctzll(pending);
+      pending &= pending - 1ull;
+      const int64_t cell = base + L;
+      const int h = (int)(cell / nwords), w = (int)(cell - (int64_t)h * nwords);
+      unsigned bits = __shfl(mask, L);
+      const Hyp* hp = hyps + h;
+      const double T0 = hp->T[0], T1 = hp->T[1], T2 = hp->T[2], T3 = hp->T[3], T4 = hp->T[4], T5 = hp->T[5];
+      const double T6 = hp->T[6], T7 = hp->T[7], T8 = hp->T[8], T9 = hp->T[9], T10 = hp->T[10], T11 = hp->T[11];
+      int cnt = 0;
+      while (bits) {
+        const int mc = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        const int64_t i = ((int64_t)w * 32 + mc) * 64 + lane;
+        bool in = false;
+        if (i < n0) {
+          const float4 a = rec[2 * i], bq = rec[2 * i + 1];
+          const double sx = a.x, sy = a.y, sz = a.z;
+          const double dx = T0 * sx + T1 * sy + T2 * sz + T3 - (double)bq.x;
+          const double dy = T4 * sx + T5 * sy + T6 * sz + T7 - (double)bq.y;
+          const double dz = T8 * sx + T9 * sy + T10 * sz + T11 - (double)bq.z;
+          in = dx * dx + dy * dy + dz * dz < thr_lt;
+        }
+        cnt += __popcll(__ballot(in));
+      }
+      if (lane == 0 && cnt) atomicAdd(&hyps[h].inliers, cnt);
+    }
+  }
+}
+
+// sel_hdr[0] = number of picked hypotheses, sel_hdr[1] = the maximum inlier count (both zero before k_count_max)
+__global__ __launch_bounds__(256) void k_count_max(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                                   int* __restrict__ sel_hdr, int few) {
+  const int nv = min(*n_valid, cap);
+  if (nv <= few) return;
+  int m = 0;
+  for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nv; h += gridDim.x * blockDim.x) m = max(m, hyps[h].inliers);
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&sel_hdr[1], m);
+}
+
+// few survivors: every hypothesis (sel = identity); many: the ones at the maximum count
+__global__ __launch_bounds__(256) void k_pick(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                              int* __restrict__ sel_hdr, int* __restrict__ sel, int few) {
+  const int nv = min(*n_valid, cap);
+  const bool all = nv <= few;
+  const int cmax = sel_hdr[1];
+  for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nv; h += gridDim.x * blockDim.x) {
+    if (all) {
+      sel[h] = h;
+    } else if (hyps[h].inliers == cmax) {
+      sel[atomicAdd(&sel_hdr[0], 1)] = h;      // the SET is what matters: k_select orders by (count, rmse, iteration)
+    }
+  }
+  if (all && blockIdx.x == 0 && threadIdx.x == 0) sel_hdr[0] = nv;
 }
 
 __device__ inline bool better(int c1, double r1, long long i1, int c2, double r2, long long i2) {
@@ -416,6 +617,64 @@ __global__ void k_select(const Hyp* __restrict__ hyps, const int* __restrict__ n
     if (s_h[0] >= 0) {
       double prev_r = best->inliers > 0 ? sqrt(best->err2 / (double)best->inliers) : 0.0;
       if (best->inliers < 0 || better(s_c[0], s_r[0], s_i[0], best->inliers, prev_r, best->it)) *best = hyps[s_h[0]];
+    }
+  }
+}
+
+// Two-stage form of k_select for long hypothesis lists (one workgroup reading 2^18 records of 128 B took 0.5 ms): kSelParts
+// workgroups each keep the best of a slice, k_select_final the best of those and of the running best.
+constexpr int kSelParts = 256;
+struct SelPart {
+  double r;
+  long long it;
+  int c, h;
+};
+
+__global__ __launch_bounds__(256) void k_select_part(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                                     SelPart* __restrict__ parts) {
+  __shared__ SelPart s_p[256];
+  const int nv = min(*n_valid, cap);
+  SelPart b;
+  b.c = -1; b.h = -1; b.r = 0.0; b.it = 0;
+  for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nv; h += gridDim.x * blockDim.x) {
+    const int c = hyps[h].inliers;
+    const double r = c > 0 ? sqrt(hyps[h].err2 / (double)c) : 0.0;
+    const long long it = hyps[h].it;
+    if (b.h < 0 || better(c, r, it, b.c, b.r, b.it)) {
+      b.c = c; b.r = r; b.it = it; b.h = h;
+    }
+  }
+  s_p[threadIdx.x] = b;
+  __syncthreads();
+  for (int stride = blockDim.x / 2; stride >= 1; stride >>= 1) {
+    if (threadIdx.x < stride) {
+      const SelPart o = s_p[threadIdx.x + stride], m = s_p[threadIdx.x];
+      if (o.h >= 0 && (m.h < 0 || better(o.c, o.r, o.it, m.c, m.r, m.it))) s_p[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = s_p[0];
+}
+
+__global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid,
+                                                            const SelPart* __restrict__ parts, Hyp* __restrict__ best,
+                                                            long long* __restrict__ total_valid) {
+  __shared__ SelPart s_p[kSelParts];
+  s_p[threadIdx.x] = parts[threadIdx.x];
+  __syncthreads();
+  for (int stride = kSelParts / 2; stride >= 1; stride >>= 1) {
+    if ((int)threadIdx.x < stride) {
+      const SelPart o = s_p[threadIdx.x + stride], m = s_p[threadIdx.x];
+      if (o.h >= 0 && (m.h < 0 || better(o.c, o.r, o.it, m.c, m.r, m.it))) s_p[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *total_valid += *n_valid;
+    const SelPart w = s_p[0];
+    if (w.h >= 0) {
+      const double prev_r = best->inliers > 0 ? sqrt(best->err2 / (double)best->inliers) : 0.0;
+      if (best->inliers < 0 || better(w.c, w.r, w.it, best->inliers, prev_r, best->it)) *best = hyps[w.h];
     }
   }
 }
@@ -720,15 +979,26 @@ struct RansacScratch {
   float4* rec;
   long long* cand;
   GeoPart* part;   // [kGeoGrid] partial scores of k_score / k_score_geometric's split form
+  float* rec2;     // [rec2_rows(n0)][12] the correspondences for k_count's scalar loads
+  unsigned* maxn2; // bits of the largest squared point norm; sel_hdr = maxn2 + 1 (count of picked hypotheses, max inliers)
+  int* sel_hdr;
+  int* sel;        // [cap] picked hypotheses
+  unsigned* band;  // [cap][band_words(n0)] flagged mini-chunks
+  SelPart* selp;   // [kSelParts]
   char* end;
 };
+
+static int band_words(int64_t n0) { return (int)((rec2_rows(n0) / kMini + 31) / 32); }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t ransac_core_bytes(int64_t n0, int64_t max_iter) {
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
-  return align256(sizeof(Hyp) + 64) + align256((size_t)(cap < 1 ? 1 : cap) * sizeof(Hyp)) + align256((size_t)n0 * 32) +
-         align256((size_t)(max_iter < 1 ? 1 : max_iter) * 8) + align256(kGeoGrid * sizeof(GeoPart)) + 256;
+  const size_t c1 = (size_t)(cap < 1 ? 1 : cap);
+  return 512 + align256(c1 * sizeof(Hyp)) + align256((size_t)n0 * 32) +
+         align256(((size_t)(max_iter < 1 ? 1 : max_iter) + kCandLists * 256) * 8) + align256(kGeoGrid * sizeof(GeoPart)) +
+         align256((size_t)rec2_rows(n0) * 48) + 256 + align256(c1 * 4) + align256(c1 * band_words(n0) * 4) +
+         align256(kSelParts * sizeof(SelPart)) + 256;
 }
 
 static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
@@ -738,28 +1008,67 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   r.best = (Hyp*)p;
   r.total_valid = (long long*)(p + sizeof(Hyp));
   r.n_valid = (int*)(p + sizeof(Hyp) + 8);
-  r.n_cand = r.n_valid + 1;   // adjacent: one 8-byte memset clears both
-  p += align256(sizeof(Hyp) + 64);
+  r.n_cand = (int*)(p + 256);   // kCandLists counters; n_valid .. the last counter: ONE memset (kCountersBytes) clears them
+  p += 512;
   r.hyps = (Hyp*)p;
   p += align256((size_t)cap * sizeof(Hyp));
   r.rec = (float4*)p;
   p += align256((size_t)n0 * 32);
   r.cand = (long long*)p;
-  p += align256((size_t)max_iter * 8);
+  p += align256(((size_t)max_iter + kCandLists * 256) * 8);
   r.part = (GeoPart*)p;
   p += align256(kGeoGrid * sizeof(GeoPart));
+  r.rec2 = (float*)p;
+  p += align256((size_t)rec2_rows(n0) * 48);
+  r.maxn2 = (unsigned*)p;
+  r.sel_hdr = (int*)p + 1;    // adjacent: one 12-byte memset clears the norm bound and the pick header
+  p += 256;
+  r.sel = (int*)p;
+  p += align256((size_t)cap * 4);
+  r.band = (unsigned*)p;
+  p += align256((size_t)cap * band_words(n0) * 4);
+  r.selp = (SelPart*)p;
+  p += align256(kSelParts * sizeof(SelPart));
   r.end = p;
   return r;
+}
+
+// correspondences -> records (both layouts) + the norm bound of k_count
+static void launch_pack(const RansacScratch& r, const float* xyz0, const float* xyz1, int64_t n1, const int64_t* corr,
+                        int64_t n0, hipStream_t st) {
+  (void)hipMemsetAsync(r.maxn2, 0, 4, st);
+  hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(2 * rec2_rows(n0), 256)), dim3(256), 0, st, xyz0, xyz1, n1,
+                     (const long long*)corr, n0, r.rec, r.rec2, r.maxn2);
+}
+
+// inlier counts + squared errors of the hypothesis list, then the running best (see the comment above k_count)
+static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, int cap, hipStream_t st) {
+  const int nwords = band_words(n0), nmini = (int)(rec2_rows(n0) / kMini);
+  // up to `few` survivors everything is scored in fp64 (APR_RANSAC_COUNT=0, read per call: always -- the A/B and test hook)
+  const int few = env_int("APR_RANSAC_COUNT", 1) ? kGeoGrid : 0x7fffffff;
+  (void)hipMemsetAsync(r.sel_hdr, 0, 8, st);
+  hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
+                     r.band, few);
+  hipLaunchKernelGGL(k_count_fix, dim3(2048), dim3(256), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, cap, r.band, nwords,
+                     few);
+  hipLaunchKernelGGL(k_count_max, dim3(256), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.sel_hdr, few);
+  hipLaunchKernelGGL(k_pick, dim3(256), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.sel_hdr, r.sel, few);
+  hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.sel_hdr, r.sel, r.part);
+  hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.sel_hdr, r.sel, n0, r.part);
+  hipLaunchKernelGGL(k_select_part, dim3(kSelParts), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.selp);
+  hipLaunchKernelGGL(k_select_final, dim3(1), dim3(kSelParts), 0, st, r.hyps, r.n_valid, r.selp, r.best, r.total_valid);
 }
 
 // sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
 static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dist, double edge_ratio, int64_t it0,
                               int64_t it1, uint64_t seed, int cap, hipStream_t st) {
-  (void)hipMemsetAsync(r.n_valid, 0, 8, st);   // n_valid and n_cand are adjacent
-  hipLaunchKernelGGL(k_sample_check, dim3((unsigned)cdiv64(it1 - it0, 256)), dim3(256), 0, st, r.rec, (uint32_t)n0,
-                     edge_ratio, (long long)it0, (long long)it1, seed, r.cand, r.n_cand);
+  const int64_t nwg = cdiv64(it1 - it0, 256);
+  const int sub_cap = (int)(cdiv64(nwg, kCandLists) * 256);
+  (void)hipMemsetAsync(r.n_valid, 0, (size_t)((char*)(r.n_cand + kCandLists) - (char*)r.n_valid), st);
+  hipLaunchKernelGGL(k_sample_check, dim3((unsigned)nwg), dim3(256), 0, st, r.rec, (uint32_t)n0, edge_ratio,
+                     (long long)it0, (long long)it1, seed, r.cand, r.n_cand, sub_cap);
   hipLaunchKernelGGL(k_fit_check, dim3(512), dim3(256), 0, st, r.rec, (uint32_t)n0, sqrt_gt_threshold(max_dist), seed,
-                     r.cand, r.n_cand, r.hyps, r.n_valid, cap);
+                     r.cand, r.n_cand, sub_cap, r.hyps, r.n_valid, cap);
 }
 
 static int fetch_result(const RansacScratch& r, double* result_host, long long* tv_out, hipStream_t st) {
@@ -804,8 +1113,7 @@ int geometric_enqueue(const float* xyz0, int64_t n0, const float* xyz1, int64_t 
   int rc = apr_internal_search_grid(xyz1, n1, (float)(2.0 * max_dist), grid_scratch, &g, st);
   if (rc != APR_OK) return rc;
   hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
-  hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz0, xyz1, n1,
-                     (const long long*)corr, n0, r.rec);
+  launch_pack(r, xyz0, xyz1, n1, corr, n0, st);
   launch_hypotheses(r, n0, max_dist, edge_ratio, 0, max_iter, seed, (int)cap, st);
   hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, r.hyps, r.n_valid,
                      (int)cap, (int)(max_validation < (1ll << 30) ? max_validation : (1ll << 30)), selected);
@@ -884,8 +1192,7 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const RansacScratch r = carve_ransac(scratch, n0, max_iter);
   const double thr_lt = sqrt_lt_threshold(max_dist);
-  hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, xyz0, xyz1, n1,
-                     (const long long*)corr, n0, r.rec);
+  launch_pack(r, xyz0, xyz1, n1, corr, n0, st);
   // Fast path: ALL iterations in one round.  The hypothesis list holds kChunk entries; only if more than that
   // survive both checkers (near-perfect correspondences) the rounds are replayed kChunk iterations at a time,
   // where the list cannot overflow.  total_valid tells which case it was.
@@ -896,10 +1203,7 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
     for (int64_t it0 = 0; it0 < max_iter; it0 += step) {
       const int64_t it1 = (it0 + step < max_iter) ? it0 + step : max_iter;
       launch_hypotheses(r, n0, max_dist, edge_ratio, it0, it1, seed, (int)cap, st);
-      hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, (int)cap,
-                         r.part);
-      hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.n_valid, (int)cap, n0, r.part);
-      hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
+      launch_scoring(r, n0, thr_lt, (int)cap, st);
     }
     APR_LAUNCH_CHECK();
     long long tv;
@@ -983,14 +1287,10 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
     RansacScratch r = carve_ransac(ransac_scratch, d.n0, max_iter);
     r.best = (Hyp*)(slots + (size_t)i * (sizeof(Hyp) + 64));
     r.total_valid = (long long*)((char*)r.best + sizeof(Hyp));
-    hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(d.n0, 256)), dim3(256), 0, st, d.xyz0, d.xyz1, d.n1,
-                       (const long long*)corr, d.n0, r.rec);
+    launch_pack(r, d.xyz0, d.xyz1, d.n1, corr, d.n0, st);
     hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
     launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, st);
-    hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, d.n0, thr_lt, r.hyps, r.n_valid, (int)cap,
-                       r.part);
-    hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.n_valid, (int)cap, d.n0, r.part);
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, st, r.hyps, r.n_valid, (int)cap, r.best, r.total_valid);
+    launch_scoring(r, d.n0, thr_lt, (int)cap, st);
   }
   APR_LAUNCH_CHECK();
   APR_HIP(hipMemcpyAsync(slots_host, slots, (size_t)B * (sizeof(Hyp) + 64), hipMemcpyDeviceToHost, st));

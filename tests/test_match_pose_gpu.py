@@ -297,3 +297,41 @@ def test_batch_path_replays_overflow_at_full_reference_criteria(dev):
     corr = ops.feature_nn(t(F0), t(F1))
     T2, info2 = ops.ransac_pose(t(xyz0), t(xyz1), corr, 0.3, 0.9, 4000000, 4)
     assert info2 == {k: info[k] for k in info2} and np.array_equal(T, T2)
+
+
+@pytest.mark.parametrize("share,iters", [(0.5, 4000000), (0.3, 1000000), (0.62, 300000)])
+def test_many_survivors_count_path_equals_full_fp64_scoring(dev, share, iters):
+    """Trained-descriptor regime (FCGF_APR/scripts/test_apr.py:148-156): 10^4 ... 10^6 hypotheses survive
+    the checkers.  Above 2048 survivors the inlier counts come from the fp32-screened count kernels (k_count +
+    k_count_fix) and only the hypotheses at the maximum count get their squared error summed; the result must be THE SAME
+    BITS as scoring every survivor in fp64 (APR_RANSAC_COUNT=0): transform, inliers, rmse, best iteration, n_valid.  The
+    last case overflows the 2^20-entry hypothesis list at once (replay in rounds)."""
+    import os
+    from apr_amd.fcgf.lib import apg
+    from apr_amd.fcgf.pipeline import PairRegistration
+    from tests.helpers import model_pair
+    a_h, b_h, T_gt = synth.make_pair(0)
+    ta, tb = torch.from_numpy(a_h).to(dev), torch.from_numpy(b_h).to(dev)
+    _, hm = model_pair("ResUNetBN2C")
+    _, pts0, pts1, n0, n1 = PairRegistration(hm, voxel_size=0.3).voxelize_pair(ta, tb)
+    pairs_gt = apg.get_matching_indices(pts0, pts1, T_gt, 0.3, K=1)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    F1 = torch.nn.functional.normalize(torch.randn(n1, 32, generator=g), dim=1).to(dev)
+    F0 = torch.nn.functional.normalize(torch.randn(n0, 32, generator=g), dim=1).to(dev)
+    pick = pairs_gt[torch.randperm(len(pairs_gt), generator=g)[:int(share * n0)].to(dev)]
+    F0[pick[:, 0]] = torch.nn.functional.normalize(F1[pick[:, 1]] + 0.02 * torch.randn(len(pick), 32, generator=g).to(dev),
+                                                   dim=1)
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["APR_RANSAC_COUNT"] = mode
+        try:
+            (T, info), = ops.match_pose_batch([F0], [F1], [pts0], [pts1], 0.3, 0.9, iters, seeds=[7])
+        finally:
+            os.environ.pop("APR_RANSAC_COUNT", None)
+        res[mode] = (T, info)
+    (T1, i1), (T0, i0) = res["1"], res["0"]
+    assert i1["n_valid"] == i0["n_valid"] > 2048
+    assert i1["inliers"] == i0["inliers"] and i1["rmse"] == i0["rmse"] and i1["best_iteration"] == i0["best_iteration"]
+    assert np.array_equal(T1, T0)
+    rte, rre = registration.rte_rre(T1, T_gt)
+    assert rte < 0.1 and rre < 0.2
