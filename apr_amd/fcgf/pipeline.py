@@ -31,6 +31,10 @@ class PairRegistration:
         self.ransac_iters = int(ransac_iters)
         self.edge_length = float(edge_length)
         self.distance_threshold = float(voxel_size) * distance_factor  # test_apr.py:149
+        # optional: called as feature_hook(F [sum n, C], rows_per_frame, pairs) -> F right after the batched encode
+        # (bench.py: descriptors with a controlled share of true matches stand in for a trained checkpoint's output; the
+        # encoder still runs)
+        self.feature_hook = None
 
     @torch.no_grad()
     def voxelize_pair(self, xyz0, xyz1):
@@ -102,6 +106,8 @@ class PairRegistration:
         counts = [int(c) for c in counts]
         pts_all = xyz_all[m.first]
         F = self.encode_batch(cm)
+        if self.feature_hook is not None:
+            F = self.feature_hook(F, counts, pairs)
         o = [0]
         for n in counts:
             o.append(o[-1] + n)

@@ -190,3 +190,42 @@ def test_config5_apg_fatbn_npr_at_size(dev):
     d = torch.cdist(sub.double(), cloud.double()).min(1)[0] ** 2
     assert abs(float(apg.chamfer_sum(sub, cloud)) - float(d.sum())) < 1e-6 * float(d.sum())
     assert float(apg.chamfer_distance(cloud[:5000], cloud[:5000])) < 1e-9
+
+
+def test_config5_distant_pair_registration_end_to_end(dev):
+    """BASELINE config 5, the registration itself (FCGF_APR/lib/complement_trainer.py:514-681, scripts/test_apr.py:130-163):
+    a 16-beam source (~30 k points) against the 64-beam target 40 m away -- a 4x density ratio -- through both FatBN-128
+    encodes, feature NN, RANSAC(4 M) and Kabsch in one batched call.  A random-init encoder cannot match, so the check of
+    the POSE uses descriptors planted after the encode (30 % of the source voxels carry their true match, the rest
+    noise); the encoder's own output is checked for shape / unit norm at both densities."""
+    from apr_amd import ops, synth
+    from apr_amd.fcgf import registration
+    from apr_amd.fcgf.lib import apg
+    from apr_amd.fcgf.pipeline import PairRegistration
+    xyz0, xyz1, T = synth.make_pair(0, n_beams1=16, dist=40.0)
+    assert 25000 < len(xyz0) < 35000 and len(xyz1) > 3.5 * len(xyz0)
+    from tests.helpers import model_pair
+    _, hm = model_pair("ResUNetFatBN", out_channels=128)
+    pipe = PairRegistration(hm, voxel_size=0.3, ransac_iters=4000000)
+    d0, d1 = torch.from_numpy(xyz0).to(dev), torch.from_numpy(xyz1).to(dev)
+    _, q0, q1, m0, m1 = pipe.voxelize_pair(d0, d1)
+    seen = {}
+
+    def plant(F, counts, prs):
+        assert counts == [m0, m1] and F.shape == (m0 + m1, 128)
+        seen["norm"] = F.norm(dim=1).clone()
+        gt = apg.get_matching_indices(q0, q1, T, 0.3, K=1)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        H1 = torch.nn.functional.normalize(torch.randn(m1, 128, generator=g), dim=1).to(dev)
+        H0 = torch.nn.functional.normalize(torch.randn(m0, 128, generator=g), dim=1).to(dev)
+        pk = gt[torch.randperm(len(gt), generator=g)[:int(0.3 * m0)].to(dev)]
+        H0[pk[:, 0]] = H1[pk[:, 1]]
+        F[:m0], F[m0:] = H0, H1
+        return F
+
+    pipe.feature_hook = plant
+    (T_est, info), = pipe.register_batch([(d0, d1)], seeds=[1])
+    assert torch.allclose(seen["norm"].cpu(), torch.ones(m0 + m1), atol=1e-5)
+    rte, rre = registration.rte_rre(T_est, T)
+    assert info["n0"] == m0 and info["n1"] == m1 and info["n_valid"] > 1000
+    assert rte < 0.3 and rre < 0.5, (rte, rre, info)
