@@ -102,7 +102,7 @@ def check_os_pipeline(verbose: bool = True) -> None:
             bodies[kernel].append(ln.strip())
     loaded, bad = {}, []
     for k, lines in bodies.items():
-        marks = [i for i, t in enumerate(lines) if t.startswith("s_waitcnt vmcnt(5)")]
+        marks = [i for i, t in enumerate(lines) if t.startswith("s_waitcnt vmcnt(5)") or t.startswith("s_waitcnt vmcnt(9)")]
         loaded[k] = set()
         if not marks:
             continue

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void k_select_part(const Hyp* __restrict__ hyp
 
 __global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid,
                                                             const SelPart* __restrict__ parts, Hyp* __restrict__ best,
-                                                            long long* __restrict__ total_valid) {
+                                                            long long* __restrict__ total_valid, int* __restrict__ sel_hdr) {
   __shared__ SelPart s_p[kSelParts];
   s_p[threadIdx.x] = parts[threadIdx.x];
   __syncthreads();
@@ -670,6 +670,7 @@ __global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    sel_hdr[0] = sel_hdr[1] = 0;      // ready for the next round's k_count_max / k_pick
     *total_valid += *n_valid;
     const SelPart w = s_p[0];
     if (w.h >= 0) {
@@ -679,13 +680,15 @@ __global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restric
   }
 }
 
-__global__ void k_init_best(Hyp* best, long long* total_valid) {
+// also clears the norm bound of k_pack_pairs and the pick header of the scoring kernels (zero3[0..2]; NULL: nothing)
+__global__ void k_init_best(Hyp* best, long long* total_valid, unsigned* zero3) {
 #pragma unroll
   for (int k = 0; k < 12; ++k) best->T[k] = (k % 5 == 0) ? 1.0 : 0.0;  // identity (open3d's default result)
   best->it = -1;
   best->inliers = -1;
   best->err2 = 0.0;
   *total_valid = 0;
+  if (zero3) zero3[0] = zero3[1] = zero3[2] = 0u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1033,10 +1036,9 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   return r;
 }
 
-// correspondences -> records (both layouts) + the norm bound of k_count
+// correspondences -> records (both layouts) + the norm bound of k_count (cleared by k_init_best, which runs first)
 static void launch_pack(const RansacScratch& r, const float* xyz0, const float* xyz1, int64_t n1, const int64_t* corr,
                         int64_t n0, hipStream_t st) {
-  (void)hipMemsetAsync(r.maxn2, 0, 4, st);
   hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(2 * rec2_rows(n0), 256)), dim3(256), 0, st, xyz0, xyz1, n1,
                      (const long long*)corr, n0, r.rec, r.rec2, r.maxn2);
 }
@@ -1046,7 +1048,6 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
   const int nwords = band_words(n0), nmini = (int)(rec2_rows(n0) / kMini);
   // up to `few` survivors everything is scored in fp64 (APR_RANSAC_COUNT=0, read per call: always -- the A/B and test hook)
   const int few = env_int("APR_RANSAC_COUNT", 1) ? kGeoGrid : 0x7fffffff;
-  (void)hipMemsetAsync(r.sel_hdr, 0, 8, st);
   hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
                      r.band, few);
   hipLaunchKernelGGL(k_count_fix, dim3(2048), dim3(256), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, cap, r.band, nwords,
@@ -1056,7 +1057,8 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
   hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.sel_hdr, r.sel, r.part);
   hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.sel_hdr, r.sel, n0, r.part);
   hipLaunchKernelGGL(k_select_part, dim3(kSelParts), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.selp);
-  hipLaunchKernelGGL(k_select_final, dim3(1), dim3(kSelParts), 0, st, r.hyps, r.n_valid, r.selp, r.best, r.total_valid);
+  hipLaunchKernelGGL(k_select_final, dim3(1), dim3(kSelParts), 0, st, r.hyps, r.n_valid, r.selp, r.best, r.total_valid,
+                     r.sel_hdr);
 }
 
 // sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
@@ -1112,7 +1114,7 @@ int geometric_enqueue(const float* xyz0, int64_t n0, const float* xyz1, int64_t 
   AprSearchGrid g;
   int rc = apr_internal_search_grid(xyz1, n1, (float)(2.0 * max_dist), grid_scratch, &g, st);
   if (rc != APR_OK) return rc;
-  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
+  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2);
   launch_pack(r, xyz0, xyz1, n1, corr, n0, st);
   launch_hypotheses(r, n0, max_dist, edge_ratio, 0, max_iter, seed, (int)cap, st);
   hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, r.hyps, r.n_valid,
@@ -1192,6 +1194,7 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const RansacScratch r = carve_ransac(scratch, n0, max_iter);
   const double thr_lt = sqrt_lt_threshold(max_dist);
+  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2);   // clears the norm bound + pick header
   launch_pack(r, xyz0, xyz1, n1, corr, n0, st);
   // Fast path: ALL iterations in one round.  The hypothesis list holds kChunk entries; only if more than that
   // survive both checkers (near-perfect correspondences) the rounds are replayed kChunk iterations at a time,
@@ -1199,7 +1202,7 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
   const int s_force_rounds = env_int("APR_RANSAC_FORCE_ROUNDS", 0);   // test hook (read per call): skip the fast path
   for (int pass = s_force_rounds ? 1 : 0; pass < 2; ++pass) {
     const int64_t step = pass == 0 ? max_iter : cap;
-    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
+    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, (unsigned*)nullptr);
     for (int64_t it0 = 0; it0 < max_iter; it0 += step) {
       const int64_t it1 = (it0 + step < max_iter) ? it0 + step : max_iter;
       launch_hypotheses(r, n0, max_dist, edge_ratio, it0, it1, seed, (int)cap, st);
@@ -1287,8 +1290,8 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
     RansacScratch r = carve_ransac(ransac_scratch, d.n0, max_iter);
     r.best = (Hyp*)(slots + (size_t)i * (sizeof(Hyp) + 64));
     r.total_valid = (long long*)((char*)r.best + sizeof(Hyp));
+    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2);
     launch_pack(r, d.xyz0, d.xyz1, d.n1, corr, d.n0, st);
-    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid);
     launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, st);
     launch_scoring(r, d.n0, thr_lt, (int)cap, st);
   }

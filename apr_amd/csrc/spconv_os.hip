@@ -31,7 +31,7 @@ constexpr int kThreads = 64 * kWaves;
 constexpr int kInBits = 23;                      // input row in the low 23 bits of a pair word, local output row above
 constexpr unsigned kInMask = (1u << kInBits) - 1u;
 constexpr int kSched = 128;                      // schedule words per tile (27 offsets x <= 4 slots)
-constexpr int kSlice = 24576;                    // bf16-split slice W[k][:, 64 columns] of a 64-channel input: 3 x 8 KB
+constexpr int kSlice64 = 24576;                  // bf16-split slice W[k][:, 64 columns] per 64 input channels: 3 x 8 KB
 constexpr int kRing = 8;                         // pair-word ring: slots of 64 B per wave
 
 // schedule word of one ITEM = (offset k, slot s): in slot s wave w owns the 16-pair group w + 8 s of the offset's list
@@ -121,13 +121,32 @@ __global__ __launch_bounds__(kThreads) void k_os_build(const int* __restrict__ n
     APR_OS_LOAD16(BUF[1], PTR, 16);                                                                                \
     APR_OS_LOAD16(BUF[2], PTR, 128);                                                                               \
     APR_OS_LOAD16(BUF[3], PTR, 144);                                                                               \
+    if (NCH == 2) {                                                                                                \
+      APR_OS_LOAD16(BUF[4 * (NCH - 1) + 0], PTR, 256);                                                             \
+      APR_OS_LOAD16(BUF[4 * (NCH - 1) + 1], PTR, 272);                                                             \
+      APR_OS_LOAD16(BUF[4 * (NCH - 1) + 2], PTR, 384);                                                             \
+      APR_OS_LOAD16(BUF[4 * (NCH - 1) + 3], PTR, 400);                                                             \
+    }                                                                                                              \
   }
-#define APR_OS_WAIT5(BUF) \
-  asm volatile("s_waitcnt vmcnt(5)" : "+v"(BUF[0]), "+v"(BUF[1]), "+v"(BUF[2]), "+v"(BUF[3])::"memory")
+// everything but the youngest 4 NCH + 1 vector-memory operations has landed; BUF is then safe to read
+#define APR_OS_WAIT_ITEM(BUF)                                                                                       \
+  if (NCH == 1)                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(5)" : "+v"(BUF[0]), "+v"(BUF[1]), "+v"(BUF[2]), "+v"(BUF[3])::"memory");         \
+  else                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(9)"                                                                              \
+                 : "+v"(BUF[0]), "+v"(BUF[1]), "+v"(BUF[2]), "+v"(BUF[3]), "+v"(BUF[4 * (NCH - 1) + 0]),             \
+                   "+v"(BUF[4 * (NCH - 1) + 1]), "+v"(BUF[4 * (NCH - 1) + 2]), "+v"(BUF[4 * (NCH - 1) + 3])::"memory")
+#define APR_OS_WAIT_ALL(BUF)                                                                                        \
+  if (NCH == 1)                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(BUF[0]), "+v"(BUF[1]), "+v"(BUF[2]), "+v"(BUF[3])::"memory");         \
+  else                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(0)"                                                                              \
+                 : "+v"(BUF[0]), "+v"(BUF[1]), "+v"(BUF[2]), "+v"(BUF[3]), "+v"(BUF[4 * (NCH - 1) + 0]),             \
+                   "+v"(BUF[4 * (NCH - 1) + 1]), "+v"(BUF[4 * (NCH - 1) + 2]), "+v"(BUF[4 * (NCH - 1) + 3])::"memory")
 
-// cin = 64.  LDS: two weight slices (48 KB) | pair-word ring (4 KB) | accumulators [R][64] f32.  DBG: the diagnostics build
-// (timeline stamps, ablation switches); the production instantiation carries neither.
-template <bool DBG>
+// cin = 64 NCH.  LDS: two weight slices (48 KB x NCH) | pair-word ring (4 KB) | schedule | accumulators [R][64] f32.
+// DBG: the diagnostics build (timeline stamps, ablation switches); the production instantiation carries neither.
+template <int NCH, bool DBG>
 __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict__ in, int64_t ldi, OsViews v, int n_out,
                                                          int R, int K, int cout, const unsigned char* __restrict__ wp3,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
@@ -136,7 +155,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
                                                          unsigned long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int ablate = DBG ? ablate_arg : 0;
-  constexpr int plane_bytes = 2 * 4096;               // one split plane of a slice: [step 2][col 64][quad 4][8 bf16]
+  constexpr int nstep = 2 * NCH;                      // 32-channel steps
+  constexpr int kSlice = NCH * kSlice64;
+  constexpr int plane_bytes = nstep * 4096;           // one split plane of a slice: [step][col 64][quad 4][8 bf16]
   unsigned char* const s_w = s_raw;                                        // two slices
   unsigned char* const s_ring = s_raw + 2 * kSlice;                        // [wave][kRing][16 words]
   unsigned* const s_sched = reinterpret_cast<unsigned*>(s_ring + kWaves * kRing * 64);   // the tile's schedule words
@@ -195,32 +216,32 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
   if (nitems > 0) {
     unsigned w0 = item(0), w1 = item(1), w2 = item(2), w3 = item(3), w4 = item(4), w5 = item(5);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) stage_piece((int)(w0 & 31u), 0, wave + kWaves * u);
+    for (int u = 0; u < kSlice / 1024 / kWaves; ++u) stage_piece((int)(w0 & 31u), 0, wave + kWaves * u);
     fetch_words(w0, 0);
     fetch_words(w1, 1);
     fetch_words(w2, 2);
     fetch_words(w3, 3);
     fetch_words(w4, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    f32x4 rowA[4], rowB[4], rowC[4];
+    f32x4 rowA[4 * NCH], rowB[4 * NCH];
     {
       const float* p0 = row_ptr(ring_word(0));
       const float* p1 = row_ptr(ring_word(1));
       APR_OS_ROWS(rowA, p0)
       APR_OS_ROWS(rowB, p1)
-      APR_OS_ROWS(rowC, p1)      // defined on every path into the loop
     }
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(rowA[0]), "+v"(rowA[1]), "+v"(rowA[2]), "+v"(rowA[3]), "+v"(rowB[0]), "+v"(rowB[1]), "+v"(rowB[2]),
-                   "+v"(rowB[3]), "+v"(rowC[0]), "+v"(rowC[1]), "+v"(rowC[2]), "+v"(rowC[3])::"memory");
+    APR_OS_WAIT_ALL(rowA);
+    APR_OS_WAIT_ALL(rowB);
     __syncthreads();   // accumulators zeroed, first slice landed
     stamp(1);
 
     int buf = 0, i = 0;
-    // Item i: its rows sit in buffer CUR (requested two items ago); the rows of item i + 2 go to buffer NXT2; the pair words
-    // of item i + 5 go to ring slot (i + 5) & 7.  Issue order inside an item: slice pieces, pair words, 4 row loads --
-    // so "all but the 5 youngest" = everything up to and including the previous item's slice pieces.
-#define APR_OS_ITEM(CUR, NXT2)                                                                                      \
+    // Item i: its rows sit in buffer CUR (requested two items ago), are split into bf16 pieces at the top of the item, and
+    // the rows of item i + 2 are then requested into CUR itself (two buffers used in turn: the loop body is written
+    // twice); the pair words of item i + 5 go to ring slot (i + 5) & 7.  Issue order inside an item: slice pieces, pair
+    // words, 4 NCH row loads -- so "all but the 4 NCH + 1 youngest" = everything up to and including the previous item's
+    // slice pieces.
+#define APR_OS_ITEM(CUR)                                                                                            \
     {                                                                                                              \
       const int slot = (int)((w0 >> 5) & 7u), cnt_k = (int)(w0 >> 16);                     \
       const bool last = (w0 & 256u) != 0;                                                                          \
@@ -229,16 +250,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
       const bool valid = g16 + r16 < cnt_k;                                                                        \
       const unsigned char* const wbuf = s_w + buf * kSlice + frag_off;                                             \
       stamp(4);                                                                                                    \
-      APR_OS_WAIT5(CUR);                                                                                           \
+      APR_OS_WAIT_ITEM(CUR);                                                                                       \
       const unsigned wd_i = ring_word(i & 7), wd_i2 = ring_word((i + 2) & 7);                                      \
       const int orow = (int)(wd_i >> kInBits);                                                                     \
       unsigned char* const arow = s_acc + orow * 256;                                                              \
       const int sw = orow & 15;                                                                                    \
-      bf16x8 ah[2], am[2], al[2];                                                                                  \
+      bf16x8 ah[nstep], am[nstep], al[nstep];                                                                      \
       f32x4 acc[4];                                                                                                \
       if (real) {                                                                                                  \
-        apr_split3(CUR[0], CUR[1], ah[0], am[0], al[0]);                                                           \
-        apr_split3(CUR[2], CUR[3], ah[1], am[1], al[1]);                                                           \
+        _Pragma("unroll") for (int s2 = 0; s2 < nstep; ++s2)                                                       \
+          apr_split3(CUR[2 * s2], CUR[2 * s2 + 1], ah[s2], am[s2], al[s2]);                                        \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                           \
           acc[cb] = *reinterpret_cast<const f32x4*>(arow + (((cb * 4 + q) ^ sw) << 4));                            \
       }                                                                                                            \
@@ -256,14 +277,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
             if (wave >= nbusy)                                                                                     \
               for (int pc = wave - nbusy; pc < kSlice / 1024; pc += nidle) stage_piece(knext, buf ^ 1, pc);        \
           } else {                                                                                                 \
-            _Pragma("unroll") for (int u = 0; u < 3; ++u) stage_piece(knext, buf ^ 1, wave + kWaves * u);          \
+            _Pragma("unroll") for (int u = 0; u < kSlice / 1024 / kWaves; ++u)                                     \
+              stage_piece(knext, buf ^ 1, wave + kWaves * u);                                                      \
           }                                                                                                        \
         }                                                                                                          \
       }                                                                                                            \
       fetch_words(w5, (i + 5) & 7);                                                                                \
       {                                                                                                            \
         const float* pr = row_ptr(wd_i2);                                                                          \
-        APR_OS_ROWS(NXT2, pr)                                                                                      \
+        APR_OS_ROWS(CUR, pr)                                                                                       \
       }                                                                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
       stamp(6);                                                                                                    \
@@ -274,9 +296,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
           _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                         \
             wf[i0][pl] = *reinterpret_cast<const bf16x8*>(wbuf + (i0 * 16) * 64 + pl * plane_bytes);               \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
-        _Pragma("unroll") for (int ii = 0; ii < 8; ++ii) {                                                         \
+        _Pragma("unroll") for (int ii = 0; ii < 4 * nstep; ++ii) {                                                 \
           const int s2 = ii >> 2, cb = ii & 3;                                                                     \
-          if (ii + 2 < 8) {                                                                                        \
+          if (ii + 2 < 4 * nstep) {                                                                                \
             const int s3 = (ii + 2) >> 2, cb3 = (ii + 2) & 3;                                                      \
             _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                       \
               wf[(ii + 2) % 3][pl] =                                                                               \
@@ -304,7 +326,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
         /* the pieces of the next slice this wave issued (in the offset's first slot, before that item's 5 younger  \
            loads) have landed; accumulator write-backs are done; then the barrier orders this offset's updates      \
            before the next one's and publishes the slice */                                                         \
-        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                   \
+        if (NCH == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
+        else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");                              \
         buf ^= 1;                                                                                                  \
         stamp(8);                                                                                                  \
       }                                                                                                            \
@@ -313,14 +336,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
       w5 = item(i + 5);                                                                                            \
     }
     do {      // items past the end are empty slots: one exit, at the bottom
-      APR_OS_ITEM(rowA, rowC)
-      APR_OS_ITEM(rowB, rowA)
-      APR_OS_ITEM(rowC, rowB)
+      APR_OS_ITEM(rowA)
+      APR_OS_ITEM(rowB)
     } while (i < nitems);
 #undef APR_OS_ITEM
-    asm volatile("s_waitcnt vmcnt(0)"      // nothing of the pipeline may outlive the loop
-                 : "+v"(rowA[0]), "+v"(rowA[1]), "+v"(rowA[2]), "+v"(rowA[3]), "+v"(rowB[0]), "+v"(rowB[1]), "+v"(rowB[2]),
-                   "+v"(rowB[3]), "+v"(rowC[0]), "+v"(rowC[1]), "+v"(rowC[2]), "+v"(rowC[3])::"memory");
+    APR_OS_WAIT_ALL(rowA);      // nothing of the pipeline may outlive the loop
+    APR_OS_WAIT_ALL(rowB);
   } else {
     __syncthreads();
   }
@@ -346,15 +367,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
 
 unsigned long long* g_trace = nullptr;   // device buffer of the diagnostics trace (8 waves x 512 stamps)
 
-// LDS: two slices (48 KB) + the pair-word ring (4 KB) + the schedule (512 B) + 256 B per accumulator row, <= 156 KB
-inline int os_rmax(int cin) { return cin == 64 ? ((156 * 1024 - 2 * kSlice - kWaves * kRing * 64 - kSched * 4) / 256) / 16 * 16 : 0; }
+// LDS: two slices (48 KB per 64 input channels) + the pair-word ring (4 KB) + the schedule (512 B) + 256 B per
+// accumulator row, <= 156 KB
+inline size_t os_fixed_lds(int cin) { return (size_t)2 * (cin / 64) * kSlice64 + kWaves * kRing * 64 + kSched * 4; }
+inline int os_rmax(int cin) {
+  return (cin == 64 || cin == 128) ? (int)((156 * 1024 - os_fixed_lds(cin)) / 256) / 16 * 16 : 0;
+}
 
 }  // namespace
 
 // Rows per tile for an [n_out]-row map feeding a cin -> cout layer: the smallest whole number m of rounds of 256
 // workgroups (one per CU: the tile's accumulators + two weight slices take most of the 160 KB of LDS) whose tiles fit.
 APR_API int32_t apr_spconv_os_tile_rows(int64_t n_out, int32_t cin, int32_t cout) {
-  if (n_out <= 0 || cin != 64 || cout < 64 || cout % 64 != 0) return 0;
+  if (n_out <= 0 || (cin != 64 && cin != 128) || cout < 64 || cout % 64 != 0) return 0;
   static const int s_cus = env_int("APR_OS_CUS", 256);
   const int64_t ncol = cout / 64;
   const int rmax = os_rmax(cin);
@@ -397,7 +422,8 @@ APR_API int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(in && os_pairs && w_bf3 && out && n_out > 0 && n_out < (1ll << 31) / 32 && K >= 1 && K <= 27,
                 "apr_spconv_os_fwd: bad n_out / K / null argument");
-  APR_CHECK_ARG(cin == 64 && cout >= 64 && cout % 64 == 0, "apr_spconv_os_fwd: needs cin == 64 and cout %% 64 == 0");
+  APR_CHECK_ARG((cin == 64 || cin == 128) && cout >= 64 && cout % 64 == 0,
+                "apr_spconv_os_fwd: needs cin 64 or 128 and cout %% 64 == 0");
   APR_CHECK_ARG(R >= 16 && R % 16 == 0 && R <= os_rmax(cin), "apr_spconv_os_fwd: tile rows out of range for this cin");
   APR_CHECK_ARG(ldi > 0 && ldi < (1ll << 31) && ldi % 4 == 0 && ldo % 4 == 0 &&
                     ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0,
@@ -412,28 +438,27 @@ APR_API int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs
     APR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(s_mu);
     if (dev >= 0 && dev < 64 && !s_attr[dev]) {
-      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_os_conv<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       s_attr[dev] = true;
     }
   }
   const int64_t ntiles = cdiv64(n_out, R);
   OsViews v = os_carve(const_cast<void*>(os_pairs), ntiles);
   static const int s_ablate = env_int("APR_OS_ABLATE", 0);   // timing experiments only (wrong results when non-zero)
-  const size_t lds = (size_t)2 * kSlice + kWaves * kRing * 64 + kSched * 4 + (size_t)R * 256;
+  const size_t lds = os_fixed_lds(cin) + (size_t)R * 256;
   const dim3 grid((unsigned)ntiles, (unsigned)(cout / 64));
   static const int s_trace = env_int("APR_OS_TRACE", 0);
   if (s_trace && !g_trace) {
     APR_HIP(hipMalloc(&g_trace, 8 * 512 * sizeof(unsigned long long)));
     APR_HIP(hipMemset(g_trace, 0, 8 * 512 * sizeof(unsigned long long)));
   }
-  if (s_trace || s_ablate)
-    hipLaunchKernelGGL(k_os_conv<true>, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout,
-                       (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, s_ablate,
-                       s_trace ? g_trace : nullptr);
-  else
-    hipLaunchKernelGGL(k_os_conv<false>, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout,
-                       (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, 0, nullptr);
+  const bool dbg = s_trace || s_ablate;
+  auto kern = cin == 64 ? (dbg ? k_os_conv<1, true> : k_os_conv<1, false>) : (dbg ? k_os_conv<2, true> : k_os_conv<2, false>);
+  hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout, (const unsigned char*)w_bf3,
+                     scale, shift, residual, ldr, relu, out, ldo, s_ablate, s_trace ? g_trace : nullptr);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -19,7 +19,9 @@ layers = [("b1 32>32 N1", 1, 1, 32, 32, False), ("b2tr 64>64 N1", 1, 1, 64, 64, 
           ("c2 32>64 1>2", 1, 2, 32, 64, False), ("b2 64>64 N2", 2, 2, 64, 64, False), ("c3 64>128 2>4", 2, 4, 64, 128, False),
           ("b3 128>128 N3", 4, 4, 128, 128, False), ("c4 128>256 4>8", 4, 8, 128, 256, False),
           ("b4 256>256 N4", 8, 8, 256, 256, False), ("c4tr 256>128 8>4", 8, 4, 256, 128, True),
-          ("c3tr 256>64 4>2", 4, 2, 256, 64, True)]
+          ("c3tr 256>64 4>2", 4, 2, 256, 64, True),
+          # ResUNetFatBN's decoder blocks (128 channels on the two finest levels)
+          ("f2tr 128>128 N1", 1, 1, 128, 128, False), ("f3tr 128>128 N2", 2, 2, 128, 128, False)]
 
 
 def timeit(fn):

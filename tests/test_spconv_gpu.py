@@ -268,6 +268,8 @@ def test_cpu_tensors_fail_loudly():
     (64, 64, 27, 5000, 5000, 0.27), (64, 64, 27, 70001, 70001, 0.27), (64, 128, 27, 3000, 1100, 0.3),
     (64, 256, 27, 1000, 9000, 0.12), (64, 64, 8, 700, 257, 0.5), (64, 64, 27, 31, 31, 0.3), (64, 64, 27, 500, 500, 0.0),
     (64, 64, 27, 100, 1000, 1.0), (64, 64, 27, 40, 2000, 0.02), (64, 64, 27, 3000, 3000, 0.9),
+    (128, 128, 27, 2500, 2500, 0.3), (128, 64, 27, 1000, 9000, 0.12), (128, 128, 27, 20000, 20000, 0.27),
+    (128, 64, 27, 100, 700, 1.0),
 ])
 def test_output_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, density):
     """apr_spconv_os_pairs_build + apr_spconv_os_fwd (accumulators in LDS, no product rows) against the fp64 oracle:
@@ -286,8 +288,8 @@ def test_output_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
     w3 = ops.pack_weights_bf3(W.to(dev))
     nbr_d = torch.from_numpy(nbr).to(dev)
     R = ops.os_tile_rows(n_out, cin, cout)
-    assert R > 0 and R % 16 == 0 and ops.os_tile_rows(n_out, 128, cout) == 0      # 64 input channels only
-    for rows in sorted({R, 64, 400}):
+    assert R > 0 and R % 16 == 0 and ops.os_tile_rows(n_out, 256, cout) == 0      # 64 or 128 input channels only
+    for rows in sorted({R, 64, 400 if cin == 64 else 208}):
         pairs = ops.build_os_pairs(nbr_d, n_in, rows)
         outw = torch.zeros(n_out, cout + 32, device=dev)
         xd, resd = xw.to(dev)[:, 32:], resw.to(dev)[:, :cout]
