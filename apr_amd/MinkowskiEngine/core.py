@@ -471,7 +471,19 @@ class MinkowskiBatchNorm(nn.Module):
     def forward(self, x: SparseTensor):
         bn = self.bn
         if _tracking(x.F, bn.weight, bn.bias):
-            return x._like(bn(x.F))            # training: torch's BatchNorm1d (autograd + running statistics)
+            if not (self.training or not bn.track_running_stats) or bn.weight is None or x.F.shape[0] < 2:
+                return x._like(bn(x.F))        # eval-mode statistics under autograd: torch's BatchNorm1d
+            # training: batch statistics, forward AND backward on the HIP kernels (ops.NormFunction); running statistics
+            # as torch's BatchNorm1d keeps them (unbiased variance, momentum)
+            y, mean, var = ops.NormFunction.apply(x.F, bn.weight, bn.bias, bn.eps)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    n = x.F.shape[0]
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+                    bn.num_batches_tracked += 1
+            return x._like(y)
         if self.training or not bn.track_running_stats:
             mean, var = ops.bn_stats(x.F)
             if bn.track_running_stats:
@@ -507,10 +519,7 @@ class MinkowskiInstanceNorm(nn.Module):
             for n in counts:
                 if n == 0:
                     continue
-                seg = x.F[r0:r0 + n]
-                mean = seg.mean(0, keepdim=True)
-                var = seg.var(0, unbiased=False, keepdim=True)
-                segs.append((seg - mean) * torch.rsqrt(var + self.eps) * self.weight + self.bias)
+                segs.append(ops.NormFunction.apply(x.F[r0:r0 + n], self.weight, self.bias, self.eps)[0])   # HIP fwd + bwd
                 r0 += n
             return x._like(torch.cat(segs, 0))
         out = torch.empty_like(x.F)

@@ -283,7 +283,104 @@ __global__ void k_l2_normalize(const float* __restrict__ x, int64_t ldx, int64_t
   for (int col = lane; col < c; col += 64) y[row * ldy + col] = x[row * ldx + col] / nrm;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of y = (x - mean) * rstd * gamma + beta over the rows of one segment (training-mode MinkowskiBatchNorm,
+// FCGF_APR/model/common.py:6, lib/trainer.py:454-527; gamma = NULL: the affine-free InstanceNorm1d of KPFCNN's blocks,
+// Predator_APR/models/blocks.py:459-468):
+//   dbeta = sum dy,  dgamma = sum dy * xhat,  dx = gamma * rstd * (dy - dbeta / n - xhat * dgamma / n)
+// Two launches of reductions (256-row partial sums in fp64, combined in fixed order: deterministic) + one apply pass.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_norm_bwd_partial(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ dy, int64_t lddy, int64_t n, int c,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          double* __restrict__ partial) {
+  __shared__ double s_a[4][64], s_b[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
+  const int64_t r1 = min((long long)(r0 + kRowsPerBlock), (long long)n);
+  double a = 0.0, b = 0.0;
+  if (col < c) {
+    const float m = mean[col], rs = rstd[col];
+    for (int64_t rb = r0 + ty; rb < r1; rb += 32) {
+      float xv[8], gv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = rb + 4 * u;
+        xv[u] = r < r1 ? x[r * ldx + col] : m;
+        gv[u] = r < r1 ? dy[r * lddy + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += (double)gv[u];
+        b += (double)gv[u] * (double)((xv[u] - m) * rs);
+      }
+    }
+  }
+  s_a[ty][tx] = a;
+  s_b[ty][tx] = b;
+  __syncthreads();
+  if (ty == 0 && col < c) {
+    partial[((int64_t)blockIdx.x * 2 + 0) * c + col] = ((s_a[0][tx] + s_a[1][tx]) + s_a[2][tx]) + s_a[3][tx];
+    partial[((int64_t)blockIdx.x * 2 + 1) * c + col] = ((s_b[0][tx] + s_b[1][tx]) + s_b[2][tx]) + s_b[3][tx];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_norm_bwd_finish(const double* __restrict__ partial, int nblk, int64_t n, int c,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ k12) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  double a = 0.0, b = 0.0;
+  for (int blk = 0; blk < nblk; ++blk) {      // fixed order
+    a += partial[((int64_t)blk * 2 + 0) * c + col];
+    b += partial[((int64_t)blk * 2 + 1) * c + col];
+  }
+  if (dbeta) dbeta[col] = (float)a;
+  if (dgamma) dgamma[col] = (float)b;
+  k12[col] = (float)(a / (double)n);
+  k12[c + col] = (float)(b / (double)n);
+}
+
+__global__ void k_norm_bwd_apply(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                                 int64_t n, int c, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 const float* __restrict__ gamma, const float* __restrict__ k12, float* __restrict__ dx,
+                                 int64_t lddx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  const int64_t r = t / c;
+  const int col = (int)(t - r * c);
+  const float rs = rstd[col];
+  const float xh = (x[r * ldx + col] - mean[col]) * rs;
+  const float g = gamma ? gamma[col] : 1.f;
+  dx[r * lddx + col] = g * rs * (dy[r * lddy + col] - k12[col] - xh * k12[c + col]);
+}
+
 }  // namespace
+
+APR_API size_t apr_norm_backward_scratch_bytes(int64_t n, int32_t c) {
+  return (size_t)cdiv64(n > 0 ? n : 1, kRowsPerBlock) * 2 * (size_t)c * sizeof(double) + (size_t)2 * c * sizeof(float) + 512;
+}
+
+APR_API int apr_norm_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t n, int32_t c,
+                              const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
+                              float* dgamma, float* dbeta, void* scratch, size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(x && dy && mean && rstd && dx && n > 0 && c > 0 && ldx >= c && lddy >= c && lddx >= c,
+                "apr_norm_backward: bad arguments");
+  APR_CHECK_ARG(scratch && scratch_bytes >= apr_norm_backward_scratch_bytes(n, c), "apr_norm_backward: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv64(n, kRowsPerBlock);
+  double* partial = (double*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  float* k12 = (float*)(partial + (size_t)nblk * 2 * c);
+  hipLaunchKernelGGL(k_norm_bwd_partial, dim3(nblk, (unsigned)cdiv64(c, 64)), dim3(256), 0, st, x, ldx, dy, lddy, n, c, mean,
+                     rstd, partial);
+  hipLaunchKernelGGL(k_norm_bwd_finish, dim3((unsigned)cdiv64(c, 256)), dim3(256), 0, st, partial, nblk, n, c, dgamma, dbeta,
+                     k12);
+  hipLaunchKernelGGL(k_norm_bwd_apply, dim3((unsigned)cdiv64(n * c, 256)), dim3(256), 0, st, x, ldx, dy, lddy, n, c, mean,
+                     rstd, gamma, k12, dx, lddx);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
 
 APR_API size_t apr_bn_stats_scratch_bytes(int64_t n, int32_t c) {
   return (size_t)cdiv64(n > 0 ? n : 1, kRowsPerBlock) * 2 * (size_t)c * sizeof(double);

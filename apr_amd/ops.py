@@ -611,6 +611,50 @@ def norm_params(x, eps):
     return ss[0], ss[1]
 
 
+def norm_backward(x, dy, mean, rstd, gamma=None, want_affine_grads=True):
+    """dx (and dgamma, dbeta) of y = (x - mean) * rstd * gamma + beta over all rows (apr_norm_backward)."""
+    x, ldx = _rows(x, "norm_backward.x")
+    dy, lddy = _rows(dy, "norm_backward.dy")
+    n, c = x.shape
+    lib = _lib_()
+    dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
+    sb = int(lib.apr_norm_backward_scratch_bytes(n, c))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    check(lib.apr_norm_backward(ptr(x), ldx, ptr(dy), lddy, n, c, ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), c, ptr(dg),
+                                ptr(db), ptr(scratch), sb, stream()))
+    return dx, dg, db
+
+
+class NormFunction(torch.autograd.Function):
+    """y = (x - mean) / sqrt(var + eps) * weight + bias with the batch statistics of the rows of x, forward and backward on
+    the HIP kernels (apr_bn_stats + apr_affine_act; apr_norm_backward).  weight / bias None: no affine (InstanceNorm1d of
+    KPFCNN's blocks).  Returns (y, mean, var) -- mean / var detached, for the caller's running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        mean, var = bn_stats(x)
+        rstd = torch.rsqrt(var + eps)
+        # (x - mean) first, then the scale: x * scale - mean * scale cancels two large terms when |mean| >> std
+        scale = rstd if weight is None else rstd * weight.reshape(-1)
+        y = affine_act(x - mean, scale=scale.contiguous(), shift=None if bias is None else bias.reshape(-1).contiguous())
+        ctx.save_for_backward(x, mean, rstd, weight)
+        ctx.has_bias = bias is not None
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, mean, rstd, weight = ctx.saved_tensors
+        g = None if weight is None else weight.reshape(-1).contiguous()
+        dx, dg, db = norm_backward(x, dy.contiguous(), mean, rstd, g, want_affine_grads=weight is not None or ctx.has_bias)
+        dw = dg.reshape(weight.shape) if weight is not None else None
+        dbias = db if ctx.has_bias else None
+        return dx, dw, dbias, None
+
+
 def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None, leaky=None):
     """y = act(x*scale + shift + residual); relu=True -> ReLU, leaky=slope -> LeakyReLU(slope)."""
     x, ldx = _rows(x, "affine_act.x")

@@ -81,6 +81,40 @@ def linear(x, wp_info, shift=None, relu=False, out=None):
     return y
 
 
+class LinearFunction(torch.autograd.Function):
+    """y = x @ W^T (nn.Linear without bias; KPFCNN's unary / bottleneck layers, Predator_APR/models/blocks.py:499-504) with
+    forward, d x and d W on the HIP kernels: y and d x = dy @ W through the dense GEMM (`linear`), d W = dy^T x through
+    apr_spconv_wgrad with the identity map (deterministic chunked reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, wp_info):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        return linear(x, wp_info)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = weight.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = linear(dy, pack_linear(weight.detach()))          # [N, cout] @ [cout, cin]
+        if ctx.needs_input_grad[1]:
+            dw = ops.spconv_wgrad(x, dy, None, 1, cin, cout)[0].t()  # (x^T dy)^T
+        return dx, dw, None
+
+
+def linear_train(x, weight, wp_info):
+    """The tracked (training) form of a bias-free Linear: HIP kernels when both widths are multiples of 64, torch otherwise."""
+    cout, cin = weight.shape
+    if HIP_TRAIN_LINEAR and cin % 64 == 0 and cout % 64 == 0 and x.shape[0] > 0:
+        return LinearFunction.apply(x, weight, wp_info)
+    return torch.nn.functional.linear(x, weight)
+
+
+HIP_TRAIN_LINEAR = os.environ.get("APR_HIP_TRAIN_LINEAR", "1") != "0"   # A/B switch: 0 = torch's Linear in training
+HIP_TRAIN_NORM = os.environ.get("APR_HIP_TRAIN_NORM", "1") != "0"   # A/B switch: 0 = torch ops for the training-mode norms
 DENSE_BF3 = os.environ.get("APR_DENSE_BF3", "1") != "0"     # A/B switch: 0 keeps every Linear on the exact-fp32 MFMA
 
 
@@ -231,10 +265,13 @@ def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=No
     if segments is not None and len(segments) <= 2:
         segments = None
     if tracking(x, residual):
+        # training: statistics, normalisation and its backward on the HIP kernels (ops.NormFunction, no affine); the
+        # activation / residual add stay elementwise torch ops
+        nf = lambda t: ops.NormFunction.apply(t, None, None, eps)[0] if HIP_TRAIN_NORM else instance_norm_rows(t, eps)
         if segments is None:
-            y = instance_norm_rows(x, eps)
+            y = nf(x)
         else:
-            y = torch.cat([instance_norm_rows(x[a:b], eps) for a, b in zip(segments[:-1], segments[1:])], 0)
+            y = torch.cat([nf(x[a:b]) for a, b in zip(segments[:-1], segments[1:])], 0)
         return _act(y if residual is None else y + residual, leaky, relu)
     if segments is not None:
         x, ldx = ops._rows(x, "instance_norm_act.x")

@@ -142,7 +142,8 @@ class UnaryBlock(nn.Module):
         return self._packed
 
     def forward(self, x, batch=None):
-        y = self.mlp(x) if kp_ops.tracking(x, self.mlp.weight) else kp_ops.linear(x, self._weight())
+        y = (kp_ops.linear_train(x, self.mlp.weight, self._weight()) if kp_ops.tracking(x, self.mlp.weight)
+             else kp_ops.linear(x, self._weight()))
         return self.batch_norm(y, leaky=None if self.no_relu else 0.1, segments=pair_segments(batch, y))
 
 

@@ -233,6 +233,16 @@ int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c,
                  float* mean, float* var, void* scratch, size_t scratch_bytes, void* stream);
 size_t apr_bn_stats_scratch_bytes(int64_t n, int32_t c);
 
+/* Backward of y = (x - mean) * rstd * gamma + beta over all n rows (training-mode MinkowskiBatchNorm,
+ * FCGF_APR/model/common.py:6 under FCGF_APR/lib/trainer.py:454-527; gamma = NULL: the affine-free InstanceNorm1d of
+ * KPFCNN's blocks, Predator_APR/models/blocks.py:459-468 under Predator_APR/lib/trainer.py:142-280): dx, and (non-NULL)
+ * dgamma[c], dbeta[c].  mean / rstd: the forward's batch statistics (rstd = 1 / sqrt(var + eps)).  fp64 partial sums
+ * combined in fixed order: deterministic. */
+size_t apr_norm_backward_scratch_bytes(int64_t n, int32_t c);
+int apr_norm_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t n, int32_t c,
+                      const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
+                      float* dgamma, float* dbeta, void* scratch, size_t scratch_bytes, void* stream);
+
 /* Per-channel normalisation parameters over all rows, no affine: scale = 1/sqrt(var + eps),
  * shift = -mean*scale (InstanceNorm1d over the stacked points, Predator_APR/models/blocks.py:451-466;
  * InstanceNorm2d of the edge convolutions, models/gcn.py:41-48).  Same scratch as apr_bn_stats. */

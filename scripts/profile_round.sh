@@ -5,7 +5,7 @@
 #   gpurun -- scripts/profile_round.sh r02        -> gpurun_out/profile_r02/*  (scripts/collect_profiles.py copies
 #   what is judged into profiles/)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
