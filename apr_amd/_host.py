@@ -29,11 +29,19 @@ def limit_cpu_threads():
     quota allows 16 CPUs: the idle pool threads spin after every small CPU op (a 4x4 pose product is enough), the
     quota runs out and the kernel throttles the whole process for the rest of the 100 ms period -- measured on the
     MI355X box as 20-70 ms stalls every few pairs (cpu.stat nr_throttled 82 in a 9 s run, 0 with one thread).  The hot
-    path has no CPU tensor work worth a pool: cap it at a quarter of the quota (once per process)."""
+    path has no CPU tensor work worth a pool: cap it at a quarter of the quota (once per process, announced with a
+    warning).  A process-wide side effect of building a pipeline object: APR_CPU_THREADS=0 opts out, APR_CPU_THREADS=n
+    picks the cap."""
     global _done
     if _done:
         return
     _done = True
-    cap = max(1, min(8, cpu_quota() // 4))
+    want = os.environ.get("APR_CPU_THREADS")          # "0": leave torch's pool alone; "n": cap at n
+    if want == "0":
+        return
+    cap = max(1, int(want)) if want else max(1, min(8, cpu_quota() // 4))
     if torch.get_num_threads() > cap:
+        import warnings
+        warnings.warn(f"apr_amd: capping torch's intra-op CPU pool at {cap} threads (was {torch.get_num_threads()}; cgroup "
+                      f"quota {cpu_quota()} CPUs); APR_CPU_THREADS=0 leaves it alone", RuntimeWarning, stacklevel=2)
         torch.set_num_threads(cap)

@@ -603,6 +603,9 @@ APR_API int apr_feature_nn_fast(const float* f0, int64_t n0, const float* f1, in
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(n0 >= 0 && n1 > 0 && n1 < (1ll << 31) && n0 < (1ll << 31), "apr_feature_nn_fast: bad shape");
   APR_CHECK_ARG(c == 32 || c == 64 || c == 128, "apr_feature_nn_fast: c=%d, supported: 32, 64, 128", c);
+  // the scratch bound (apr_feature_nn_fast_scratch_bytes) assumes at most ceil(768 / qblocks) target chunks, which holds
+  // while one chunk (capped at 2^24 - 64 rows) can cover n1 / that count
+  APR_CHECK_ARG(n1 < (1ll << 24) - 64, "apr_feature_nn_fast: n1 = %lld, supported below 2^24 - 64 targets", (long long)n1);
   APR_CHECK_ARG(((((uintptr_t)f0) | ((uintptr_t)f1)) & 15) == 0, "apr_feature_nn_fast: 16-byte aligned rows required");
   APR_CHECK_ARG(scratch_bytes >= apr_feature_nn_fast_scratch_bytes(n0, n1, c), "apr_feature_nn_fast: scratch too small");
   if (n0 == 0) return APR_OK;

@@ -110,6 +110,21 @@ class KPFCNN(nn.Module):
             self._temp_key = key
         return self._temp
 
+    def _drop_temperature(self):
+        self._temp_key = None
+
+    def train(self, mode=True):                       # writes through `.data` do not bump `_version`: every entry point
+        self._drop_temperature()                      # that can rewrite epsilon behind the cache's back drops it
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._drop_temperature()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_temperature()
+        return super()._apply(fn, *args, **kwargs)
+
     def regular_score(self, score):
         score = torch.where(torch.isnan(score), torch.zeros_like(score), score)
         return torch.where(torch.isinf(score), torch.zeros_like(score), score)

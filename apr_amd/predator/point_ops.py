@@ -116,10 +116,10 @@ def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, limit=0):
 class SearchGrid:
     """The scratch buffer of a radius_neighbors_async call, kept so that a second query set can search the same
     support grid (apr_radius_neighbors_regrid_async)."""
-    __slots__ = ("scratch", "supports", "radius", "ns")
+    __slots__ = ("scratch", "supports", "radius", "ns", "stream", "version")
 
     def __init__(self):
-        self.scratch = self.supports = self.radius = self.ns = None
+        self.scratch = self.supports = self.radius = self.ns = self.stream = self.version = None
 
 
 def radius_neighbors_async(queries, supports, q_lengths, s_lengths, radius, limit, flags, keep_grid=None,
@@ -138,8 +138,10 @@ def radius_neighbors_async(queries, supports, q_lengths, s_lengths, radius, limi
         raise _lib.AprHipError("radius_neighbors_async: needs limit > 0 and a contiguous int32[2] flag tensor")
     out = torch.empty((nq, int(limit)), dtype=torch.int32, device=queries.device)
     sb = int(lib.apr_radius_scratch_bytes(nq, ns))
+    # the grid in the scratch is only valid for the tensor it was built from, unmodified since (in-place writes bump
+    # `_version`), and for work ordered behind the build: the same stream
     if (grid is not None and grid.supports is supports and grid.radius == float(radius) and grid.ns == ns
-            and grid.scratch.numel() >= sb):
+            and grid.scratch.numel() >= sb and grid.stream == stream().value and grid.version == supports._version):
         # `keep_grid` of an earlier call on the same supports / radius: search its grid, no rebuild
         check(lib.apr_radius_neighbors_regrid_async(ptr(queries), nq, ptr(supports), ns, qp, sp, len(qa), float(radius),
                                                     int(limit), ptr(out), int(limit), ptr(flags), ptr(grid.scratch),
@@ -152,6 +154,7 @@ def radius_neighbors_async(queries, supports, q_lengths, s_lengths, radius, limi
                                          ptr(out), int(limit), ptr(flags), ptr(scratch), sb, stream()))
     if keep_grid is not None:
         keep_grid.scratch, keep_grid.supports, keep_grid.radius, keep_grid.ns = scratch, supports, float(radius), ns
+        keep_grid.stream, keep_grid.version = stream().value, supports._version
     return out
 
 

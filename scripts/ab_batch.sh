@@ -1,7 +1,8 @@
 #!/bin/bash
-# pairs/s over (pairs per step, streams) settings; args: "B:S" ...
-for spec in "$@"; do
-  B=${spec%%:*}; S=${spec#*:}
-  v=$(timeout -k 10 200 python bench.py --no-cpu-baseline --no-roofline --steps $((900 / B)) --pairs-per-step $B --streams $S </dev/null 2>/dev/null | python -c "import sys,json; print(round(json.loads(sys.stdin.read().strip().splitlines()[-1])['value'],1))")
-  echo "B=$B streams=$S: $v pairs/s"
+# pairs per step x steps in flight sweep of the headline loop (no roofline / workloads / cpu baseline)
+for B in ${BS:-4 6 8 10 12}; do
+  for S in ${SS:-3}; do
+    python bench.py --pairs-per-step $B --streams $S --steps ${STEPS:-120} --no-roofline --no-workloads --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('B=$B S=$S', round(d['value'],1), 'pairs/s', round(d['ms_per_step'],3), 'ms/step')"
+  done
 done

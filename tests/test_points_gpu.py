@@ -52,7 +52,7 @@ def test_grid_subsample_cells_beyond_the_wave_sort(dev):
     t0 = time.perf_counter()
     gp, gl, gf = point_ops.grid_subsample(tp, lens, 0.3, tf)
     torch.cuda.synchronize()
-    assert time.perf_counter() - t0 < 0.05
+    assert time.perf_counter() - t0 < 0.5      # the regression this guards against took 1 s; 10x headroom for a busy box
     assert np.array_equal(gl, rl)
     assert np.array_equal(REF.canonical_rows(gp.cpu().numpy(), gl).view(np.uint32),
                           REF.canonical_rows(rp, rl).view(np.uint32))
