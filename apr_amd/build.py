@@ -125,7 +125,7 @@ def check_os_pipeline(verbose: bool = True) -> None:
             for tok in ops[2:]:
                 src_regs |= regs(tok)
             if src_regs & loaded[k]:
-                bad.append(t)
+                bad.append(f"{t}    [{k[:48]}]")
     if not loaded or not all(loaded.values()):
         raise RuntimeError("check_os_pipeline: found no inline-asm row loads in k_os_conv (the check is out of date)")
     if bad:
