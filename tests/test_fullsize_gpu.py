@@ -229,3 +229,39 @@ def test_config5_distant_pair_registration_end_to_end(dev):
     rte, rre = registration.rte_rre(T_est, T)
     assert info["n0"] == m0 and info["n1"] == m1 and info["n_valid"] > 1000
     assert rte < 0.3 and rre < 0.5, (rte, rre, info)
+
+
+def test_bn2c_headline_batch_matches_oracle_and_single_frames(dev):
+    """The headline's encoder call at its real shape: ResUNetBN2C / 32 on a batched sparse tensor of 6 full 118 k-point
+    frames (a bench step has 12) -- the shape at which the 64-channel residual blocks run on the output-stationary kernel
+    with tiles of several hundred rows, the 128- / 256-channel levels on the weight-stationary pair and the rest on the
+    tile kernel.  Every frame's rows against the CPU oracle's encode of that frame alone (north_star: 1e-4 relative;
+    asserted 2e-5), and the same call with every stage forced onto the tile kernel (exact-fp32 MFMA) for the default
+    path's own deviation."""
+    import os
+    from apr_amd.fcgf.pipeline import PairRegistration
+    om, hm = model_pair("ResUNetBN2C", out_channels=32)
+    om.eval(); hm.eval()
+    frames = [synth.make_frame(s) for s in range(6)]
+    pipe = PairRegistration(hm, voxel_size=0.3)
+    clouds = [torch.from_numpy(f).to(dev) for f in frames]
+    cm, counts, first, offs, pts_all = pipe.voxelize_batch(clouds)
+    F = pipe.encode_batch(cm)
+    assert F.shape == (sum(counts), 32) and sum(counts) > 70000
+    o = 0
+    for b, xyz in enumerate(frames):
+        c, sel = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+        C = OME.batched_coordinates([c])
+        with torch.no_grad():
+            ref = om(OME.SparseTensor(np.ones((len(C), 1), np.float32), coordinates=C)).F
+        assert counts[b] == len(C)
+        assert rel_l2(F[o:o + counts[b]].cpu(), ref) < 2e-5, b
+        o += counts[b]
+    again = pipe.encode_batch(cm)
+    assert torch.equal(again, F)                                   # bitwise reproducible, run to run
+    os.environ["APR_WS_STAGES"], os.environ["APR_OS_STAGES"] = "none", "none"
+    try:
+        tile = pipe.encode_batch(pipe.voxelize_batch(clouds)[0])
+    finally:
+        os.environ.pop("APR_WS_STAGES"); os.environ.pop("APR_OS_STAGES")
+    assert rel_l2(F.cpu(), tile.cpu()) < 5e-6
