@@ -518,7 +518,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     results = {}
     step_log = []      # (step, worker, host start, host end) of every step
-    job = {"first": 0, "last": 0, "stop": False, "err": None, "next": 0}
+    job = {"first": 0, "last": 0, "stop": False, "err": None, "next": 0, "stagger": 0.0}
     take = threading.Lock()
     go = threading.Barrier(nstreams + 1)
     done = threading.Barrier(nstreams + 1)
@@ -531,6 +531,14 @@ def main():
                 if job["stop"]:
                     return
                 try:
+                    # Staggered start: released together, the workers run their first steps in the same phase -- three
+                    # front ends, then three encoders, then three matchers, and three Python phases queueing on the GIL
+                    # (step log of round 2's driver runs: the first three steps took 10-12 ms each against 7.5 ms for
+                    # three steps in steady state, and the convoy lasted two more rounds).  In steady state steps
+                    # complete one interval apart; worker w therefore starts w intervals late, which is where the
+                    # pipeline would have it anyway.  The wait is inside the timed region.
+                    if job["stagger"] > 0 and w > 0:
+                        time.sleep(w * job["stagger"])
                     while True:      # the next unclaimed step (a static deal leaves workers idle at the tail)
                         with take:
                             i = job["next"]
@@ -586,6 +594,13 @@ def main():
     tp = time.perf_counter()
     run_steps(0, nprime)
     log(f"setup: {nprime} priming steps on {nstreams} worker stream(s) in {time.perf_counter() - tp:.3f}s")
+    # the steady-state interval between step completions, from the priming run (the start stagger of the workers)
+    ends0 = sorted(tb for _, _, _, tb in step_log)
+    gaps0 = np.diff(np.array(ends0)) if len(ends0) > 2 else np.array([0.0])
+    stagger_env = os.environ.get("APR_BENCH_STAGGER_MS")
+    job["stagger"] = (float(stagger_env) * 1e-3 if stagger_env is not None
+                      else (float(np.median(gaps0)) if not pipelined and nstreams > 1 else 0.0))
+    log(f"setup: worker start stagger {1e3 * job['stagger']:.3f} ms")
     # ... then the W warm-up steps the contract asks for
     run_steps(nprime, nprime + args.warmup)
     step_log.clear()
