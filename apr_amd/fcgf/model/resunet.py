@@ -171,6 +171,9 @@ class ResUNet2(ME.MinkowskiNetwork):
         batch = ops.SpconvBatch()   # the 23 conv launches leave through ONE library call
 
         ws, osn = _ws_stages(), _os_stages()
+        # One library call per stage (9 per encode) instead of one per encode: with a single step in flight the GPU idled
+        # for the ~0.6 ms Python needs to plan all 23 launches before the first one left (APR_FUSED_EAGER=0: one call)
+        eager = os.environ.get("APR_FUSED_EAGER", "1") != "0"
 
         def stage(name, feats, cmap, n_out, bmap, out):
             """conv -> folded BN -> residual block; cmap / bmap = (ts_in, ts_out, kernel, transpose)."""
@@ -185,7 +188,10 @@ class ResUNet2(ME.MinkowskiNetwork):
                 bl = cm.os_pair_list(*bmap, blk.conv1.in_channels, blk.conv1.out_channels)
             if bl is None and "block" + name in ws:
                 bl = cm.pair_list(*bmap)
-            return blk.fused_eval(a, cm.kernel_map(*bmap), out, batch=batch, plist=bl)
+            r = blk.fused_eval(a, cm.kernel_map(*bmap), out, batch=batch, plist=bl)
+            if eager:
+                batch.launch()      # the stage's three convolutions leave now: the GPU works while Python plans the next stage
+            return r
 
         stage("1", x.F, (1, 1, k1, False), N1, (1, 1, 3, False), s1)
         stage("2", s1, (1, 2, 3, False), N2, (2, 2, 3, False), s2)
