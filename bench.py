@@ -194,6 +194,15 @@ def extra_workloads(dev, log):
     ks = kp_ops.kpconv_profile_summary(kp_ops.PROFILE)
     kp_ops.PROFILE = None
     kr = conv_roofline(ks)
+    # counter traffic of the kernel-point correlation (k_kpconv_weighted_mfma: the gather + the [N, 15 cin] intermediate it
+    # writes for step 2), per launch, from the committed PMC passes over scripts/kpconv_bench.py (the level mix of one pair)
+    try:
+        import glob
+        f_ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spconv_summary.json")))[-1]
+        kr["traffic"] = json.load(open(f_))["predator_kpconv"]["kernels"]["k_kpconv_weighted_mfma"]["hbm_bytes_per_launch"]
+        kr["traffic_source"] = os.path.relpath(f_, ROOT) + " (k_kpconv_weighted_mfma per launch, one pair per call)"
+    except (IndexError, KeyError, OSError):
+        pass
     kr["kernel"] = ("KPConv layer = k_row_sums + k_kpconv_weighted_mfma (kernel-point correlation) + "
                     "k_dense_gemm_bf3 ([N, 15*cin] x [15*cin, cout], bf16 3-way split, fp32-equivalent; priced "
                     f"against the fp32-MFMA peak); {ks['launches']} layers of one KPFCNN forward")
