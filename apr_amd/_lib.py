@@ -114,6 +114,10 @@ PROTOTYPES = {
     "apr_row_sums": (C.c_int, [_p, _i64, _i64, _i32, _p, _p]),
     "apr_kpconv_weighted": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _p, _i32, _f32, _p, _p, _i64, _p]),
     "apr_kpconv_dfeat": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _p, _i32, _f32, _p, _p, _i64, _p]),
+    "apr_kpconv_dfeat_contrib": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _p, _i32, _f32, _p, _p, _p]),
+    "apr_reverse_table_scratch_bytes": (_sz, [_i64, _i32, _i64]),
+    "apr_reverse_table_build": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _sz, _p]),
+    "apr_reverse_gather": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _i64, _p]),
     "apr_gather_pool": (C.c_int, [_p, _i64, _i64, _i32, _p, _i32, _i64, _i32, _p, _i64, _p]),
     "apr_edge_features": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "apr_group_max": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _f32, _p, _i64, _p]),

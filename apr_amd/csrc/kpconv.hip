@@ -153,7 +153,8 @@ template <int CPL>   // channels per lane: cin <= 64 * CPL
 __global__ __launch_bounds__(256) void k_kpconv_dfeat(
     const float* __restrict__ q_pts, const float* __restrict__ s_pts, const int* __restrict__ nbr, int H,
     const float* __restrict__ dwf, int64_t lddwf, int cin, const float* __restrict__ kp, float extent,
-    const float* __restrict__ rowsum, float* __restrict__ dx, int64_t lddx, int nq, int ns) {
+    const float* __restrict__ rowsum, float* __restrict__ dx, int64_t lddx, int nq, int ns,
+    float* __restrict__ contrib) {      // non-NULL: the deterministic form -- row (q, h) of contrib instead of an atomic add
   __shared__ int s_idx[4][kMaxH];
   __shared__ float s_w[4][kMaxH][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -198,7 +199,10 @@ __global__ __launch_bounds__(256) void k_kpconv_dfeat(
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < kKP; ++k) acc = fmaf(w[k], g[u][k], acc);
-      if (c < cin) atomicAdd(dx + (int64_t)idx * lddx + c, acc);
+      if (c < cin) {
+        if (contrib) contrib[((int64_t)qi * H + h) * cin + c] = acc;
+        else atomicAdd(dx + (int64_t)idx * lddx + c, acc);
+      }
     }
   }
 }
@@ -665,9 +669,9 @@ APR_API int apr_kpconv_weighted(const float* q_pts, int64_t nq, const float* s_p
   return APR_OK;
 }
 
-APR_API int apr_kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr, int32_t H,
-                             const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points, int32_t n_kp,
-                             float extent, const float* rowsum, float* dx, int64_t lddx, void* stream) {
+static int kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr, int32_t H,
+                        const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points, int32_t n_kp,
+                        float extent, const float* rowsum, float* dx, int64_t lddx, float* contrib, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(n_kp == kKP, "apr_kpconv_dfeat: built for %d kernel points, got %d", kKP, n_kp);
   APR_CHECK_ARG(nq >= 0 && ns > 0 && H > 0 && H <= kMaxH && cin > 0 && cin <= 512 && extent > 0.f,
@@ -677,7 +681,7 @@ APR_API int apr_kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts,
   const unsigned grid = (unsigned)cdiv64(nq, 4);
 #define APR_DF(N)                                                                                                     \
   hipLaunchKernelGGL(k_kpconv_dfeat<N>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, dwf, lddwf, cin, kernel_points, \
-                     extent, rowsum, dx, lddx, (int)nq, (int)ns)
+                     extent, rowsum, dx, lddx, (int)nq, (int)ns, contrib)
   if (cin <= 64) APR_DF(1);
   else if (cin <= 128) APR_DF(2);
   else if (cin <= 256) APR_DF(4);
@@ -685,6 +689,24 @@ APR_API int apr_kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts,
 #undef APR_DF
   APR_LAUNCH_CHECK();
   return APR_OK;
+}
+
+APR_API int apr_kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr, int32_t H,
+                             const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points, int32_t n_kp,
+                             float extent, const float* rowsum, float* dx, int64_t lddx, void* stream) {
+  return kpconv_dfeat(q_pts, nq, s_pts, ns, nbr, H, dwf, lddwf, cin, kernel_points, n_kp, extent, rowsum, dx, lddx, nullptr,
+                      stream);
+}
+
+// The deterministic form: the per-(query, neighbour) contributions go to contrib f32 [nq * H, cin] (rows of padding
+// neighbours are left untouched and never read); apr_reverse_gather then sums every support point's rows in the order of
+// the reverse table (apr_reverse_table_build): a fixed order, no float atomics.
+APR_API int apr_kpconv_dfeat_contrib(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr,
+                                     int32_t H, const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points,
+                                     int32_t n_kp, float extent, const float* rowsum, float* contrib, void* stream) {
+  APR_CHECK_ARG(contrib != nullptr, "apr_kpconv_dfeat_contrib: null contribution buffer");
+  return kpconv_dfeat(q_pts, nq, s_pts, ns, nbr, H, dwf, lddwf, cin, kernel_points, n_kp, extent, rowsum, contrib, cin,
+                      contrib, stream);
 }
 
 APR_API int apr_gather_pool(const float* x, int64_t ldx, int64_t ns, int32_t c, const int32_t* inds, int32_t H,

@@ -154,6 +154,32 @@ def kpconv_weighted(q_pts, s_pts, nbr, x, kernel_points, extent):
     return wf
 
 
+_REV_CACHE = {}     # (data_ptr, shape, version, ns) -> (nbr tensor kept alive, rev_t, start): one build per neighbour table
+
+
+def reverse_table(nbr, ns):
+    """Flat positions of `nbr` [nq, H] sorted by the support row they point at + the start of every row's run
+    (apr_reverse_table_build; stable, deterministic).  Cached per table: the layers of a pyramid level share theirs."""
+    key = (nbr.data_ptr(), tuple(nbr.shape), nbr._version, int(ns))
+    hit = _REV_CACHE.get(key)
+    if hit is not None:
+        return hit[1], hit[2]
+    if len(_REV_CACHE) > 16:
+        _REV_CACHE.clear()
+    lib = _lib.load()
+    nq, H = nbr.shape
+    rev_t = torch.empty(nq * H, dtype=torch.int32, device=nbr.device)
+    start = torch.empty(int(ns) + 1, dtype=torch.int32, device=nbr.device)
+    sb = int(lib.apr_reverse_table_scratch_bytes(nq, H, int(ns)))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=nbr.device)
+    check(lib.apr_reverse_table_build(ptr(nbr), nq, H, int(ns), ptr(rev_t), ptr(start), ptr(scratch), sb, stream()))
+    _REV_CACHE[key] = (nbr, rev_t, start)
+    return rev_t, start
+
+
+DET_DX = os.environ.get("APR_KPCONV_DX", "det") != "atomic"     # A/B switch: "atomic" = round 2's float-atomic scatter
+
+
 class KPConvFunction(torch.autograd.Function):
     """Rigid KPConv (blocks.py:229-374) with forward AND both gradients on the HIP kernels:
     forward   wf = step 1 (apr_kpconv_weighted), out = wf @ W (dense MFMA GEMM);
@@ -187,12 +213,24 @@ class KPConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             dwf = linear(dout, pack_linear(weights.detach().reshape(K * cin, cout).t().contiguous(), bf3=False))   # [nq, K*cin]
             dwf, lddwf = ops._rows(dwf, "kpconv.dwf")
-            dx = torch.zeros_like(x)
             rs = row_sums(x)
-            check(_lib.load().apr_kpconv_dfeat(ptr(q_pts.contiguous()), q_pts.shape[0], ptr(s_pts.contiguous()),
-                                               s_pts.shape[0], ptr(inds), inds.shape[1], ptr(dwf), lddwf, cin,
-                                               ptr(kernel_points.contiguous()), kernel_points.shape[0], ctx.extent,
-                                               ptr(rs), ptr(dx), dx.stride(0), stream()))
+            lib = _lib.load()
+            nq, H, ns = q_pts.shape[0], inds.shape[1], s_pts.shape[0]
+            if DET_DX and cin % 4 == 0 and nq * H * cin * 4 <= (8 << 30):
+                # deterministic: one contribution row per (query, neighbour), summed per support row in the fixed order of the
+                # reverse table (no float atomics: the same bits every run)
+                rev_t, start = reverse_table(inds, ns)
+                contrib = torch.empty((nq * H, cin), dtype=torch.float32, device=x.device)
+                check(lib.apr_kpconv_dfeat_contrib(ptr(q_pts.contiguous()), nq, ptr(s_pts.contiguous()), ns, ptr(inds), H,
+                                                   ptr(dwf), lddwf, cin, ptr(kernel_points.contiguous()),
+                                                   kernel_points.shape[0], ctx.extent, ptr(rs), ptr(contrib), stream()))
+                dx = torch.empty_like(x)
+                check(lib.apr_reverse_gather(ptr(contrib), cin, ptr(rev_t), ptr(start), ns, ptr(dx), dx.stride(0), stream()))
+            else:
+                dx = torch.zeros_like(x)
+                check(lib.apr_kpconv_dfeat(ptr(q_pts.contiguous()), nq, ptr(s_pts.contiguous()), ns, ptr(inds), H, ptr(dwf),
+                                           lddwf, cin, ptr(kernel_points.contiguous()), kernel_points.shape[0], ctx.extent,
+                                           ptr(rs), ptr(dx), dx.stride(0), stream()))
         return None, None, None, dx, dw, None, None
 
 

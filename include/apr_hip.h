@@ -479,6 +479,19 @@ int apr_kpconv_dfeat(const float* q_pts, int64_t nq, const float* s_pts, int64_t
                      const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points, int32_t n_kp,
                      float extent, const float* rowsum, float* dx, int64_t lddx, void* stream);
 
+/* The same gradient without float atomics (deterministic): apr_kpconv_dfeat_contrib writes the contribution of every
+ * (query, neighbour) entry to contrib f32 [nq * H, cin]; apr_reverse_table_build sorts the table's flat positions by the
+ * support row they point at (stable: ties in ascending position; once per neighbour table) and apr_reverse_gather sums
+ * every support row's contributions in that order: dx f32 [ns, cin] is WRITTEN, not accumulated. */
+int apr_kpconv_dfeat_contrib(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int32_t* nbr, int32_t H,
+                             const float* dwf, int64_t lddwf, int32_t cin, const float* kernel_points, int32_t n_kp,
+                             float extent, const float* rowsum, float* contrib, void* stream);
+size_t apr_reverse_table_scratch_bytes(int64_t nq, int32_t H, int64_t ns);
+int apr_reverse_table_build(const int32_t* nbr, int64_t nq, int32_t H, int64_t ns, int32_t* rev_t, int32_t* start,
+                            void* scratch, size_t scratch_bytes, void* stream);
+int apr_reverse_gather(const float* src, int32_t c, const int32_t* rev_t, const int32_t* start, int64_t ns, float* out,
+                       int64_t ldo, void* stream);
+
 /* mode 0: max_pool(x, inds) (blocks.py:86-102); mode 1: closest_pool(x, inds) (blocks.py:71-83).
  * Index ns addresses an implicit all-zero shadow row. */
 int apr_gather_pool(const float* x, int64_t ldx, int64_t ns, int32_t c, const int32_t* inds, int32_t H,

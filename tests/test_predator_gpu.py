@@ -180,7 +180,8 @@ def test_kpfcnn_training_path_gradients(dev):
 
 
 def test_kpconv_backward_kernels_match_autograd_through_oracle(dev):
-    """SURVEY 8(f) next-3, Predator side: d features (apr_kpconv_dfeat, on the forward's neighbour table) and d weights
+    """SURVEY 8(f) next-3, Predator side: d features (apr_kpconv_dfeat_contrib + apr_reverse_gather over the reverse of the
+    forward's neighbour table; round 2's apr_kpconv_dfeat as the cross-check) and d weights
     (apr_spconv_wgrad on the recomputed step-1 output) against torch autograd through the CPU oracle's KPConv
     (= Predator_APR/models/blocks.py:229-374), relative L2 <= 1e-4."""
     rng = np.random.default_rng(4)
@@ -203,6 +204,21 @@ def test_kpconv_backward_kernels_match_autograd_through_oracle(dev):
         assert rel_l2(out.detach().cpu(), KO.kpconv(q, s, inds, x, W, kp, 1.2)) < 5e-6
         assert rel_l2(xg.grad.cpu(), xr.grad) < 1e-4, (cin, cout)
         assert rel_l2(Wg.grad.cpu(), Wr.grad) < 1e-4, (cin, cout)
+        # d x is DETERMINISTIC (contribution rows summed per support point in reverse-table order, no float atomics): the
+        # same bits on a second backward; and equal to round 2's atomic scatter up to summation order
+        g1 = xg.grad.clone()
+        xg.grad = None
+        out2 = kp_ops.KPConvFunction.apply(q.to(dev), s.to(dev), inds.to(dev), xg, Wg, kp.to(dev), 1.2)
+        (out2 * proj.to(dev)).sum().backward()
+        assert torch.equal(xg.grad, g1), (cin, cout)
+        kp_ops.DET_DX = False
+        try:
+            xa = x.to(dev).requires_grad_(True)
+            (kp_ops.KPConvFunction.apply(q.to(dev), s.to(dev), inds.to(dev), xa, W.to(dev), kp.to(dev), 1.2)
+             * proj.to(dev)).sum().backward()
+        finally:
+            kp_ops.DET_DX = True
+        assert rel_l2(xa.grad.cpu(), g1.cpu()) < 2e-6, (cin, cout)
 
 
 def test_stacked_pairs_equal_one_pair_at_a_time(dev):
