@@ -335,3 +335,35 @@ def test_many_survivors_count_path_equals_full_fp64_scoring(dev, share, iters):
     assert np.array_equal(T1, T0)
     rte, rre = registration.rte_rre(T1, T_gt)
     assert rte < 0.1 and rre < 0.2
+
+
+@pytest.mark.parametrize("n,scale,noise", [(100, 1.0, 0.0), (777, 1.0, 0.05), (3001, 1000.0, 30.0), (64, 1.0, 0.02)])
+def test_count_path_edge_cases_equal_full_fp64_scoring(dev, n, scale, noise):
+    """The fp32-screened count path (above 2048 surviving hypotheses) on small and awkward correspondence sets: fewer
+    correspondences than one 64-wide mini-chunk, an odd count (padded row), coordinates 1000x KITTI's (the guard band then
+    spans most of the threshold: nearly every cell is recounted in fp64) -- always the same bits as scoring every
+    survivor in fp64 (APR_RANSAC_COUNT=0)."""
+    import os
+    rng = np.random.default_rng(n)
+    src = (rng.uniform(-40, 40, (n, 3)) * scale).astype(np.float32)
+    ang = 0.3
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    t = np.array([3.0, -2.0, 0.5]) * scale
+    tgt = (src.astype(np.float64) @ R.T + t + rng.normal(0, noise, (n, 3))).astype(np.float32)
+    corr = np.arange(n, dtype=np.int64)
+    bad = rng.random(n) < 0.2
+    corr[bad] = rng.integers(0, n, int(bad.sum()))
+    thr = 0.3 * scale
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["APR_RANSAC_COUNT"] = mode
+        try:
+            res[mode] = ops.ransac_pose(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev),
+                                        torch.from_numpy(corr).to(dev), thr, 0.9, 60000, 3)
+        finally:
+            os.environ.pop("APR_RANSAC_COUNT", None)
+    (T1, i1), (T0, i0) = res["1"], res["0"]
+    assert i1["n_valid"] == i0["n_valid"] > 2048, i1
+    assert i1["inliers"] == i0["inliers"] and i1["rmse"] == i0["rmse"] and i1["best_iteration"] == i0["best_iteration"]
+    assert np.array_equal(T1, T0)
+    assert i1["inliers"] >= 0.7 * n
