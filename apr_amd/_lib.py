@@ -122,6 +122,7 @@ PROTOTYPES = {
     "apr_edge_features": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "apr_group_max": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _f32, _p, _i64, _p]),
     "apr_mha": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "apr_mha_headmajor": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_softmax_matvec": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _p, _p]),
     "apr_softmax_matvec_bt": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _p, _p]),
     "apr_softmax_matvec_mfma": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _p, _p]),

@@ -621,6 +621,126 @@ __global__ __launch_bounds__(64 * kSmvWaves) void k_softmax_matvec_mfma(const fl
   }
 }
 
+// Multi-head attention on the fp32 MFMA, inputs HEAD-MAJOR (channel h * 64 + d: the caller permutes the output channels
+// of the three projections, see gcn.py), output in the reference's interleaved layout (channel d * heads + h) so the
+// merge layer is untouched.  A workgroup owns 16 queries of ONE head; its 4 waves walk the 16-key tiles in turn with an
+// online softmax.  Per tile: scores^T (rows = keys, columns = queries) as in k_softmax_matvec_mfma, so lane (r16, q)
+// holds keys 4q .. 4q+3 against ITS query r16; the per-query tile maximum needs two cross-lane steps (the 4 q-lanes of
+// a query); the probabilities are then already the B operand of O^T += V^T P (k-slot q of step i = key 4q + i), the A
+// operand being V[key 4q+i][4 r16 + b] -- one 16-byte load per step serves the 4 row blocks b, and the accumulators end
+// as O^T[d = 4 (4q+i) + b][query r16]: one query per lane, so the online rescale is a per-lane scalar.  The 4 waves'
+// (max, denominator, numerator) triples are merged in fixed order through LDS.
+__global__ __launch_bounds__(256) void k_mha_mfma(const float* __restrict__ qm, const float* __restrict__ km,
+                                                  const float* __restrict__ vm, int n, int m, int heads,
+                                                  float scl, float* __restrict__ out) {
+  constexpr int DIM = 64;
+  __shared__ float s_o[4][16][DIM + 1];      // [wave][query][d]
+  __shared__ float s_mx[4][16], s_den[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int nqb = (n + 15) >> 4;
+  const int qb = blockIdx.x % nqb, h = blockIdx.x / nqb;
+  const int i0 = qb * 16, c = DIM * heads;
+  const float* qrow = qm + (int64_t)min(i0 + r16, n - 1) * c + h * DIM + 4 * q;
+  f32x4 qa[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qa[s] = *reinterpret_cast<const f32x4*>(qrow + 16 * s);
+  const float* kbase = km + h * DIM + 4 * q;     // + key * c + 16 s   (key = tile * 16 + r16)
+  const float* vbase = vm + h * DIM + 4 * r16;   // + key * c          (key = tile * 16 + 4 q + i)
+  const int ntile = (m + 15) >> 4;
+  f32x4 kb[4], vv[4], kn[4], vn[4];
+  auto load_tile = [&](int t, f32x4* kd, f32x4* vd) {
+    const float* krow = kbase + (int64_t)min(t * 16 + r16, m - 1) * c;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kd[s] = *reinterpret_cast<const f32x4*>(krow + 16 * s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      vd[i] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)min(t * 16 + 4 * q + i, m - 1) * c);
+  };
+  if (wave < ntile) load_tile(wave, kb, vv);
+  float mx = -__builtin_inff(), den = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = wave; t < ntile; t += 4) {
+    if (t + 4 < ntile) load_tile(t + 4, kn, vn);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[s][e], qa[s][e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[s][e + 1], qa[s][e + 1], acc1, 0, 0, 0);
+      }
+    }
+    float sc[4], tmx = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sc[i] = t * 16 + 4 * q + i < m ? (acc0[i] + acc1[i]) * scl : -__builtin_inff();
+      tmx = fmaxf(tmx, sc[i]);
+    }
+    tmx = fmaxf(tmx, __shfl_xor(tmx, 16));
+    tmx = fmaxf(tmx, __shfl_xor(tmx, 32));      // the tile holds at least one key: finite
+    const float mnew = fmaxf(mx, tmx);
+    const float f = expf(mx - mnew);            // 0 on the first tile
+    mx = mnew;
+    float p[4], ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      p[i] = expf(sc[i] - mnew);                // exp(-inf) = 0 for the keys past m
+      ps += p[i];
+    }
+    den = fmaf(den, f, ps);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) o[b] *= f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) o[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[i][b], p[i], o[b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kb[s] = kn[s];
+      vv[s] = vn[s];
+    }
+  }
+  den += __shfl_xor(den, 16);
+  den += __shfl_xor(den, 32);
+  if (q == 0) {
+    s_mx[wave][r16] = mx;
+    s_den[wave][r16] = den;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_o[wave][r16][4 * (4 * q + i) + b] = o[b][i];
+  }
+  __syncthreads();
+  // thread -> (query = tid / 16, d = tid % 16 + 16 j): waves that saw no tile carry den = 0
+  const int qi = threadIdx.x >> 4, d0 = threadIdx.x & 15;
+  if (i0 + qi < n) {
+    float M = -__builtin_inff();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, s_mx[w][qi]);
+    float fw[4], D = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      fw[w] = s_den[w][qi] > 0.f ? expf(s_mx[w][qi] - M) : 0.f;
+      D = fmaf(s_den[w][qi], fw[w], D);
+    }
+    const float inv = 1.f / D;
+    float* orow = out + (int64_t)(i0 + qi) * c + h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = d0 + 16 * j;
+      float N = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) N = fmaf(s_o[w][qi][d], fw[w], N);
+      orow[d * heads] = N * inv;
+    }
+  }
+}
+
 // y = clamp(sigmoid(x), 0, 1) with NaN / Inf -> 0   (architectures.py:131-134, 203-207)
 __global__ void k_score_head(const float* __restrict__ x, int64_t ldx, int64_t n, float* __restrict__ y) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -758,6 +878,20 @@ APR_API int apr_mha(const float* q, const float* k, const float* v, int32_t n, i
   const unsigned nqb = (unsigned)((n + kMhaQ - 1) / kMhaQ);
   hipLaunchKernelGGL(k_mha, dim3(nqb * (unsigned)heads), dim3(256), lds, (hipStream_t)stream, q, k, v, n, m, dim, heads,
                      out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// apr_mha with q / k / v HEAD-MAJOR (channel h * dim + d) and out interleaved (channel d * heads + h) as apr_mha writes
+// it: dim = 64 only (k_mha_mfma), rows 16-byte aligned; no limit on m.  Same value to fp32 summation order.
+APR_API int apr_mha_headmajor(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim,
+                              int32_t heads, float* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && heads > 0 && q && k && v && out, "apr_mha_headmajor: bad arguments");
+  APR_CHECK_ARG(dim == 64, "apr_mha_headmajor: head dimension %d not supported (64 only)", dim);
+  APR_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "apr_mha_headmajor: q, k, v must be 16-byte aligned");
+  const unsigned nqb = (unsigned)((n + 15) / 16);
+  hipLaunchKernelGGL(k_mha_mfma, dim3(nqb * (unsigned)heads), dim3(256), 0, (hipStream_t)stream, q, k, v, n, m, heads,
+                     1.f / sqrtf((float)dim), out);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -270,6 +270,18 @@ def mha(q, k, v, heads):
     return out
 
 
+MHA_MFMA = os.environ.get("APR_MHA", "mfma") != "scalar"      # A/B switch: the scalar kernel on interleaved channels
+
+
+def mha_headmajor(q, k, v, heads):
+    """`mha` with q / k / v head-major (channel h*dim + d); the result is in `mha`'s interleaved layout."""
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    n, c = q.shape
+    out = torch.empty_like(q)
+    check(_lib.load().apr_mha_headmajor(ptr(q), ptr(k), ptr(v), n, k.shape[0], c // heads, heads, ptr(out), stream()))
+    return out
+
+
 def softmax_matvec(a, b, w, temperature):
     a, w = a.contiguous(), w.contiguous().view(-1)
     out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)

@@ -30,6 +30,28 @@ class _Packed:
         return self.val
 
 
+class _PackedHeadMajor:
+    """The packed weight and the bias of a projection with its OUTPUT channels reordered from the reference's
+    interleaved head layout (c = d*heads + h, gcn.py:105-107) to head-major (c = h*dim + d): every output channel is
+    its own dot product, so the values are the same bits, only where they land changes -- and a head's 64 channels
+    become one contiguous 256-byte run for the attention kernel."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, conv, heads):
+        key = (_param_key(conv.weight), None if conv.bias is None else _param_key(conv.bias), heads)
+        if key != self.key:
+            cout = conv.weight.shape[0]
+            dim = cout // heads
+            perm = torch.arange(cout, device=conv.weight.device).view(dim, heads).t().reshape(-1)   # new h*dim+d <- d*heads+h
+            w = conv.weight.detach().reshape(cout, conv.weight.shape[1])[perm].t().contiguous()
+            bias = None if conv.bias is None else conv.bias.detach()[perm].contiguous()
+            self.val = (kp_ops.pack_linear(w), bias)
+            self.key = key
+        return self.val
+
+
 def conv1x1(x, conv, cache, relu=False):
     """Conv1d / Conv2d with kernel size 1 on rows: x [N,cin] -> [N,cout] (+ bias)."""
     if kp_ops.tracking(x, conv.weight, conv.bias):
@@ -94,8 +116,15 @@ class MultiHeadedAttention(nn.Module):
         self.merge = nn.Conv1d(d_model, d_model, kernel_size=1)
         self.proj = nn.ModuleList([deepcopy(self.merge) for _ in range(3)])
         self._c = [_Packed() for _ in range(4)]
+        self._hm = [_PackedHeadMajor() for _ in range(3)]
 
     def forward(self, query, key, value):
+        if self.dim == 64 and kp_ops.MHA_MFMA and not kp_ops.tracking(query, key, value, *self.parameters()):
+            # projections written head-major, attention on the fp32 MFMA, output back in the interleaved layout
+            packed = [c.get(l, self.num_heads) for l, c in zip(self.proj, self._hm)]
+            q, k, v = [kp_ops.linear(x, wp, shift=b) for x, (wp, b) in zip((query, key, value), packed)]
+            x = kp_ops.mha_headmajor(q, k, v, self.num_heads)
+            return conv1x1(x, self.merge, self._c[3])
         q, k, v = [conv1x1(x, l, c) for l, x, c in zip(self.proj, (query, key, value), self._c[:3])]
         if kp_ops.tracking(q, k, v):
             qh, kh, vh = (t.view(-1, self.dim, self.num_heads) for t in (q, k, v))      # channel c = d*heads + h

@@ -509,6 +509,12 @@ int apr_group_max(const float* y, int64_t ldy, int32_t n, int32_t k, int32_t c, 
 int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
             float* out, void* stream);
 
+/* apr_mha with q / k / v handed over HEAD-MAJOR (channel h*dim + d: the caller permutes the output channels of the
+ * three projections, gcn.py:101-108) and out in apr_mha's interleaved layout; fp32 MFMA, dim = 64 only, q / k / v
+ * 16-byte aligned, no limit on m. */
+int apr_mha_headmajor(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim,
+                      int32_t heads, float* out, void* stream);
+
 /* out[i] = sum_j softmax_j(<a_i, b_j> / temperature) * w[j]  (cross saliency, architectures.py:176-181). */
 int apr_softmax_matvec(const float* a, const float* b, const float* w, int32_t n, int32_t m, int32_t c,
                        float temperature, float* out, void* stream);

@@ -65,6 +65,19 @@ def test_pools_attention_pieces_match_oracle(dev):
     prob = torch.softmax(torch.einsum('ndh,mdh->hnm', qh, kh) / 8.0, dim=-1)
     ref = torch.einsum('hnm,mdh->ndh', prob, vh).reshape(333, 256)
     assert rel_l2(kp_ops.mha(q.to(dev), k.to(dev), v.to(dev), 4).cpu(), ref) < 1e-5
+    # the same on the fp32 MFMA with q / k / v head-major (channel h*64 + d), output interleaved; ragged sizes, fewer
+    # key tiles than waves, a single key, scores far from zero
+    hm = lambda t: t.view(-1, 64, 4).permute(0, 2, 1).reshape(t.shape[0], 256).contiguous()
+    for (nq, nk, gain) in ((333, 411, 1.0), (16, 16, 1.0), (1, 1, 1.0), (37, 5, 1.0), (50, 33, 1.0), (129, 1000, 6.0)):
+        qq = torch.from_numpy(rng.standard_normal((nq, 256)).astype(np.float32)) * gain
+        kk = torch.from_numpy(rng.standard_normal((nk, 256)).astype(np.float32))
+        vv = torch.from_numpy(rng.standard_normal((nk, 256)).astype(np.float32))
+        qh, kh, vh = (t.double().view(-1, 64, 4) for t in (qq, kk, vv))
+        prob = torch.softmax(torch.einsum('ndh,mdh->hnm', qh, kh) / 8.0, dim=-1)
+        ref = torch.einsum('hnm,mdh->ndh', prob, vh).reshape(nq, 256).float()
+        got = kp_ops.mha_headmajor(hm(qq).to(dev), hm(kk).to(dev), hm(vv).to(dev), 4).cpu()
+        assert rel_l2(got, ref) < 1e-5, (nq, nk, rel_l2(got, ref))
+        assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (nq, nk)
     a = torch.nn.functional.normalize(q, dim=1); b = torch.nn.functional.normalize(k, dim=1)
     w = torch.from_numpy(rng.standard_normal(411).astype(np.float32))
     ref = torch.softmax(a @ b.t() / 0.0367, dim=1) @ w
