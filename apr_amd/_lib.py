@@ -99,6 +99,7 @@ PROTOTYPES = {
     "apr_match_pose_batch_scratch_bytes": (_sz, [_i32, _i64, _i64, _i32, _i64]),
     "apr_match_pose_batch": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p]),
     "apr_match_pose_batch_slot_bytes": (_sz, [_i32]),
+    "apr_match_pose_set_lanes": (C.c_int, [_i32]),
     "apr_match_pose_batch_enqueue": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p]),
     "apr_match_pose_batch_finish": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _i64, _p, _sz, _p, _p, _p]),
     "apr_irls_scratch_bytes": (_sz, [_i64]),

@@ -20,7 +20,11 @@
 // sqrt(d2) < m is evaluated as d2 < T2 with T2 = the smallest double whose
 // correctly-rounded sqrt is >= m (found on the host): sqrt is monotone, so the two
 // predicates are identical for every d2, and no fp64 sqrt runs per point.
+#include <atomic>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "common.h"
 
@@ -1227,22 +1231,74 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+// The pairs of a batch are independent and most of their ~25 kernels are small (a 28 k-point pair: grids of a few
+// hundred workgroups, 5-60 us each), so run back to back on one stream they leave the card mostly idle.  The batch is
+// therefore dealt over `lanes` streams: lane 0 is the caller's stream, the others are library-owned streams forked from
+// it by an event and joined back before the result copy -- to the caller it is still ONE stream's worth of ordering.
+// Each lane has its own matching / RANSAC scratch (pairs of a lane reuse it in stream order).
+// OFF by default (APR_MATCH_LANES=1): it is a remedy for a caller with ONE stream in flight (6-pair FCGF step on one
+// stream: 1558 -> 1640 pairs/s with 3 lanes, 1718 with the host three steps ahead as well); a caller that already keeps
+// several steps in flight on its own streams has the card full, and more concurrent small kernels cost it throughput
+// (three streams: 2380 pairs/s with 1 lane, 2260 with 3; 2040 with 3 lanes and 8 hardware queues).
+constexpr int kMaxLanes = 4;
+
+std::atomic<int> g_match_lanes{0};      // 0 = not set: APR_MATCH_LANES, else 1
+
+int match_lanes(int32_t B) {
+  static const int s_env = env_int("APR_MATCH_LANES", 1);
+  const int set = g_match_lanes.load(std::memory_order_relaxed);
+  const int want = set > 0 ? set : s_env;
+  const int l = want < 1 ? 1 : (want > kMaxLanes ? kMaxLanes : want);
+  return B < l ? B : l;
+}
+
 struct BatchLayout {
-  size_t nn_scratch, best, ransac, slots, corr_each, total;
+  size_t nn_scratch, best, ransac, lane, slots, corr_each, total;   // lane = nn_scratch + best + ransac, once per lane
+  int lanes;
 };
 
 BatchLayout batch_layout(int32_t B, int64_t n0_max, int64_t n1_max, int32_t c, int64_t max_iter) {
   BatchLayout L;
+  L.lanes = match_lanes(B);
   L.nn_scratch = align256(apr_feature_nn_fast_scratch_bytes(n0_max, n1_max, c) + 256);
   L.best = align256((size_t)n0_max * 8);
   L.ransac = align256(ransac_core_bytes(n0_max, max_iter) + 256);
+  L.lane = L.nn_scratch + L.best + L.ransac;
   L.slots = align256((size_t)B * (sizeof(Hyp) + 64));
   L.corr_each = align256((size_t)n0_max * 8);
-  L.total = L.nn_scratch + L.best + L.ransac + L.slots + (size_t)B * L.corr_each + 512;
+  L.total = (size_t)L.lanes * L.lane + L.slots + (size_t)B * L.corr_each + 512;
   return L;
 }
 
+// Library-owned side streams, kMaxLanes - 1 per (device, caller stream), created on first use and kept for the life of
+// the process (a caller stream's side streams carry only work forked from it, so two caller streams never share one).
+struct SideStreams { hipStream_t s[kMaxLanes - 1]; };
+
+int side_streams(hipStream_t caller, SideStreams* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SideStreams> pools;
+  int dev = 0;
+  APR_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = pools.find({dev, caller});
+  if (it == pools.end()) {
+    SideStreams ss;
+    for (int i = 0; i < kMaxLanes - 1; ++i) APR_HIP(hipStreamCreateWithFlags(&ss.s[i], hipStreamNonBlocking));
+    it = pools.emplace(std::make_pair(dev, caller), ss).first;
+  }
+  *out = it->second;
+  return APR_OK;
+}
+
 }  // namespace
+
+// Streams the pairs of a batch are dealt over (1 .. 4; see match_lanes above).  Takes effect for the calls that follow:
+// set it before apr_match_pose_batch_scratch_bytes, whose answer depends on it.
+APR_API int apr_match_pose_set_lanes(int32_t lanes) {
+  APR_CHECK_ARG(lanes >= 1 && lanes <= kMaxLanes, "apr_match_pose_set_lanes: 1 .. %d lanes", kMaxLanes);
+  g_match_lanes.store(lanes, std::memory_order_relaxed);
+  return APR_OK;
+}
 
 APR_API size_t apr_match_pose_batch_scratch_bytes(int32_t B, int64_t n0_max, int64_t n1_max, int32_t c,
                                                   int64_t max_iter) {
@@ -1270,31 +1326,62 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
   const BatchLayout L = batch_layout(B, n0_max, n1_max, c, max_iter);
   APR_CHECK_ARG(scratch_bytes >= L.total, "apr_match_pose_batch: scratch too small");
   char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-  void* nn_scratch = p;                 p += L.nn_scratch;
-  uint64_t* best = (uint64_t*)p;        p += L.best;
-  void* ransac_scratch = p;             p += L.ransac;
+  char* lane_base = p;                  p += (size_t)L.lanes * L.lane;
   char* slots = p;                      p += L.slots;
   char* corr_base = p;
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const double thr_lt = sqrt_lt_threshold(max_dist);
   const bool fast_nn = (c == 32 || c == 64 || c == 128);
-  for (int i = 0; i < B; ++i) {
+  // fork: the side lanes start behind everything the caller has queued so far (the descriptors, the points)
+  hipStream_t lane_st[kMaxLanes] = {st};
+  hipEvent_t fork = nullptr;
+  if (L.lanes > 1) {
+    SideStreams ss;
+    const int rc = side_streams(st, &ss);
+    if (rc != APR_OK) return rc;
+    APR_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    APR_HIP(hipEventRecord(fork, st));
+    for (int l = 1; l < L.lanes; ++l) {
+      lane_st[l] = ss.s[l - 1];
+      APR_HIP(hipStreamWaitEvent(lane_st[l], fork, 0));
+    }
+  }
+  int rc = APR_OK;
+  for (int i = 0; i < B && rc == APR_OK; ++i) {
     const apr_pair_desc& d = pairs[i];
-    int rc = fast_nn ? apr_feature_nn_fast(d.f0, d.n0, d.f1, d.n1, c, best, nn_scratch, L.nn_scratch, stream)
-                     : apr_feature_nn(d.f0, d.n0, d.f1, d.n1, c, best, stream);
-    if (rc != APR_OK) return rc;
+    const int l = i % L.lanes;
+    hipStream_t ls = lane_st[l];
+    char* lp = lane_base + (size_t)l * L.lane;
+    void* nn_scratch = lp;
+    uint64_t* best = (uint64_t*)(lp + L.nn_scratch);
+    void* ransac_scratch = lp + L.nn_scratch + L.best;
+    rc = fast_nn ? apr_feature_nn_fast(d.f0, d.n0, d.f1, d.n1, c, best, nn_scratch, L.nn_scratch, ls)
+                 : apr_feature_nn(d.f0, d.n0, d.f1, d.n1, c, best, ls);
+    if (rc != APR_OK) break;
     int64_t* corr = (int64_t*)(corr_base + (size_t)i * L.corr_each);
-    rc = apr_nn_unpack(best, d.n0, corr, nullptr, stream);
-    if (rc != APR_OK) return rc;
+    rc = apr_nn_unpack(best, d.n0, corr, nullptr, ls);
+    if (rc != APR_OK) break;
     // single-round RANSAC into this pair's result slot
     RansacScratch r = carve_ransac(ransac_scratch, d.n0, max_iter);
     r.best = (Hyp*)(slots + (size_t)i * (sizeof(Hyp) + 64));
     r.total_valid = (long long*)((char*)r.best + sizeof(Hyp));
-    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2);
-    launch_pack(r, d.xyz0, d.xyz1, d.n1, corr, d.n0, st);
-    launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, st);
-    launch_scoring(r, d.n0, thr_lt, (int)cap, st);
+    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, ls, r.best, r.total_valid, r.maxn2);
+    launch_pack(r, d.xyz0, d.xyz1, d.n1, corr, d.n0, ls);
+    launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, ls);
+    launch_scoring(r, d.n0, thr_lt, (int)cap, ls);
   }
+  // join (also on an error above: whatever reached a side lane is ordered before the caller's next work)
+  if (L.lanes > 1) {
+    for (int l = 1; l < L.lanes; ++l) {
+      hipEvent_t join = nullptr;
+      APR_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+      APR_HIP(hipEventRecord(join, lane_st[l]));
+      APR_HIP(hipStreamWaitEvent(st, join, 0));
+      APR_HIP(hipEventDestroy(join));      // released by the runtime once it has completed
+    }
+    APR_HIP(hipEventDestroy(fork));
+  }
+  if (rc != APR_OK) return rc;
   APR_LAUNCH_CHECK();
   APR_HIP(hipMemcpyAsync(slots_host, slots, (size_t)B * (sizeof(Hyp) + 64), hipMemcpyDeviceToHost, st));
   return APR_OK;
@@ -1315,9 +1402,8 @@ APR_API int apr_match_pose_batch_finish(const apr_pair_desc* pairs, int32_t B, i
   const BatchLayout L = batch_layout(B, n0_max, n1_max, c, max_iter);
   APR_CHECK_ARG(scratch_bytes >= L.total, "apr_match_pose_batch: scratch too small");
   char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-  p += L.nn_scratch + L.best;
-  void* ransac_scratch = p;
-  p += L.ransac + L.slots;
+  void* ransac_scratch = p + L.nn_scratch + L.best;      // lane 0's
+  p += (size_t)L.lanes * L.lane + L.slots;
   char* corr_base = p;
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const size_t slot_bytes = sizeof(Hyp) + 64;

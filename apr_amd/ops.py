@@ -783,6 +783,11 @@ def match_pose_batch(feats0, feats1, pts0, pts1, max_dist, edge_ratio=0.9, max_i
     return out
 
 
+def set_match_lanes(lanes):
+    """Streams the pairs of a `match_pose_batch` are dealt over inside libapr_hip (apr_match_pose_set_lanes; 1 .. 4)."""
+    check(_lib_().apr_match_pose_set_lanes(int(lanes)))
+
+
 def match_pose_batch_async(feats0, feats1, pts0, pts1, max_dist, edge_ratio=0.9, max_iter=4000000, seeds=None):
     """`match_pose_batch` in two halves (apr_match_pose_batch_enqueue / _finish): everything is enqueued on the current
     stream, the B result slots travel to pinned host memory asynchronously -> PendingFetch whose finish() returns the

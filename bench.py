@@ -43,6 +43,15 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="pairs in flight per GPU: each on its own HIP stream + host thread (a 28 k-voxel pair "
                          "cannot fill 256 CUs alone, so independent pairs overlap)")
+    ap.add_argument("--depth", type=int, default=1,
+                    help="steps in flight PER STREAM: depth d puts d host workers (or scheduler slots) on every stream, so "
+                         "the next steps' kernels are already queued behind the running one and the stream never waits "
+                         "for the host between a step's device->host fetch and the following launch (--streams 1 "
+                         "--depth 3: one HIP stream, the host up to three steps ahead)")
+    ap.add_argument("--match-lanes", type=int, default=0,
+                    help="deal the pairs of a step's matching + RANSAC batch over this many streams forked from the "
+                         "step's stream inside libapr_hip (APR_MATCH_LANES; 0 = leave the library default, 1 lane).  Helps "
+                         "--streams 1 (1558 -> 1640 pairs/s with 3), costs throughput once several steps are in flight")
     ap.add_argument("--host", choices=["pipelined", "threads"], default="threads",
                     help="how the --streams steps in flight are driven: one Python thread per stream (default: the step's "
                          "host work is mostly inside library calls, which release the GIL, so three threads enqueue three "
@@ -463,6 +472,8 @@ def main():
             dist.init_process_group(backend)
 
     from apr_amd import ops, shard, synth
+    if args.match_lanes > 0:
+        ops.set_match_lanes(args.match_lanes)
     from apr_amd.fcgf.pipeline import PairRegistration
 
     model = build_model(args.model, args.n_out, dev)
@@ -523,8 +534,14 @@ def main():
     import threading
     if os.environ.get("APR_BENCH_SWITCH"):
         sys.setswitchinterval(float(os.environ["APR_BENCH_SWITCH"]))
-    nstreams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    nhip = max(1, args.streams)
+    depth = max(1, args.depth)
+    hip_streams = [torch.cuda.Stream(device=dev) for _ in range(nhip)]
+    # worker / slot w enqueues on stream w % nhip.  Workers that share a stream interleave their launches on it: every
+    # step's scratch comes from torch's per-stream caching allocator at call time (no cached workspaces, no static device
+    # state in libapr_hip), so FIFO order on the stream keeps a block's reuse behind its last reader.
+    nstreams = nhip * depth
+    streams = [hip_streams[w % nhip] for w in range(nstreams)]
     results = {}
     step_log = []      # (step, worker, host start, host end) of every step
     job = {"first": 0, "last": 0, "stop": False, "err": None, "next": 0, "stagger": 0.0}
@@ -582,7 +599,7 @@ def main():
             for i, r in res.items():
                 results[i] = r[-1]
             step_log.extend((i, 0, t, t) for i, t in done_at)
-            for st in streams:
+            for st in hip_streams:
                 st.synchronize()
             return
         job["first"], job["last"], job["next"] = first, last, first
@@ -670,7 +687,8 @@ def main():
                                f"per step share one batched encoder call (2x{B} frames), then NN + RANSAC per pair",
                    "encoder": args.model, "feature_dim": args.n_out, "points_per_frame": int(n_pts),
                    "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
-                   "pairs_per_step": B, "streams_per_gpu": nstreams,
+                   "pairs_per_step": B, "streams_per_gpu": nhip, "steps_in_flight_per_stream": depth,
+                   "match_lanes": args.match_lanes or int(os.environ.get("APR_MATCH_LANES", "1")),
                    "host": "one thread, steps resumed on fetch completion" if pipelined else f"{nstreams} threads",
                    "sharding": f"{world} ranks x independent pairs",
                    "host_enqueue_ms_per_step": (None if host_busy["s"] is None

@@ -363,6 +363,14 @@ int apr_match_pose_batch_finish(const apr_pair_desc* pairs, int32_t B, int32_t c
                                 int64_t max_iter, void* scratch, size_t scratch_bytes, const void* slots_host,
                                 double* results_host, void* stream);
 
+/* Deal the pairs of a batch over `lanes` streams (1 .. 4): lane 0 is the caller's stream, the others are library-owned
+ * streams forked from it by an event and joined back before the result copy, each with its own matching / RANSAC
+ * scratch - ordering as seen by the caller is unchanged, results are identical.  Default 1 (or APR_MATCH_LANES): a
+ * remedy for a caller with ONE step in flight; with several steps in flight on the caller's own streams the card is
+ * already full and more lanes cost throughput.  Set it before apr_match_pose_batch_scratch_bytes (whose answer
+ * depends on it) and not while batches are between _enqueue and _finish. */
+int apr_match_pose_set_lanes(int32_t lanes);
+
 /* Robust linearised 6-DoF pose (20 IRLS iterations), replaces
  * est_quad_linear_robust (FCGF_APR/util/transform_estimation.py:89-116).
  * pts0/pts1 f32[n,3] paired, weight f32[n] nullable; T_host f32[16]; syncs. */

@@ -282,6 +282,30 @@ def test_match_pose_batch_equals_per_pair_calls(dev):
         T, info = ops.ransac_pose(g(xyz0), g(xyz1), corr, 0.3, 0.9, iters, seed)
         assert info == ib and np.array_equal(T, Tb)
     assert batch[3][1]["n_valid"] == iters and batch[3][1]["inliers"] == 260
+    # the pairs dealt over 2 / 3 / 4 streams inside the library (fork / join around the caller's stream), 7 pairs so
+    # that lanes carry different numbers of them: the same bits as on one stream, and the caller's stream still orders
+    # what follows behind all of them (the features are overwritten right after the call)
+    seven = (cases + cases)[:7]
+    seeds7 = list(range(11, 18))
+    ref7 = None
+    try:
+        for lanes in (1, 2, 3, 4):
+            ops.set_match_lanes(lanes)
+            f0s, f1s = [g(c[2]) for c in seven], [g(c[3]) for c in seven]
+            pend = ops.match_pose_batch_async(f0s, f1s, [g(c[0]) for c in seven], [g(c[1]) for c in seven], 0.3, 0.9,
+                                              iters, seeds=seeds7)
+            for f in f0s + f1s:
+                f.zero_()                      # enqueued behind the join
+            pend.event.synchronize()
+            got = pend.finish()
+            if ref7 is None:
+                ref7 = got
+            for (Ta, ia), (Tb, ib) in zip(ref7, got):
+                assert ia == ib and np.array_equal(Ta, Tb), lanes
+        with pytest.raises(Exception):
+            ops.set_match_lanes(5)
+    finally:
+        ops.set_match_lanes(1)
 
 
 def test_batch_path_replays_overflow_at_full_reference_criteria(dev):
