@@ -65,6 +65,7 @@ class CoordinateManager:
         self._kmaps = {}
         self._plists = {}
         self._plist_counters = None
+        self._bbox = None
         self.device = self.maps[1].keys.device
 
     # -- coordinate maps -----------------------------------------------------
@@ -129,6 +130,17 @@ class CoordinateManager:
                                [s for s in (2 ** i for i in range(1, 12)) if s <= ts])
         self._finalize()
         return self.maps[ts]
+
+    def set_bbox(self, bbox):
+        """The 8 host ints of `ops.coords_bbox` over the stride-1 coordinates (or over the raw points they were
+        quantised from): handed over by a caller that fetched them with the map sizes, so `get_bbox` costs no sync."""
+        self._bbox = tuple(int(v) for v in bbox)
+
+    def get_bbox(self):
+        if self._bbox is None:
+            m = self.get_map(1)
+            self._bbox = tuple(ops.coords_bbox(m.coords[:m.n].contiguous()).tolist())      # synchronises
+        return self._bbox
 
     def get_coordinates(self, key):
         return self.get_map(key.stride if isinstance(key, CoordinateMapKey) else key).coords
@@ -196,6 +208,9 @@ class SparseTensor:
         device = torch.device(device)
         if device.type != "cuda":
             raise AprHipError("SparseTensor: device must be a GPU")
+        # the caller's promise that every feature is exactly 1.0 (FCGF's input, complement_data_loader.py:805-812):
+        # a first convolution with in_channels = 1 then runs on occupancy alone (ops.occ_conv); never inherited
+        self.unit_features = bool(unused.get("unit_features", False))
         self.F = features.to(device=device, dtype=torch.float32)
         if self.F.dim() != 2:
             raise AprHipError("SparseTensor: features must be [N, C]")
@@ -393,6 +408,24 @@ class _ConvBase(nn.Module):
                   relu=relu, out=out, n_out=n_out, plist=None if os_pairs is not None else plist,
                   w_bf3=self.packed_weight_bf3() if plist is not None else None, os_pairs=os_pairs)
 
+    def occ_ready(self, x: SparseTensor):
+        """True if this layer on this input is the occupancy special case (ops.occ_conv): constant-1 features, one input
+        channel, stride-1 same-level map.  APR_OCC_CONV=0 keeps the kernel-map path."""
+        import os
+        if not (getattr(x, "unit_features", False) and self.in_channels == 1 and not self.TRANSPOSE and self.stride == 1
+                and not self.use_mm and x.coordinate_map_key.stride == 1 and x.F.shape[1] == 1):
+            return False
+        if os.environ.get("APR_OCC_CONV", "1") == "0" or _tracking(x.F, self.kernel, self.bias):
+            return False
+        return ops.occ_conv_supported(x.coordinate_manager.get_bbox(), self.kernel_size, self.out_channels)
+
+    def run_occ(self, cm, n_out, scale=None, shift=None, relu=False, out=None):
+        if shift is None and self.bias is not None:
+            shift = self.bias.view(-1)
+        w = self.kernel.detach().reshape(self.kernel_volume, self.out_channels)
+        return ops.occ_conv(cm.get_map(1).coords, n_out, cm.get_bbox(), self.kernel_size, w, scale=scale, shift=shift,
+                            relu=relu, out=out)
+
     def _reverse_map(self, x: SparseTensor, nbr_fwd, ts_out):
         """Map of the input gradient: (table, mirrored offsets?)  (backward)."""
         ts = x.coordinate_map_key.stride
@@ -406,6 +439,9 @@ class _ConvBase(nn.Module):
     def forward(self, x: SparseTensor):
         if x.F.shape[1] != self.in_channels:
             raise AprHipError(f"conv expects {self.in_channels} input channels, got {x.F.shape[1]}")
+        if self.occ_ready(x):
+            cm = x.coordinate_manager
+            return x._like(self.run_occ(cm, cm.size(1)), CoordinateMapKey(1))
         nbr, ts_out = self._maps(x)
         if _tracking(x.F, self.kernel, self.bias):
             # training: forward + both gradients on the HIP kernels through autograd

@@ -1,0 +1,213 @@
+// The encoder's first convolution when the input feature is the constant 1 (FCGF's voxel features ARE ones:
+// FCGF_APR/lib/complement_data_loader.py:805-812 `feats = np.ones((len(coords), 1))`, model/resunet.py:57 conv1 with
+// in_channels = 1, kernel 5 or 7): out[j] = sum over the offsets k whose neighbour EXISTS of W[k, 0, :].  The values
+// gathered through a kernel map are all 1, so the map's row indices are never needed -- only the occupancy of the
+// ks^3 cells around every voxel.  The generic path builds a [n, ks^3] int32 neighbour table for it (189 k voxels x 125
+// offsets: 62 hash probes per voxel, 94 MB written, then read back by k_spconv_smallcin -- 190 us per 12-frame step,
+// the most expensive index structure of the encoder, used by this one layer); here the voxels are scattered into a
+// dense bitmap over the batch's bounding box (1 bit per cell, x along the bits of a word: 12 KITTI frames = 17 MB,
+// cleared by one memset) and a voxel reads its 5 x-neighbours of a (dy, dz) row with ONE 8-byte load: 25 loads instead
+// of 62 probes, no table.
+// Accumulation runs over k ascending with acc += W[k] (== fmaf(1, W[k], acc) of k_spconv_smallcin) and the epilogue is
+// the same expression: the same bits as the generic path on all-ones features.
+#include <climits>
+
+#include "common.h"
+
+namespace {
+
+struct OccGrid {
+  int minx, miny, minz;      // cell (x, y, z) lives at (x - minx, y - miny, z - minz); the box is padded by ks / 2
+  int dy, dz, wx;            // rows per slab, slabs per frame, 32-bit words per row (one spare word at the end)
+};
+
+__device__ inline int64_t occ_word(const OccGrid& g, int b, int x, int y, int z) {
+  return (((int64_t)b * g.dz + (z - g.minz)) * g.dy + (y - g.miny)) * g.wx + ((x - g.minx) >> 5);
+}
+
+__global__ void k_bbox_init(int* __restrict__ bbox) {
+  if (threadIdx.x < 3) bbox[threadIdx.x] = INT_MAX;
+  else if (threadIdx.x < 7) bbox[threadIdx.x] = INT_MIN;
+  else if (threadIdx.x == 7) bbox[7] = 0;
+}
+
+// bbox[0..2] = min x, y, z; bbox[3..5] = max x, y, z; bbox[6] = max batch index
+__global__ __launch_bounds__(256) void k_bbox(const int4* __restrict__ coords, int64_t n, int* __restrict__ bbox) {
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = coords[i];
+    lo[0] = min(lo[0], c.y); lo[1] = min(lo[1], c.z); lo[2] = min(lo[2], c.w);
+    hi[0] = max(hi[0], c.y); hi[1] = max(hi[1], c.z); hi[2] = max(hi[2], c.w); hi[3] = max(hi[3], c.x);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) lo[a] = min(lo[a], __shfl_xor(lo[a], d));
+#pragma unroll
+    for (int a = 0; a < 4; ++a) hi[a] = max(hi[a], __shfl_xor(hi[a], d));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) atomicMin(&bbox[a], lo[a]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) atomicMax(&bbox[3 + a], hi[a]);
+  }
+}
+
+__global__ void k_occ_set(const int4* __restrict__ coords, int n, OccGrid g, unsigned* __restrict__ bm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  atomicOr(&bm[occ_word(g, c.x, c.y, c.z, c.w)], 1u << ((c.y - g.minx) & 31));
+}
+
+// 64 voxels per workgroup, 4 threads per voxel.  Phase 1: the voxel's ks^2 (dy, dz) rows are dealt over its 4 threads;
+// a row's ks bits (dx = -h .. h) are bits sh .. sh + ks - 1 of the 64-bit window that starts at the word of x - h, and
+// land at offset index ks * ((dy + h) + ks * (dz + h)) of the voxel's occupancy mask in LDS.  Phase 2: thread (voxel,
+// channel group of 8) walks the set bits in ascending k.
+template <int KS>
+__global__ __launch_bounds__(256) void k_occ_conv(const int4* __restrict__ coords, int n, OccGrid g,
+                                                  const unsigned* __restrict__ bm, const float* __restrict__ w,
+                                                  int cout, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, const float* __restrict__ residual,
+                                                  int64_t ldr, int relu, float* __restrict__ out, int64_t ldo) {
+  constexpr int H = KS / 2, K = KS * KS * KS, MW = (K + 31) / 32;
+  __shared__ unsigned s_mask[64][MW + 1];
+  const int tid = threadIdx.x;
+  const int r = tid >> 2, cg = tid & 3;
+  const int row = blockIdx.x * 64 + r;
+  for (int t = tid; t < 64 * (MW + 1); t += 256) (&s_mask[0][0])[t] = 0u;
+  __syncthreads();
+  if (row < n) {
+    const int4 c = coords[row];
+    const int x0 = c.y - H - g.minx;                 // >= 0: the box is padded by H
+    const int sh = x0 & 31;
+    const unsigned* base = bm + occ_word(g, c.x, c.y - H, c.z, c.w);
+    for (int p = cg; p < KS * KS; p += 4) {
+      const int oy = p % KS - H, oz = p / KS - H;
+      const unsigned* q = base + ((int64_t)oz * g.dy + oy) * g.wx;
+      const unsigned long long win = (unsigned long long)q[0] | ((unsigned long long)q[1] << 32);
+      const unsigned bits = (unsigned)(win >> sh) & ((1u << KS) - 1u);
+      if (bits) {
+        const int k0 = KS * p;
+        atomicOr(&s_mask[r][k0 >> 5], bits << (k0 & 31));
+        if ((k0 & 31) + KS > 32) atomicOr(&s_mask[r][(k0 >> 5) + 1], bits >> (32 - (k0 & 31)));
+      }
+    }
+  }
+  __syncthreads();
+  if (row >= n) return;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int c0 = cg * 8; c0 < cout; c0 += 32) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) {
+      unsigned m = s_mask[r][mw];
+      while (m) {
+        const int k = mw * 32 + __ffs((int)m) - 1;
+        m &= m - 1;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + (int64_t)k * cout + c0);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + (int64_t)k * cout + c0 + 4);
+        acc[0] += w0[0]; acc[1] += w0[1]; acc[2] += w0[2]; acc[3] += w0[3];
+        acc[4] += w1[0]; acc[5] += w1[1]; acc[6] += w1[2]; acc[7] += w1[3];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;
+      float v = acc[i] * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+      if (residual) v += residual[(int64_t)row * ldr + c];
+      if (relu) v = fmaxf(v, 0.f);
+      out[(int64_t)row * ldo + c] = v;
+    }
+  }
+}
+
+struct OccLayout {
+  OccGrid g;
+  int64_t words;
+  bool ok;
+};
+
+OccLayout occ_layout(const int32_t* bbox, int32_t ks) {
+  OccLayout L;
+  L.ok = false;
+  L.words = 0;
+  const int h = ks / 2;
+  for (int a = 0; a < 3; ++a)
+    if (bbox[3 + a] < bbox[a]) return L;
+  if (bbox[6] < 0) return L;
+  const int64_t dx = (int64_t)bbox[3] - bbox[0] + 1 + 2 * h, dy = (int64_t)bbox[4] - bbox[1] + 1 + 2 * h,
+                dz = (int64_t)bbox[5] - bbox[2] + 1 + 2 * h;
+  const int64_t wx = (dx + 31) / 32 + 1;
+  const int64_t words = ((int64_t)bbox[6] + 1) * dz * dy * wx;
+  if (dx > (1 << 24) || dy > (1 << 24) || dz > (1 << 24) || words > (1ll << 29)) return L;      // 2 GB of bitmap at most
+  L.g.minx = bbox[0] - h;
+  L.g.miny = bbox[1] - h;
+  L.g.minz = bbox[2] - h;
+  L.g.dy = (int)dy;
+  L.g.dz = (int)dz;
+  L.g.wx = (int)wx;
+  L.words = words;
+  L.ok = true;
+  return L;
+}
+
+}  // namespace
+
+// bbox_dev int32[8] <- {min x, y, z, max x, y, z, max batch index, 0} of coords int32[n, 4] (batch, x, y, z)
+APR_API int apr_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox_dev, void* stream) {
+  APR_CHECK_ARG(n >= 0 && bbox_dev && (n == 0 || coords), "apr_coords_bbox: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, st, bbox_dev);
+  if (n > 0) {
+    int64_t nblk = cdiv64(n, 256 * 4);
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(k_bbox, dim3((unsigned)nblk), dim3(256), 0, st, (const int4*)coords, n, bbox_dev);
+  }
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// Bytes of the occupancy bitmap for the box bbox_host (the 8 ints of apr_coords_bbox) and an odd kernel size; 0 = the
+// box is empty or unreasonably large (the caller takes the kernel-map path).
+APR_API size_t apr_occ_conv_scratch_bytes(const int32_t* bbox_host, int32_t kernel_size) {
+  if (!bbox_host || kernel_size < 1 || !(kernel_size & 1)) return 0;
+  const OccLayout L = occ_layout(bbox_host, kernel_size);
+  return L.ok ? (size_t)L.words * 4 + 256 : 0;
+}
+
+// out[j, :] = act((sum_{k : cell(coords[j] + offset_k) occupied} w[k, :]) * scale + shift (+ residual[j, :])):
+// a stride-1, dilation-1, ks^3 sparse convolution of the constant-1 feature over the voxels `coords` (unique rows;
+// offsets x-fastest as apr_kernel_map), w f32[ks^3, cout] (the reference's [K, 1, cout] kernel), cout % 8 == 0,
+// ks in {3, 5, 7}.  Every voxel must lie inside bbox_host (apr_coords_bbox of the same rows or a superset).
+APR_API int apr_occ_conv(const int32_t* coords, int64_t n, const int32_t* bbox_host, int32_t kernel_size,
+                         const float* w, int32_t cout, const float* scale, const float* shift, const float* residual,
+                         int64_t ldr, int32_t relu, float* out, int64_t ldo, void* scratch, size_t scratch_bytes,
+                         void* stream) {
+  APR_CHECK_ARG(n >= 0 && n < (1ll << 31) && bbox_host && w && out && scratch, "apr_occ_conv: bad arguments");
+  APR_CHECK_ARG(kernel_size == 3 || kernel_size == 5 || kernel_size == 7, "apr_occ_conv: kernel_size %d, supported: 3, 5, 7",
+                kernel_size);
+  APR_CHECK_ARG(cout > 0 && cout % 8 == 0 && ldo >= cout && (!residual || ldr >= cout), "apr_occ_conv: cout %% 8 != 0 or short rows");
+  APR_CHECK_ARG((((uintptr_t)w) & 15) == 0, "apr_occ_conv: weights must be 16-byte aligned");
+  if (n == 0) return APR_OK;
+  const OccLayout L = occ_layout(bbox_host, kernel_size);
+  APR_CHECK_ARG(L.ok, "apr_occ_conv: empty or oversized bounding box");
+  APR_CHECK_ARG(scratch_bytes >= (size_t)L.words * 4 + 256, "apr_occ_conv: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* bm = (unsigned*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  APR_HIP(hipMemsetAsync(bm, 0, (size_t)L.words * 4, st));
+  hipLaunchKernelGGL(k_occ_set, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (const int4*)coords, (int)n, L.g, bm);
+  const dim3 grid((unsigned)cdiv64(n, 64));
+  if (kernel_size == 3)
+    hipLaunchKernelGGL(k_occ_conv<3>, grid, dim3(256), 0, st, (const int4*)coords, (int)n, L.g, bm, w, cout, scale, shift,
+                       residual, ldr, relu, out, ldo);
+  else if (kernel_size == 5)
+    hipLaunchKernelGGL(k_occ_conv<5>, grid, dim3(256), 0, st, (const int4*)coords, (int)n, L.g, bm, w, cout, scale, shift,
+                       residual, ldr, relu, out, ldo);
+  else
+    hipLaunchKernelGGL(k_occ_conv<7>, grid, dim3(256), 0, st, (const int4*)coords, (int)n, L.g, bm, w, cout, scale, shift,
+                       residual, ldr, relu, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}

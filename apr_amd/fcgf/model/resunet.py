@@ -179,8 +179,12 @@ class ResUNet2(ME.MinkowskiNetwork):
             """conv -> folded BN -> residual block; cmap / bmap = (ts_in, ts_out, kernel, transpose)."""
             conv, norm, blk = getattr(self, "conv" + name), getattr(self, "norm" + name), getattr(self, "block" + name)
             sc, sh = norm.folded()
-            a = conv.run(feats, cm.kernel_map(*cmap), n_out, scale=sc, shift=sh, batch=batch,
-                         plist=cm.pair_list(*cmap) if "conv" + name in ws else None)
+            if name == "1" and conv.occ_ready(x):
+                # constant-1 input: conv1 on occupancy alone -- its 5^3 kernel map is never built (ops.occ_conv)
+                a = conv.run_occ(cm, n_out, scale=sc, shift=sh)
+            else:
+                a = conv.run(feats, cm.kernel_map(*cmap), n_out, scale=sc, shift=sh, batch=batch,
+                             plist=cm.pair_list(*cmap) if "conv" + name in ws else None)
             bl = None
             # 64 input channels only: at 128 the kernel exists and is tested but loses to the weight-stationary pair
             # on every level (12 frames per call: 494 vs 444 us at 189 k rows, 79 vs 69 us at 26 k)

@@ -50,7 +50,7 @@ class PairRegistration:
     @torch.no_grad()
     def encode_pair(self, coords, n0):
         feats = torch.ones((coords.shape[0], 1), dtype=torch.float32, device=coords.device)
-        out = self.model(ME.SparseTensor(feats, coordinates=coords)).F
+        out = self.model(ME.SparseTensor(feats, coordinates=coords, unit_features=True)).F
         return out[:n0], out[n0:]
 
     @torch.no_grad()
@@ -72,8 +72,10 @@ class PairRegistration:
         coords_all = ops.voxelize_segments(xyz_all, self.voxel_size, offs_dev)         # one launch for all frames
         m = ops.build_map(coords_all, want_first=True)
         counts_dev = ops.segment_counts(m, offs_dev)
+        bbox_dev = ops.coords_bbox(coords_all)         # for conv1 on occupancy (ops.occ_conv); fetched with the sizes
         cm = ME.CoordinateManager(base_map=m)
-        (counts,) = cm.build_pyramid([2, 4, 8], extras=[counts_dev])
+        counts, bbox = cm.build_pyramid([2, 4, 8], extras=[counts_dev, bbox_dev])
+        cm.set_bbox(bbox)
         # representative point of every voxel row: ONE gather over the concatenated points (frame b = rows
         # sum(counts[:b]) .. + counts[b], contiguous)
         pts_all = xyz_all[m.first]
@@ -99,10 +101,12 @@ class PairRegistration:
         coords_all = ops.voxelize_segments(xyz_all, self.voxel_size, offs_dev)
         m = ops.build_map(coords_all, want_first=True)
         counts_dev = ops.segment_counts(m, offs_dev)
+        bbox_dev = ops.coords_bbox(coords_all)         # for conv1 on occupancy (ops.occ_conv); fetched with the sizes
         cm = ME.CoordinateManager(base_map=m)
-        pending = cm.build_pyramid_async([2, 4, 8], extras=[counts_dev])
+        pending = cm.build_pyramid_async([2, 4, 8], extras=[counts_dev, bbox_dev])
         yield pending
-        (counts,) = pending.finish()
+        counts, bbox = pending.finish()
+        cm.set_bbox(bbox)
         counts = [int(c) for c in counts]
         pts_all = xyz_all[m.first]
         F = self.encode_batch(cm)
@@ -127,7 +131,8 @@ class PairRegistration:
     def encode_batch(self, cm):
         n = cm.size(1)
         feats = torch.ones((n, 1), dtype=torch.float32, device=cm.device)
-        return self.model(ME.SparseTensor(feats, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm)).F
+        return self.model(ME.SparseTensor(feats, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm,
+                                          unit_features=True)).F
 
     @torch.no_grad()
     def register_batch(self, pairs, seeds=None):

@@ -783,6 +783,48 @@ def match_pose_batch(feats0, feats1, pts0, pts1, max_dist, edge_ratio=0.9, max_i
     return out
 
 
+def coords_bbox(coords):
+    """int32 [n, 4] (batch, x, y, z) -> device int32 [8]: min x, y, z, max x, y, z, max batch index, 0 (no sync)."""
+    if coords.dtype != torch.int32 or coords.dim() != 2 or coords.shape[1] != 4 or not coords.is_contiguous():
+        raise _lib.AprHipError("coords_bbox: coords must be contiguous int32 [n, 4]")
+    bbox = torch.empty(8, dtype=torch.int32, device=coords.device)
+    check(_lib_().apr_coords_bbox(ptr(coords), coords.shape[0], ptr(bbox), stream()))
+    return bbox
+
+
+def occ_conv_supported(bbox, kernel_size, cout):
+    """True if `occ_conv` takes this case (odd kernel 3 / 5 / 7, cout % 8 == 0, a box whose bitmap stays under 2 GB)."""
+    if bbox is None or kernel_size not in (3, 5, 7) or cout % 8 != 0:
+        return False
+    box = (C.c_int32 * 8)(*[int(v) for v in bbox])
+    return int(_lib_().apr_occ_conv_scratch_bytes(box, int(kernel_size))) > 0
+
+
+def occ_conv(coords, n, bbox, kernel_size, w, scale=None, shift=None, relu=False, residual=None, out=None):
+    """Stride-1 ks^3 convolution of the constant-1 feature over the voxels coords[:n] (apr_occ_conv): w f32 [ks^3, cout];
+    bbox: the 8 host ints of `coords_bbox` for these rows (or a superset).  Same bits as `spconv` over the kernel map on
+    all-ones features."""
+    lib = _lib_()
+    w = _f32(w, "occ_conv.w").contiguous()
+    K, cout = w.shape
+    if K != kernel_size ** 3:
+        raise _lib.AprHipError("occ_conv: w must be [kernel_size^3, cout]")
+    box = (C.c_int32 * 8)(*[int(v) for v in bbox])
+    sb = int(lib.apr_occ_conv_scratch_bytes(box, int(kernel_size)))
+    if sb == 0:
+        raise _lib.AprHipError("occ_conv: empty or oversized bounding box (use occ_conv_supported)")
+    if out is None:
+        out = torch.empty((n, cout), dtype=torch.float32, device=coords.device)
+    out, ldo = _rows(out, "occ_conv.out")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "occ_conv.residual")
+    scratch = torch.empty(sb, dtype=torch.uint8, device=coords.device)
+    check(lib.apr_occ_conv(ptr(coords), int(n), box, int(kernel_size), ptr(w), cout, ptr(scale), ptr(shift), ptr(residual),
+                           ldr, int(bool(relu)), ptr(out), ldo, ptr(scratch), sb, stream()))
+    return out
+
+
 def set_match_lanes(lanes):
     """Streams the pairs of a `match_pose_batch` are dealt over inside libapr_hip (apr_match_pose_set_lanes; 1 .. 4)."""
     check(_lib_().apr_match_pose_set_lanes(int(lanes)))

@@ -115,6 +115,22 @@ int apr_kernel_map(const int32_t* out_coords, int64_t n_out, const int32_t* n_ou
                    const uint64_t* in_keys, const int32_t* in_vals, int64_t cap,
                    int32_t kernel_size, int32_t scale, int32_t* nbr, void* stream);
 
+/* ---- first convolution on constant-1 features (occ.hip) --------------------------------------------------------
+ * FCGF feeds the encoder `feats = ones((n, 1))` (FCGF_APR/lib/complement_data_loader.py:805-812) into conv1 with
+ * in_channels = 1 and a 5^3 / 7^3 kernel (FCGF_APR/model/resunet.py:57-63): every gathered value is 1, so the layer is
+ *   out[j, :] = act((sum over the offsets k whose cell around voxel j is occupied of w[k, :]) * scale + shift)
+ * and needs occupancy, not a neighbour table.  apr_coords_bbox: bbox_dev int32[8] <- {min x, y, z, max x, y, z, max
+ * batch index, 0} of coords int32[n,4] (batch, x, y, z).  apr_occ_conv: the voxels are scattered into a bitmap over
+ * that box (scratch: apr_occ_conv_scratch_bytes(bbox, ks), 0 = box empty / too large -> use apr_kernel_map +
+ * apr_spconv) and every voxel reads the ks x-neighbours of a (dy, dz) row with one 8-byte load.  coords: unique rows,
+ * all inside bbox_host; offsets x-fastest as apr_kernel_map; w f32[ks^3, cout], cout % 8 == 0, ks in {3, 5, 7}; same
+ * bits as apr_spconv over the apr_kernel_map table on all-ones features. */
+int apr_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox_dev, void* stream);
+size_t apr_occ_conv_scratch_bytes(const int32_t* bbox_host, int32_t kernel_size);
+int apr_occ_conv(const int32_t* coords, int64_t n, const int32_t* bbox_host, int32_t kernel_size, const float* w,
+                 int32_t cout, const float* scale, const float* shift, const float* residual, int64_t ldr,
+                 int32_t relu, float* out, int64_t ldo, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Sparse convolution forward (gather -> MFMA -> fused epilogue), fp32.
  *   out[j, :] = act( (sum_o in[nbr[j,o], :] @ W[o]) * scale + shift + residual[j, :] )

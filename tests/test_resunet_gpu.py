@@ -49,6 +49,33 @@ def test_eval_modular_matches_fused_and_oracle(dev):
     assert rel_l2(out_f.F.cpu(), out_m.F.cpu()) < TOL
 
 
+@pytest.mark.parametrize("name,n_out,fused", [("ResUNetBN2C", 32, True), ("ResUNetBN2C", 32, False),
+                                               ("ResUNetFatBN", 128, True)])
+def test_unit_feature_input_runs_conv1_on_occupancy_with_the_same_bits(dev, name, n_out, fused, monkeypatch):
+    """FCGF's input features are ones: flagged `unit_features`, conv1 runs from the occupancy bitmap (no 5^3 kernel
+    map is built) and the encoder's output is bit-identical to the kernel-map path and within the bar of the oracle."""
+    om, hm = model_pair(name, n_out)
+    om.eval(); hm.eval()
+    hm.use_fused = fused
+    C, F = batched_input([5, 6])
+    assert np.all(F == 1.0) and F.shape[1] == 1
+    Cd, Fd = torch.from_numpy(C).to(dev), torch.from_numpy(F).to(dev)
+    with torch.no_grad():
+        ref = om(OME.SparseTensor(F, coordinates=C)).F
+        plain = hm(ME.SparseTensor(Fd, coordinates=Cd))
+        x = ME.SparseTensor(Fd, coordinates=Cd, unit_features=True)
+        occ = hm(x)
+        k1 = hm.conv1.kernel_size
+        assert (1, 1, k1, False) in plain.coordinate_manager._kmaps
+        assert (1, 1, k1, False) not in x.coordinate_manager._kmaps         # the table was never needed
+        assert not occ.unit_features                                         # never inherited by outputs
+        monkeypatch.setenv("APR_OCC_CONV", "0")
+        off = hm(ME.SparseTensor(Fd, coordinates=Cd, unit_features=True))
+        assert (1, 1, k1, False) in off.coordinate_manager._kmaps
+    assert torch.equal(occ.F, plain.F) and torch.equal(off.F, plain.F)
+    assert rel_l2(occ.F.cpu(), ref) < TOL
+
+
 def test_batched_equals_separate(dev):
     """Encoding two clouds in one batch == encoding them one by one (eval BN), as the eval script does."""
     om, hm = model_pair("ResUNetBN2C", 32)

@@ -305,3 +305,64 @@ def test_output_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
         again = ops.spconv_os(xd, ops.build_os_pairs(nbr_d, n_in, rows), cin, cout, w3, scale=scale.to(dev),
                               shift=shift.to(dev), residual=resd, relu=True)
         assert torch.equal(again, out)
+
+
+def _clustered_coords(rng, n, nbatch, lo, hi, spread):
+    """Unique int32 (batch, x, y, z) rows: blobs with plenty of occupied neighbour cells, some isolated voxels, the box
+    corners occupied (the bitmap's padding is exercised), negative coordinates."""
+    pts = []
+    for b in range(nbatch):
+        centres = rng.integers(lo + spread, hi - spread, size=(6, 3))
+        c = centres[rng.integers(0, 6, n)] + np.rint(rng.standard_normal((n, 3)) * spread / 3).astype(np.int64)
+        c = np.clip(c, lo, hi)
+        far = rng.integers(lo, hi + 1, size=(n // 10, 3))
+        corners = np.array([[lo, lo, lo], [hi, hi, hi], [lo, hi, lo], [hi, lo, hi]])
+        xyz = np.concatenate([c, far, corners])
+        pts.append(np.concatenate([np.full((len(xyz), 1), b), xyz], 1))
+    coords = np.unique(np.concatenate(pts), axis=0)
+    return coords[rng.permutation(len(coords))].astype(np.int32)
+
+
+@pytest.mark.parametrize("ks,cout,n,nbatch,lo,hi,spread", [
+    (5, 32, 4000, 3, -40, 55, 6), (3, 32, 3000, 2, -20, 20, 4), (7, 32, 1500, 2, -25, 30, 5), (5, 8, 500, 1, 0, 31, 3),
+    (5, 40, 2500, 4, -100, -36, 5), (5, 32, 60000, 2, -160, 160, 30), (5, 64, 1, 1, 7, 7, 0),
+])
+def test_occupancy_conv_equals_kernel_map_path(dev, ks, cout, n, nbatch, lo, hi, spread):
+    """conv1 on constant-1 features from the occupancy bitmap (apr_occ_conv) == the kernel-map path (apr_kernel_map_same
+    + k_spconv_smallcin) bit for bit, and == the fp64 oracle; epilogue (scale, shift, ReLU) and a strided output slice
+    included; the bounding box comes from apr_coords_bbox."""
+    rng = np.random.default_rng(ks * 100 + cout + n)
+    if n == 1:
+        coords = np.array([[0, 7, 7, 7]], dtype=np.int32)
+    else:
+        coords = _clustered_coords(rng, n, nbatch, lo, hi, spread)
+    N, K = len(coords), ks ** 3
+    cd = torch.from_numpy(coords).to(dev)
+    bbox = ops.coords_bbox(cd).tolist()
+    assert bbox[:7] == [int(coords[:, 1].min()), int(coords[:, 2].min()), int(coords[:, 3].min()),
+                        int(coords[:, 1].max()), int(coords[:, 2].max()), int(coords[:, 3].max()), int(coords[:, 0].max())]
+    assert ops.occ_conv_supported(bbox, ks, cout)
+    W = torch.from_numpy((rng.standard_normal((K, 1, cout)) / np.sqrt(K / 4)).astype(np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    m = ops.build_map(cd)
+    ops.finalize_maps([m])
+    assert m.n == N
+    nbr = ops.kernel_map(m, m, ks, 1)
+    ones = torch.ones((N, 1), dtype=torch.float32, device=dev)
+    wp = ops.pack_weights(W.to(dev))
+    for sc, sh, relu in ((None, None, False), (scale, shift, True)):
+        scd, shd = (None if t is None else t.to(dev) for t in (sc, sh))
+        ref = ops.spconv(ones, nbr, K, 1, cout, wp, scale=scd, shift=shd, relu=relu, n_out=N)
+        buf = torch.full((N, cout + 8), -7.0, dtype=torch.float32, device=dev)
+        got = ops.occ_conv(m.coords, N, bbox, ks, W.view(K, cout).to(dev), scale=scd, shift=shd, relu=relu, out=buf[:, 4:4 + cout])
+        assert torch.equal(got, ref)
+        assert bool((buf[:, :4] == -7.0).all()) and bool((buf[:, 4 + cout:] == -7.0).all())
+        orc = _oracle_conv(torch.ones(N, 1), nbr.cpu().numpy(), W, sc, sh, relu=relu)
+        assert rel_l2(got.cpu(), orc) < 2e-6
+    # a superset box (the raw points' box in the pipeline) gives the same result
+    big = [bbox[0] - 3, bbox[1] - 40, bbox[2], bbox[3] + 37, bbox[4], bbox[5] + 2, bbox[6] + 1, 0]
+    assert torch.equal(ops.occ_conv(m.coords, N, big, ks, W.view(K, cout).to(dev)), ops.spconv(ones, nbr, K, 1, cout, wp, n_out=N))
+    # a box that would need more than 2 GB of bitmap is declined (the caller keeps the kernel-map path)
+    assert not ops.occ_conv_supported([0, 0, 0, 1 << 20, 1 << 20, 64, 0, 0], ks, cout)
+    assert not ops.occ_conv_supported(bbox, ks, cout + 1)
