@@ -685,7 +685,12 @@ __global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restric
 }
 
 // also clears the norm bound of k_pack_pairs and the pick header of the scoring kernels (zero3[0..2]; NULL: nothing)
-__global__ void k_init_best(Hyp* best, long long* total_valid, unsigned* zero3) {
+// `counters` (nullable): the n_valid .. n_cand words that launch_hypotheses would otherwise clear with a memset node of
+// its own -- the single-round callers hand them over here (one launch less per pair)
+__global__ void k_init_best(Hyp* best, long long* total_valid, unsigned* zero3, int* counters, int n_counters) {
+  if (counters)
+    for (int i = threadIdx.x; i < n_counters; i += blockDim.x) counters[i] = 0;
+  if (threadIdx.x != 0) return;
 #pragma unroll
   for (int k = 0; k < 12; ++k) best->T[k] = (k % 5 == 0) ? 1.0 : 0.0;  // identity (open3d's default result)
   best->it = -1;
@@ -1066,11 +1071,13 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
 }
 
 // sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
+static int counter_words(const RansacScratch& r) { return (int)((r.n_cand + kCandLists) - r.n_valid); }
+
 static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dist, double edge_ratio, int64_t it0,
-                              int64_t it1, uint64_t seed, int cap, hipStream_t st) {
+                              int64_t it1, uint64_t seed, int cap, hipStream_t st, bool counters_cleared = false) {
   const int64_t nwg = cdiv64(it1 - it0, 256);
   const int sub_cap = (int)(cdiv64(nwg, kCandLists) * 256);
-  (void)hipMemsetAsync(r.n_valid, 0, (size_t)((char*)(r.n_cand + kCandLists) - (char*)r.n_valid), st);
+  if (!counters_cleared) (void)hipMemsetAsync(r.n_valid, 0, (size_t)counter_words(r) * 4, st);
   hipLaunchKernelGGL(k_sample_check, dim3((unsigned)nwg), dim3(256), 0, st, r.rec, (uint32_t)n0, edge_ratio,
                      (long long)it0, (long long)it1, seed, r.cand, r.n_cand, sub_cap);
   hipLaunchKernelGGL(k_fit_check, dim3(512), dim3(256), 0, st, r.rec, (uint32_t)n0, sqrt_gt_threshold(max_dist), seed,
@@ -1118,7 +1125,7 @@ int geometric_enqueue(const float* xyz0, int64_t n0, const float* xyz1, int64_t 
   AprSearchGrid g;
   int rc = apr_internal_search_grid(xyz1, n1, (float)(2.0 * max_dist), grid_scratch, &g, st);
   if (rc != APR_OK) return rc;
-  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2);
+  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2, (int*)nullptr, 0);
   launch_pack(r, xyz0, xyz1, n1, corr, n0, st);
   launch_hypotheses(r, n0, max_dist, edge_ratio, 0, max_iter, seed, (int)cap, st);
   hipLaunchKernelGGL(k_rank_by_iteration, dim3((unsigned)cdiv64(cap, 256)), dim3(256), 0, st, r.hyps, r.n_valid,
@@ -1198,7 +1205,7 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const RansacScratch r = carve_ransac(scratch, n0, max_iter);
   const double thr_lt = sqrt_lt_threshold(max_dist);
-  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2);   // clears the norm bound + pick header
+  hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, r.maxn2, (int*)nullptr, 0);   // clears the norm bound + pick header
   launch_pack(r, xyz0, xyz1, n1, corr, n0, st);
   // Fast path: ALL iterations in one round.  The hypothesis list holds kChunk entries; only if more than that
   // survive both checkers (near-perfect correspondences) the rounds are replayed kChunk iterations at a time,
@@ -1206,7 +1213,7 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
   const int s_force_rounds = env_int("APR_RANSAC_FORCE_ROUNDS", 0);   // test hook (read per call): skip the fast path
   for (int pass = s_force_rounds ? 1 : 0; pass < 2; ++pass) {
     const int64_t step = pass == 0 ? max_iter : cap;
-    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, (unsigned*)nullptr);
+    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, (unsigned*)nullptr, (int*)nullptr, 0);
     for (int64_t it0 = 0; it0 < max_iter; it0 += step) {
       const int64_t it1 = (it0 + step < max_iter) ? it0 + step : max_iter;
       launch_hypotheses(r, n0, max_dist, edge_ratio, it0, it1, seed, (int)cap, st);
@@ -1365,9 +1372,9 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
     RansacScratch r = carve_ransac(ransac_scratch, d.n0, max_iter);
     r.best = (Hyp*)(slots + (size_t)i * (sizeof(Hyp) + 64));
     r.total_valid = (long long*)((char*)r.best + sizeof(Hyp));
-    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, ls, r.best, r.total_valid, r.maxn2);
+    hipLaunchKernelGGL(k_init_best, dim3(1), dim3(128), 0, ls, r.best, r.total_valid, r.maxn2, r.n_valid, counter_words(r));
     launch_pack(r, d.xyz0, d.xyz1, d.n1, corr, d.n0, ls);
-    launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, ls);
+    launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, ls, true);
     launch_scoring(r, d.n0, thr_lt, (int)cap, ls);
   }
   // join (also on an error above: whatever reached a side lane is ordered before the caller's next work)

@@ -12,6 +12,8 @@ pairs = [("bench.json", f"{prefix}_bench.json"), ("bench_s1.json", f"{prefix}_be
          ("pmc_spconv_summary.json", f"{prefix}_pmc_spconv_summary.json"),
          ("pred_stats/p_kernel_stats.csv", f"{prefix}_predator_kernel_stats.csv"),
          ("predator_profile.log", f"{prefix}_predator_host_profile.log")]
+pairs += [("bench_s1_plain.json", f"{prefix}_bench_streams1_plain.json"),
+          ("bench_s1_d3_l3.json", f"{prefix}_bench_streams1_depth3_lanes3.json")]
 pairs += [(f"driver_cmd_{i}.json", f"{prefix}_driver_cmd_{i}.json") for i in (1, 2, 3)]
 pairs += [(f"driver_cmd_{i}.log", f"{prefix}_driver_cmd_{i}.log") for i in (1, 2, 3)]
 for a, b in pairs:

@@ -16,6 +16,9 @@ for i in 1 2 3; do
 done
 echo "[profile] default bench"
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err </dev/null || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
+echo "[profile] one stream: plain, and with the host three steps ahead + the matching batch on three lanes"
+python3 $R/bench.py --streams 1 --steps 120 --no-cpu-baseline --no-roofline --no-workloads > $OUT/bench_s1_plain.json 2> $OUT/bench_s1_plain.err </dev/null || { echo "s1 plain failed"; exit 1; }
+python3 $R/bench.py --streams 1 --depth 3 --match-lanes 3 --steps 120 --no-cpu-baseline --no-roofline --no-workloads > $OUT/bench_s1_d3_l3.json 2> $OUT/bench_s1_d3_l3.err </dev/null || { echo "s1 depth 3 lanes 3 failed"; exit 1; }
 echo "[profile] rocprof stats, default run"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $R/bench.py --no-cpu-baseline --no-workloads > $OUT/bench_prof.json 2> $OUT/bench_prof.err </dev/null || { echo "rocprof default failed"; exit 1; }
 echo "[profile] rocprof stats, single stream"
