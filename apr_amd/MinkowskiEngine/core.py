@@ -397,16 +397,20 @@ class _ConvBase(nn.Module):
         return cm.kernel_map(ts, ts_out, self.kernel_size, self.stride != 1), ts_out
 
     def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None, batch=None,
-            plist=None):
-        """Raw fused launch on feature rows (used by the fused encoder plan); `batch` defers the launch."""
+            plist=None, l2norm=False):
+        """Raw fused launch on feature rows (used by the fused encoder plan); `batch` defers the launch; `l2norm`
+        (batched launches only): rows of the result divided by their 2-norm in the same launch."""
         if shift is None and self.bias is not None:
             shift = self.bias.view(-1)
         fn = ops.spconv if batch is None else batch.add
         os_pairs = plist if isinstance(plist, ops.OsPairs) else None     # output-stationary tile lists
+        kw = {"l2norm": True} if l2norm else {}
+        if l2norm and batch is None:
+            raise AprHipError("conv.run(l2norm=True) needs a SpconvBatch")
         return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
                   self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
                   relu=relu, out=out, n_out=n_out, plist=None if os_pairs is not None else plist,
-                  w_bf3=self.packed_weight_bf3() if plist is not None else None, os_pairs=os_pairs)
+                  w_bf3=self.packed_weight_bf3() if plist is not None else None, os_pairs=os_pairs, **kw)
 
     def occ_ready(self, x: SparseTensor):
         """True if this layer on this input is the occupancy special case (ops.occ_conv): constant-1 features, one input

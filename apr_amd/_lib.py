@@ -36,7 +36,7 @@ class SpconvDesc(C.Structure):
                 ("counters", C.c_void_p), ("plist", C.c_void_p), ("prod_scratch", C.c_void_p),
                 ("plist_bytes", C.c_int64), ("w_bf3", C.c_void_p),
                 ("os_pairs", C.c_void_p), ("os_rows", C.c_int64), ("os_build_bytes", C.c_int64),
-                ("os_n_in", C.c_int64)]
+                ("os_n_in", C.c_int64), ("l2norm", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void k_spconv_pairs(
     const float* __restrict__ in, int64_t ldi, const int* __restrict__ nbr, int n_out, int K,
     int cin, int cout, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ residual, int64_t ldr, int relu,
-    float* __restrict__ out, int64_t ldo) {
+    float* __restrict__ out, int64_t ldo, int l2norm) {
   constexpr int CB = CN / 16;   // 16-col blocks per wave item
   constexpr int NJ = CK / 16;   // 16-wide k groups per chunk
   constexpr int LDO = CN + 4;   // accumulator row stride (floats), 16-B aligned rows
@@ -388,6 +388,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void k_spconv_pairs(
     if (relu) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
+    if (l2norm) {
+      // row / |row|_2 (the encoder's normalize_feature, FCGF_APR/model/resunet.py:139-142) fused behind the last layer:
+      // the host launches this only with cout == CN, so the row's CN channels sit in the CN / 4 consecutive lanes of
+      // this pass.  The sum of squares follows k_l2_normalize's butterfly (channel distance CN/2 ... 4 across lanes,
+      // then 2 and 1 inside the lane) and the division is the same: the same bits as the separate kernel.
+      f32x4 sq;      // rounded squares (k_l2_normalize's fmaf(v, v, 0)): must not contract into the adds below
+      sq[0] = fmaf(v[0], v[0], 0.f); sq[1] = fmaf(v[1], v[1], 0.f);
+      sq[2] = fmaf(v[2], v[2], 0.f); sq[3] = fmaf(v[3], v[3], 0.f);
+#pragma unroll
+      for (int dl = CN / 8; dl >= 1; dl >>= 1) {
+        sq[0] += __shfl_xor(sq[0], dl); sq[1] += __shfl_xor(sq[1], dl);
+        sq[2] += __shfl_xor(sq[2], dl); sq[3] += __shfl_xor(sq[3], dl);
+      }
+      const float nrm = sqrtf((sq[0] + sq[2]) + (sq[1] + sq[3]));
+      v[0] = v[0] / nrm; v[1] = v[1] / nrm; v[2] = v[2] / nrm; v[3] = v[3] / nrm;
+    }
     *reinterpret_cast<f32x4*>(out + (int64_t)row * ldo + col) = v;
   }
 }
@@ -496,10 +512,14 @@ template <int TM, int CN, int CK, int NW>
 int launch_pairs(const float* in, int64_t ldi, const int* nbr, int64_t n_out, int K, int cin,
                  int cout, const float* wp, const float* scale, const float* shift,
                  const float* residual, int64_t ldr, int relu, float* out, int64_t ldo,
-                 hipStream_t st) {
+                 hipStream_t st, int l2norm = 0) {
   int64_t tiles = cdiv64(n_out, TM) * (cout / CN);
+  if (l2norm && cout != CN) {
+    apr_set_error("spconv: fused row normalisation needs the whole row in one tile (cout %d, tile %d)", cout, CN);
+    return APR_EINVAL;
+  }
   hipLaunchKernelGGL((k_spconv_pairs<TM, CN, CK, NW>), dim3((unsigned)tiles), dim3(64 * NW), 0, st, in, ldi,
-                     nbr, (int)n_out, K, cin, cout, wp, scale, shift, residual, ldr, relu, out, ldo);
+                     nbr, (int)n_out, K, cin, cout, wp, scale, shift, residual, ldr, relu, out, ldo, l2norm);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -525,10 +545,40 @@ APR_API int apr_spconv_pack_weights(const float* w, int32_t K, int32_t cin, int3
   return APR_OK;
 }
 
+// apr_spconv_fwd + optional row normalisation of the result (out[j] /= |out[j]|_2): fused into the tile kernel's
+// epilogue when that kernel runs the layer with the whole row in one tile (cout 32 or 64), else a second launch.
+static int spconv_fwd_impl(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
+                           int32_t cout, const float* w_packed, const float* scale, const float* shift,
+                           const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, void* stream,
+                           int l2norm);
+
 APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_out, int32_t K,
                            int32_t cin, int32_t cout, const float* w_packed, const float* scale,
                            const float* shift, const float* residual, int64_t ldr, int32_t relu,
                            float* out, int64_t ldo, void* stream) {
+  return spconv_fwd_impl(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift, residual, ldr, relu, out, ldo, stream, 0);
+}
+
+static int spconv_fwd_plain(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
+                            int32_t cout, const float* w_packed, const float* scale, const float* shift,
+                            const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, void* stream,
+                            int l2f, bool* fused);
+
+static int spconv_fwd_impl(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
+                           int32_t cout, const float* w_packed, const float* scale, const float* shift,
+                           const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, void* stream,
+                           int l2norm) {
+  bool fused = false;
+  int rc = spconv_fwd_plain(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift, residual, ldr, relu, out, ldo,
+                            stream, l2norm, &fused);
+  if (rc != APR_OK || !l2norm || fused || n_out == 0) return rc;
+  return apr_l2_normalize(out, ldo, n_out, cout, out, ldo, stream);
+}
+
+static int spconv_fwd_plain(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_out, int32_t K, int32_t cin,
+                            int32_t cout, const float* w_packed, const float* scale, const float* shift,
+                            const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, void* stream,
+                            int l2f, bool* fused) {
   hipStream_t st = (hipStream_t)stream;
   APR_CHECK_ARG(n_out >= 0 && n_out < (1ll << 31), "apr_spconv_fwd: n_out=%lld", (long long)n_out);
   APR_CHECK_ARG(K >= 1 && cin >= 1 && cout >= 1, "apr_spconv_fwd: bad K/cin/cout");
@@ -546,10 +596,13 @@ APR_API int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int
       ((((uintptr_t)scale) | ((uintptr_t)shift) | ((uintptr_t)w_packed)) & 15) == 0)
     return apr_internal_dense_gemm(in, ldi, n_out, cin, cout, w_packed, scale, shift, residual, ldr, relu, out, ldo, st);
   if (s_impl == 2 && use_mfma(K, cin, cout) && K <= kKMax && vec_ok) {
+    // the row normalisation rides in this kernel's epilogue when a tile holds the whole row (CN == cout)
+    const int l2k = (l2f && (cout == 32 || cout == 64)) ? 1 : 0;
+    static const int s_nw = env_int("APR_SPCONV_NW", 4);
+    if (l2k && !(s_nw == 8 && cout % 64 == 0) && !(cout == 64 && env_int("APR_SPCONV_CN", 0) == 32)) *fused = true;
 #define APR_PAIRS(TM_, CN_, CK_)                                                                      \
   return launch_pairs<TM_, CN_, CK_, 4>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift,    \
-                                        residual, ldr, relu, out, ldo, st)
-    static const int s_nw = env_int("APR_SPCONV_NW", 4);
+                                        residual, ldr, relu, out, ldo, st, *fused ? 1 : 0)
     if (s_nw == 8 && cout % 64 == 0)   // 8-wave tiles: 32-row tile, 32-channel pieces (<= 128 VGPRs, 4 waves/SIMD)
       return launch_pairs<32, 64, 32, 8>(in, ldi, nbr, n_out, K, cin, cout, w_packed, scale, shift, residual, ldr,
                                          relu, out, ldo, st);
@@ -655,9 +708,13 @@ static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e
     if (rcw != APR_OK) return rcw;
   } else {
     if (e0) APR_HIP(hipEventRecord(e0, st));
-    int rc = apr_spconv_fwd(d.in, d.ldi, d.nbr, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.scale, d.shift, d.residual,
-                            d.ldr, d.relu, d.out, d.ldo, stream);
+    int rc = spconv_fwd_impl(d.in, d.ldi, d.nbr, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.scale, d.shift, d.residual,
+                             d.ldr, d.relu, d.out, d.ldo, stream, d.l2norm);
     if (rc != APR_OK) return rc;
+  }
+  if (d.l2norm && (d.plist || (d.os_pairs && d.w_bf3)) && d.n_out > 0) {   // other conv families: a second launch
+    int rcn = apr_l2_normalize(d.out, d.ldo, d.n_out, d.cout, d.out, d.ldo, stream);
+    if (rcn != APR_OK) return rcn;
   }
   if (e1) APR_HIP(hipEventRecord(e1, st));
   return APR_OK;

@@ -205,10 +205,9 @@ class ResUNet2(ME.MinkowskiNetwork):
         stage("3_tr", cat3, (4, 2, 3, True), N2, (2, 2, 3, False), cat2[:, :TR[3]])
         stage("2_tr", cat2, (2, 1, 3, True), N1, (1, 1, 3, False), cat1[:, :TR[2]])
         h = self.conv1_tr.run(cat1, None, N1, relu=True, batch=batch)
-        out = self.final.run(h, None, N1, batch=batch)
+        # the row normalisation rides in the last layer's launch (same bits as ops.l2_normalize behind it)
+        out = self.final.run(h, None, N1, batch=batch, l2norm=self.normalize_feature)
         batch.launch()
-        if self.normalize_feature:
-            out = ops.l2_normalize(out, out=out)
         return ME.SparseTensor(out, coordinate_map_key=CoordinateMapKey(1), coordinate_manager=cm)
 
     def forward(self, x):

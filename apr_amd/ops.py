@@ -523,7 +523,7 @@ class SpconvBatch:
         self.meta = []      # (P, cin, cout, mfma?, path) per launch while a SpconvProfile is active
 
     def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
-            plist=None, w_bf3=None, os_pairs=None):
+            plist=None, w_bf3=None, os_pairs=None, l2norm=False):
         x, ldi = _rows(x, "spconv.x")
         if nbr is not None:
             n_out = nbr.shape[0]
@@ -538,6 +538,7 @@ class SpconvBatch:
         d = _lib.SpconvDesc()
         d.inp, d.ldi, d.nbr, d.n_out = x.data_ptr(), ldi, (nbr.data_ptr() if nbr is not None else None), n_out
         d.K, d.cin, d.cout, d.relu = K, cin, cout, int(bool(relu))
+        d.l2norm = int(bool(l2norm))        # rows of the result divided by their 2-norm (fused where the kernel allows)
         d.w_packed = wp.data_ptr()
         d.scale = scale.data_ptr() if scale is not None else None
         d.shift = shift.data_ptr() if shift is not None else None

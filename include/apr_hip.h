@@ -232,6 +232,10 @@ typedef struct apr_spconv_desc {
   int64_t os_rows;        /* ... of os_rows rows per tile; */
   int64_t os_build_bytes; /* > 0: apr_spconv_os_pairs_build(nbr -> os_pairs, n_in = os_n_in) first */
   int64_t os_n_in;
+  int32_t l2norm;         /* != 0: out[j, :] /= |out[j, :]|_2 behind the epilogue (the encoder's normalize_feature,
+                           * FCGF_APR/model/resunet.py:139-142): in the tile kernel's epilogue when it runs the layer
+                           * with cout 32 or 64 (same bits as apr_l2_normalize), else as a second launch */
+  int32_t reserved_;
 } apr_spconv_desc;
 int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* stream);
 /* Same, with one HIP event pair per launch recorded on `stream` (around the conv kernels only, not a pair-list

@@ -366,3 +366,30 @@ def test_occupancy_conv_equals_kernel_map_path(dev, ks, cout, n, nbatch, lo, hi,
     # a box that would need more than 2 GB of bitmap is declined (the caller keeps the kernel-map path)
     assert not ops.occ_conv_supported([0, 0, 0, 1 << 20, 1 << 20, 64, 0, 0], ks, cout)
     assert not ops.occ_conv_supported(bbox, ks, cout + 1)
+
+
+@pytest.mark.parametrize("cin,cout,n,K", [(64, 32, 5000, 1), (64, 32, 70001, 1), (96, 64, 3000, 1), (32, 32, 2500, 27),
+                                          (64, 128, 4000, 1), (32, 64, 900, 27), (64, 64, 40000, 1)])
+def test_row_normalisation_fused_behind_the_last_layer(dev, cin, cout, n, K):
+    """`l2norm` on a batched launch (the encoder's normalize_feature riding in the final layer's epilogue) == the conv
+    followed by ops.l2_normalize, bit for bit, whichever kernel family runs the layer (tile kernel: fused; dense GEMM:
+    a second launch inside the library); scale / shift / ReLU in front of it; strided output rows."""
+    rng = np.random.default_rng(cin + cout + n)
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(dev)
+    W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 4)).astype(np.float32)).to(dev)
+    nbr = None if K == 1 else torch.from_numpy(_random_map(rng, n, n, K, 0.3)).to(dev)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(dev)
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev)
+    wp = ops.pack_weights(W)
+    for sc, sh, relu in ((None, None, False), (scale, shift, True)):
+        plain = ops.spconv(x, nbr, K, cin, cout, wp, scale=sc, shift=sh, relu=relu, n_out=n)
+        ref = ops.l2_normalize(plain.clone())
+        buf = torch.full((n, cout + 8), 3.0, dtype=torch.float32, device=dev)
+        b = ops.SpconvBatch()
+        got = b.add(x, nbr, K, cin, cout, wp, scale=sc, shift=sh, relu=relu, out=buf[:, 4:4 + cout], n_out=n, l2norm=True)
+        b.launch()
+        assert torch.equal(got, ref)
+        assert bool((buf[:, :4] == 3.0).all()) and bool((buf[:, 4 + cout:] == 3.0).all())
+        nrm = got.norm(dim=1)
+        ok = torch.isfinite(nrm)                 # an all-zero row (possible behind the ReLU) is 0 / 0 in both forms
+        assert torch.allclose(nrm[ok], torch.ones_like(nrm[ok]), atol=1e-5)
