@@ -43,15 +43,18 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="pairs in flight per GPU: each on its own HIP stream + host thread (a 28 k-voxel pair "
                          "cannot fill 256 CUs alone, so independent pairs overlap)")
-    ap.add_argument("--depth", type=int, default=1,
+    ap.add_argument("--depth", type=int, default=None,
                     help="steps in flight PER STREAM: depth d puts d host workers (or scheduler slots) on every stream, so "
                          "the next steps' kernels are already queued behind the running one and the stream never waits "
                          "for the host between a step's device->host fetch and the following launch (--streams 1 "
-                         "--depth 3: one HIP stream, the host up to three steps ahead)")
-    ap.add_argument("--match-lanes", type=int, default=0,
+                         "--depth 3: one HIP stream, the host up to three steps ahead).  Default: 1, except 3 with "
+                         "--streams 1")
+    ap.add_argument("--match-lanes", type=int, default=None,
                     help="deal the pairs of a step's matching + RANSAC batch over this many streams forked from the "
                          "step's stream inside libapr_hip (APR_MATCH_LANES; 0 = leave the library default, 1 lane).  Helps "
-                         "--streams 1 (1558 -> 1640 pairs/s with 3), costs throughput once several steps are in flight")
+                         "--streams 1 (1613 -> 1896 pairs/s together with --depth 3), costs throughput once several steps "
+                         "are in flight.  Default: 0, except 3 with --streams 1 (the plain one-stream loop: --streams 1 "
+                         "--depth 1 --match-lanes 1)")
     ap.add_argument("--host", choices=["pipelined", "threads"], default="threads",
                     help="how the --streams steps in flight are driven: one Python thread per stream (default: the step's "
                          "host work is mostly inside library calls, which release the GIL, so three threads enqueue three "
@@ -70,7 +73,15 @@ def parse():
                          "rank at the end; value = pairs_total / max-over-ranks seconds, strong scaling.  --steps is "
                          "ignored (a rank runs ceil(block / pairs-per-step) steps)")
     ap.set_defaults(pairs_per_step=6)
-    return ap.parse_args()
+    args = ap.parse_args()
+    # a single stream gets the two remedies for a caller with one step in flight unless told otherwise (both are
+    # reported in config: steps_in_flight_per_stream, match_lanes)
+    one = args.streams == 1 and not args.pairs_total
+    if args.depth is None:
+        args.depth = 3 if one else 1
+    if args.match_lanes is None:
+        args.match_lanes = 3 if one else 0
+    return args
 
 
 def build_model(name, n_out, dev):
@@ -778,6 +789,8 @@ def main():
             "by_kernel": {names[k]: v for k, v in sorted(legs.items())},
         }
     if rank == 0 and world == 1 and not args.no_workloads:
+        if args.match_lanes > 1:
+            ops.set_match_lanes(1)      # the side workloads keep several steps in flight themselves
         out["workloads"] = extra_workloads(dev, log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline (oracle on host cores) ...")

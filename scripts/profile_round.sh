@@ -17,15 +17,15 @@ done
 echo "[profile] default bench"
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err </dev/null || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "[profile] one stream: plain, and with the host three steps ahead + the matching batch on three lanes"
-python3 $R/bench.py --streams 1 --steps 120 --no-cpu-baseline --no-roofline --no-workloads > $OUT/bench_s1_plain.json 2> $OUT/bench_s1_plain.err </dev/null || { echo "s1 plain failed"; exit 1; }
+python3 $R/bench.py --streams 1 --depth 1 --match-lanes 1 --steps 120 --no-cpu-baseline --no-roofline --no-workloads > $OUT/bench_s1_plain.json 2> $OUT/bench_s1_plain.err </dev/null || { echo "s1 plain failed"; exit 1; }
 python3 $R/bench.py --streams 1 --depth 3 --match-lanes 3 --steps 120 --no-cpu-baseline --no-roofline --no-workloads > $OUT/bench_s1_d3_l3.json 2> $OUT/bench_s1_d3_l3.err </dev/null || { echo "s1 depth 3 lanes 3 failed"; exit 1; }
 echo "[profile] rocprof stats, default run"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $R/bench.py --no-cpu-baseline --no-workloads > $OUT/bench_prof.json 2> $OUT/bench_prof.err </dev/null || { echo "rocprof default failed"; exit 1; }
 echo "[profile] rocprof stats, single stream"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o b -- python3 $R/bench.py --streams 1 --steps 60 --no-cpu-baseline --no-workloads > $OUT/bench_s1.json 2> $OUT/bench_s1.err </dev/null || { echo "rocprof s1 failed"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o b -- python3 $R/bench.py --streams 1 --depth 1 --match-lanes 1 --steps 60 --no-cpu-baseline --no-workloads > $OUT/bench_s1.json 2> $OUT/bench_s1.err </dev/null || { echo "rocprof s1 failed"; exit 1; }
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "[profile] pmc $C"
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $R/bench.py --steps 4 --warmup 2 --streams 1 --no-cpu-baseline --no-roofline --no-workloads > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err </dev/null || { echo "pmc $C failed"; exit 1; }
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- python3 $R/bench.py --steps 4 --warmup 2 --streams 1 --depth 1 --match-lanes 1 --no-cpu-baseline --no-roofline --no-workloads > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err </dev/null || { echo "pmc $C failed"; exit 1; }
 done
 echo "[profile] predator pair: kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pred_stats -o p -- python3 $R/scripts/predator_profile.py > $OUT/predator_profile.log 2>&1 </dev/null || { echo "predator stats failed"; exit 1; }
