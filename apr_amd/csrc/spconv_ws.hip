@@ -310,11 +310,14 @@ __global__ void k_pack_weights_bf3(const float* __restrict__ w, int K, int cin, 
   wp3[base + 2 * plane] = l;
 }
 
-template <int NCH>   // cin / 64: 1, 2 or 4
-__global__ __launch_bounds__(256, 2) void k_ws_gemm_bf3(const float* __restrict__ in, int64_t ldi, PairViews v, int K,
+// NW waves per workgroup: 4, or 8 for the 256-channel slice (96 KB: ONE workgroup per CU whatever its size -- with 4
+// waves that is one wave per SIMD and nothing to hide the gather -> split -> MFMA chain behind; 8 waves share the slice).
+template <int NCH, int NW = 4>   // cin / 64: 1, 2 or 4
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_ws_gemm_bf3(const float* __restrict__ in, int64_t ldi, PairViews v, int K,
                                                         int cin, int cout, const __bf16* __restrict__ wp3,
                                                         float* __restrict__ prod, int n_out, int target_units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];   // [plane 3][step][col 64][quad 4][8 bf16]
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q = lane >> 4;
@@ -359,20 +362,20 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm_bf3(const float* __restrict_
     unsigned idx = (g < ngroups) ? (unsigned)v.pair_in[my_p < p_end ? my_p : p_begin] : 0u;
     unsigned idx_n = 0;
     {
-      const int np = p_begin + (g + 4) * 16 + r16;
-      if (g + 4 < ngroups) idx_n = (unsigned)v.pair_in[np < p_end ? np : p_begin];
+      const int np = p_begin + (g + NW) * 16 + r16;
+      if (g + NW < ngroups) idx_n = (unsigned)v.pair_in[np < p_end ? np : p_begin];
     }
     {   // stage the slice: a straight copy (the global layout IS the LDS image)
       const unsigned char* src = reinterpret_cast<const unsigned char*>(wp3) +
                                  ((int64_t)k * (cout >> 6) + blockIdx.y) * slice_bytes;
-      for (int o0 = tid * 16; o0 < slice_bytes; o0 += 8 * 256 * 16) {
+      for (int o0 = tid * 16; o0 < slice_bytes; o0 += 8 * NT * 16) {
         f32x4 t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (o0 + u * 256 * 16 < slice_bytes) t[u] = *reinterpret_cast<const f32x4*>(src + o0 + u * 256 * 16);
+          if (o0 + u * NT * 16 < slice_bytes) t[u] = *reinterpret_cast<const f32x4*>(src + o0 + u * NT * 16);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (o0 + u * 256 * 16 < slice_bytes) *reinterpret_cast<f32x4*>(s_raw + o0 + u * 256 * 16) = t[u];
+          if (o0 + u * NT * 16 < slice_bytes) *reinterpret_cast<f32x4*>(s_raw + o0 + u * NT * 16) = t[u];
       }
     }
     // rows: lane (pair r16, quad q) holds channels 32 s + 8 q .. + 7 of its pair for the chunk's two steps
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm_bf3(const float* __restrict_
     for (int j = 0; j < 4; ++j) bufA[j] = *reinterpret_cast<const f32x4*>(abase + (j >> 1) * 32 + (j & 1) * 4);
     __syncthreads();
 
-    const int nsteps = (g < ngroups) ? ((ngroups - g + 3) >> 2) * NCH : 0;
+    const int nsteps = (g < ngroups) ? ((ngroups - g + NW - 1) / NW) * NCH : 0;
     int c = 0;
     f32x4 acc[4];
 #pragma unroll
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm_bf3(const float* __restrict_
     {                                                                                                             \
       const bool last = (c + 1 == NCH);                                                                           \
       const float* nb = last ? in + (uint64_t)idx_n * ldi32 + q * 8 : abase + (c + 1) * 64;                       \
-      const int np2 = p_begin + (g + 8) * 16 + r16;                                                               \
+      const int np2 = p_begin + (g + 2 * NW) * 16 + r16;                                                               \
       const unsigned idx_nn = (unsigned)v.pair_in[np2 < p_end ? np2 : p_begin];                                    \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
         nxt[j] = *reinterpret_cast<const f32x4*>(nb + (j >> 1) * 32 + (j & 1) * 4);                               \
@@ -432,8 +435,8 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm_bf3(const float* __restrict_
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                          \
           __builtin_nontemporal_store(acc[cb], reinterpret_cast<f32x4*>(dst + cb * 16));                         \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};                   \
-        g += 4;                                                                                                   \
-        my_p += 64;                                                                                               \
+        g += NW;                                                                                                  \
+        my_p += 16 * NW;                                                                                          \
         abase = nb;                                                                                               \
         idx_n = idx_nn;                                                                                           \
         c = 0;                                                                                                    \
@@ -565,6 +568,7 @@ static int ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const v
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       s_attr[dev] = true;
     }
   }
@@ -577,9 +581,15 @@ static int ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const v
     if (target3 > s_target) target3 = s_target;
     int64_t gx3 = cdiv64(target3, cout / 64);
     if (gx3 > need) gx3 = need;
-    auto k3 = cin == 64 ? k_ws_gemm_bf3<1> : cin == 128 ? k_ws_gemm_bf3<2> : k_ws_gemm_bf3<4>;
-    hipLaunchKernelGGL(k3, dim3((unsigned)gx3, cout / 64), dim3(256), lds3, st, in, ldi, v, K, cin, cout,
-                       (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
+    static const int s_nw8 = env_int("APR_WS_NW8", 1);      // A/B switch: 0 = 4 waves for the 256-channel slice too
+    if (cin == 256 && s_nw8)
+      hipLaunchKernelGGL((k_ws_gemm_bf3<4, 8>), dim3((unsigned)gx3, cout / 64), dim3(512), lds3, st, in, ldi, v, K, cin, cout,
+                         (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
+    else {
+      auto k3 = cin == 64 ? k_ws_gemm_bf3<1> : cin == 128 ? k_ws_gemm_bf3<2> : k_ws_gemm_bf3<4>;
+      hipLaunchKernelGGL(k3, dim3((unsigned)gx3, cout / 64), dim3(256), lds3, st, in, ldi, v, K, cin, cout,
+                         (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
+    }
   } else {
   auto kern = cin == 64 ? k_ws_gemm<1> : cin == 128 ? k_ws_gemm<2> : cin == 256 ? k_ws_gemm<4> : k_ws_gemm<0>;
   hipLaunchKernelGGL(kern, dim3(units, cout / 64), dim3(256), lds, st, in, ldi, v, K, cin, cout, w_packed,
