@@ -421,6 +421,8 @@ class _ConvBase(nn.Module):
             return False
         if os.environ.get("APR_OCC_CONV", "1") == "0" or _tracking(x.F, self.kernel, self.bias):
             return False
+        if os.environ.get("APR_CHECK_UNIT_FEATURES") == "1" and not bool((x.F == 1.0).all()):     # debugging aid: synchronises
+            raise AprHipError("SparseTensor(unit_features=True): the features are not all 1.0")
         return ops.occ_conv_supported(x.coordinate_manager.get_bbox(), self.kernel_size, self.out_channels)
 
     def run_occ(self, cm, n_out, scale=None, shift=None, relu=False, out=None):

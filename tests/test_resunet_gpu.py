@@ -74,6 +74,13 @@ def test_unit_feature_input_runs_conv1_on_occupancy_with_the_same_bits(dev, name
         assert (1, 1, k1, False) in off.coordinate_manager._kmaps
     assert torch.equal(occ.F, plain.F) and torch.equal(off.F, plain.F)
     assert rel_l2(occ.F.cpu(), ref) < TOL
+    # the promise can be checked: a caller that flags features which are not ones is told so
+    monkeypatch.delenv("APR_OCC_CONV")
+    monkeypatch.setenv("APR_CHECK_UNIT_FEATURES", "1")
+    with torch.no_grad():
+        hm(ME.SparseTensor(Fd, coordinates=Cd, unit_features=True))
+        with pytest.raises(Exception, match="not all 1.0"):
+            hm(ME.SparseTensor(Fd * 2.0, coordinates=Cd, unit_features=True))
 
 
 def test_batched_equals_separate(dev):
