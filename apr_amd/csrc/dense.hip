@@ -306,7 +306,8 @@ APR_API int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t 
                 "apr_dense_gemm_bf3: scale / shift must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t ncol = cout / 64;
-  if (cdiv64(M, 128) * ncol >= 512)
+  static const int s_g = env_int("APR_DENSE_G", 0);      // A/B switch: force 64-row (1) or 128-row (2) tiles
+  if (s_g == 2 || (s_g == 0 && cdiv64(M, 128) * ncol >= 512))
     hipLaunchKernelGGL(k_dense_gemm_bf3<2>, dim3((unsigned)(cdiv64(M, 128) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
                        cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo);
   else
