@@ -150,7 +150,14 @@ __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q = lane >> 4;
   const int ncol = cout >> 6;
-  const int tile_m = blockIdx.x / ncol, tile_n = blockIdx.x - tile_m * ncol;
+  // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Consecutive LINEAR tile ids (the column
+  // blocks of one row tile, then the next row tile) are therefore given to ONE XCD: the ncol workgroups that read the
+  // same A rows share them through that L2 instead of fetching them ncol times from the Infinity Cache / HBM
+  // (16 KPFCNN shapes: 1319 -> 1250 us in all; [14692, 3840] x [3840, 256] 198 -> 181 us).
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int lin = xcd * (nb >> 3) + min(xcd, nb & 7) + loc;
+  const int tile_m = lin / ncol, tile_n = lin - tile_m * ncol;
   const int row0 = tile_m * (64 * G) + wave * (16 * G);
   const int col0 = tile_n * 64;
   const int nchunk = cin >> 6;

@@ -321,7 +321,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_ws_gemm_bf3(const 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q = lane >> 4;
-  const int col0 = blockIdx.y * 64;
+  // 1-D grid of gx * ncb workgroups.  The ncb column-block workgroups of a unit gather the SAME input rows: they get
+  // consecutive linear ids inside ONE XCD's share of the grid (workgroups are dealt round-robin over the 8 XCDs, each
+  // with its own L2), so the second gather of a row finds it in that L2 instead of the Infinity Cache (12 frames per
+  // launch: b4 256 -> 256 87 -> 75 us, FatBN's 128 -> 128 block at 189 k rows 440 -> 413 us; with ONE column block the
+  // same re-ordering only moves units between XCDs and costs 12 % on c2tr, so it is not applied there).
+  const int ncb = cout >> 6;
+  const int nbk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int lin = ncb > 1 ? xcd * (nbk >> 3) + min(xcd, nbk & 7) + loc : bid;   // one column block: nothing to share
+  const int bx = lin / ncb, by = lin - bx * ncb, gx = nbk / ncb;
+  const int col0 = by * 64;
   constexpr int nstep = NCH * 2;                       // 32-channel steps
   constexpr int plane_bytes = nstep * 64 * 64;         // one split plane of the slice
   constexpr int slice_bytes = 3 * plane_bytes;
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_ws_gemm_bf3(const 
   int P = cnt_l;
   for (int d = 16; d >= 1; d >>= 1) P += __shfl_xor(P, d);
   P = __shfl(P, 0);
-  int G = (int)((((int64_t)(P + 63) >> 6) * gridDim.y + target_units - 1) / target_units);
+  int G = (int)((((int64_t)(P + 63) >> 6) * ncb + target_units - 1) / target_units);
   G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
   int span, units, incl;
   for (;;) {
@@ -341,14 +351,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_ws_gemm_bf3(const 
       const int t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
     }
-    if (__shfl(incl, 31) <= (int)gridDim.x || G >= kMaxG) break;
+    if (__shfl(incl, 31) <= gx || G >= kMaxG) break;
     ++G;
   }
   const int total_units = __shfl(incl, 31);
   // fragment read offset of this lane inside a (step, 16-column block): column r16, swizzled quad
   const int frag_off = (r16 * 4 + ((r16 & 8) ? (q ^ 3) : q)) * 16;
 
-  for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+  for (int unit = bx; unit < total_units; unit += gx) {
     const int k = __popcll(__ballot(lane < K && incl <= unit));
     const int excl = __builtin_amdgcn_readfirstlane(__shfl(incl - units, k));
     const int region = k * n_out;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_ws_gemm_bf3(const 
     }
     {   // stage the slice: a straight copy (the global layout IS the LDS image)
       const unsigned char* src = reinterpret_cast<const unsigned char*>(wp3) +
-                                 ((int64_t)k * (cout >> 6) + blockIdx.y) * slice_bytes;
+                                 ((int64_t)k * (cout >> 6) + by) * slice_bytes;
       for (int o0 = tid * 16; o0 < slice_bytes; o0 += 8 * NT * 16) {
         f32x4 t[8];
 #pragma unroll
@@ -583,11 +593,11 @@ static int ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const v
     if (gx3 > need) gx3 = need;
     static const int s_nw8 = env_int("APR_WS_NW8", 1);      // A/B switch: 0 = 4 waves for the 256-channel slice too
     if (cin == 256 && s_nw8)
-      hipLaunchKernelGGL((k_ws_gemm_bf3<4, 8>), dim3((unsigned)gx3, cout / 64), dim3(512), lds3, st, in, ldi, v, K, cin, cout,
+      hipLaunchKernelGGL((k_ws_gemm_bf3<4, 8>), dim3((unsigned)(gx3 * (cout / 64))), dim3(512), lds3, st, in, ldi, v, K, cin, cout,
                          (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
     else {
       auto k3 = cin == 64 ? k_ws_gemm_bf3<1> : cin == 128 ? k_ws_gemm_bf3<2> : k_ws_gemm_bf3<4>;
-      hipLaunchKernelGGL(k3, dim3((unsigned)gx3, cout / 64), dim3(256), lds3, st, in, ldi, v, K, cin, cout,
+      hipLaunchKernelGGL(k3, dim3((unsigned)(gx3 * (cout / 64))), dim3(256), lds3, st, in, ldi, v, K, cin, cout,
                          (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
     }
   } else {
