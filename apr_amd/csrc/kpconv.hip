@@ -40,12 +40,17 @@ template <int NG>
 __global__ __launch_bounds__(256) void k_kpconv_weighted_mfma(
     const float* __restrict__ q_pts, const float* __restrict__ s_pts, const int* __restrict__ nbr, int H,
     const float* __restrict__ x, int64_t ldx, int cin, const float* __restrict__ kp, float extent,
-    const float* __restrict__ rowsum, float* __restrict__ wf, int64_t ldwf, int nq, int ns) {
+    const float* __restrict__ rowsum, float* __restrict__ wf, int64_t ldwf, int nq, int ns, int xcd_swz) {
   __shared__ int s_idx[4][kMaxH];
   __shared__ float s_diff[4][kMaxH][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, qd = lane >> 4;
-  const int qi = blockIdx.x * 4 + wave;
+  int blk = blockIdx.x;
+  if (xcd_swz) {      // consecutive queries (they share neighbours) behind ONE XCD's L2
+    const int nb = gridDim.x, xcd = blk & 7, loc = blk >> 3;
+    blk = xcd * (nb >> 3) + min(xcd, nb & 7) + loc;
+  }
+  const int qi = blk * 4 + wave;
   if (qi >= nq) return;
   const float qx = q_pts[3 * (int64_t)qi], qy = q_pts[3 * (int64_t)qi + 1], qz = q_pts[3 * (int64_t)qi + 2];
   int cnt = 0;
@@ -772,15 +777,16 @@ APR_API int apr_kpconv_weighted(const float* q_pts, int64_t nq, const float* s_p
   const bool vec = cin % 64 == 0 && H <= kMaxH && ldx % 4 == 0 && ldwf % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)wf)) & 15) == 0;
   if (vec) {
     const unsigned grid = (unsigned)cdiv64(nq, 4);
+    static const int s_xcd = env_int("APR_KPCONV_XCD", 1);      // A/B switch
     if (cin >= 256)
       hipLaunchKernelGGL(k_kpconv_weighted_mfma<4>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, x, ldx, cin,
-                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
+                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns, s_xcd);
     else if (cin == 128)
       hipLaunchKernelGGL(k_kpconv_weighted_mfma<2>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, x, ldx, cin,
-                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
+                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns, s_xcd);
     else
       hipLaunchKernelGGL(k_kpconv_weighted_mfma<1>, dim3(grid), dim3(256), 0, st, q_pts, s_pts, nbr, H, x, ldx, cin,
-                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
+                         kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns, s_xcd);
   } else {
     hipLaunchKernelGGL(k_kpconv_weighted_generic, dim3((unsigned)cdiv64(nq * kKP, 256)), dim3(256), 0, st, q_pts, s_pts,
                        nbr, H, x, ldx, cin, kernel_points, extent, rowsum, wf, ldwf, (int)nq, (int)ns);
