@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 -w -o /tmp/lds_occupancy scripts/ubench/lds_occupancy.hip
 // How many workgroups of 256 threads does a CU hold as a function of their LDS footprint?  Every workgroup spins for a
 // fixed number of clock ticks; 256 CUs x NPER workgroups are launched; elapsed / spin = rounds = NPER / residency.
 #include <hip/hip_runtime.h>
