@@ -132,9 +132,19 @@ class CoordinateManager:
         return self.maps[ts]
 
     def set_bbox(self, bbox):
-        """The 8 host ints of `ops.coords_bbox` over the stride-1 coordinates (or over the raw points they were
-        quantised from): handed over by a caller that fetched them with the map sizes, so `get_bbox` costs no sync."""
+        """The 8 host ints of `ops.coords_bbox` -- min x, y, z, max x, y, z, max batch index, 0, in VOXEL units (integer
+        coordinates as stored in the stride-1 map, not metres) -- over the stride-1 coordinates or over the voxelised input
+        rows they were made unique from (a superset is fine): handed over by a caller that fetched them with the map
+        sizes, so `get_bbox` costs no sync.  A box that misses a voxel turns that voxel's conv1 output row into NaN
+        (ops.occ_conv); APR_CHECK_BBOX=1 verifies the box against the map here (synchronises)."""
         self._bbox = tuple(int(v) for v in bbox)
+        import os
+        if os.environ.get("APR_CHECK_BBOX") == "1":
+            m = self.get_map(1)
+            true = ops.coords_bbox(m.coords[:m.n].contiguous()).tolist()
+            b = self._bbox
+            if any(b[a] > true[a] for a in range(3)) or any(b[a] < true[a] for a in range(3, 7)):
+                raise AprHipError(f"set_bbox: box {b[:7]} does not contain the stride-1 coordinates {tuple(true[:7])}")
 
     def get_bbox(self):
         if self._bbox is None:
@@ -423,7 +433,7 @@ class _ConvBase(nn.Module):
             return False
         if os.environ.get("APR_CHECK_UNIT_FEATURES") == "1" and not bool((x.F == 1.0).all()):     # debugging aid: synchronises
             raise AprHipError("SparseTensor(unit_features=True): the features are not all 1.0")
-        return ops.occ_conv_supported(x.coordinate_manager.get_bbox(), self.kernel_size, self.out_channels)
+        return ops.occ_conv_supported(x.coordinate_manager.get_bbox(), self.kernel_size, self.out_channels, n=x.F.shape[0])
 
     def run_occ(self, cm, n_out, scale=None, shift=None, relu=False, out=None):
         if shift is None and self.bias is not None:

@@ -34,6 +34,9 @@ def needs_build() -> bool:
     return any(os.path.getmtime(s) > t for s in _deps())
 
 
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
@@ -49,36 +52,50 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in _deps() if h.endswith(".h"))):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-               "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}"] + CFLAGS + ["-c", src, "-o", obj]
         if verbose:
             print("[apr_amd.build]", " ".join(cmd), flush=True)
         jobs.append((src, subprocess.Popen(cmd)))
     for src, p in jobs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    # the assembly check of spconv_os.hip runs BEFORE the link: a failing check must leave no library behind that the
+    # next build() (needs_build() == False) would hand out silently
+    if any(os.path.basename(src) == "spconv_os.hip" for src, _ in jobs):
+        try:
+            check_os_pipeline(verbose)
+        except BaseException:
+            for stale in (LIB, os.path.join(LIBDIR, "spconv_os.o")):
+                if os.path.exists(stale):
+                    os.remove(stale)
+            raise
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + [
         "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print("[apr_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    if any(os.path.basename(src) == "spconv_os.hip" for src, _ in jobs):
-        check_os_pipeline(verbose)
     return LIB
+
+
+COPY_OPS = ("v_mov_b32_e32", "v_mov_b32_e64", "v_mov_b64_e32", "v_mov_b64_e64", "v_pk_mov_b32", "v_swap_b32", "v_swap_b32_e32",
+            "v_accvgpr_write_b32", "v_accvgpr_mov_b32")
+SPILL_PREFIXES = ("scratch_store", "buffer_store")
 
 
 def check_os_pipeline(verbose: bool = True) -> None:
     """spconv_os.hip keeps gathered rows in flight in registers across the item loop's back edge (inline-asm loads +
     counted s_waitcnt).  A register copy of such a value made by the compiler BEFORE its wait would read stale data, and
-    nothing at run time would say so: compile the file to assembly and refuse the build if any move / spill instruction
-    inside k_os_conv reads a register that an inline-asm global_load_dwordx4 writes."""
+    nothing at run time would say so: compile the file to assembly (the flags of the real compile) and refuse the build if
+    any move / swap / spill instruction inside k_os_conv's item loop reads a register that an inline-asm
+    global_load_dwordx4 writes (v_mov / v_pk_mov / v_swap / accvgpr writes, scratch_ / buffer_ stores = spills).  The
+    run-time guard is tests/test_spconv_gpu.py::test_os_conv_debug_pipeline_matches_production."""
     import re
     import tempfile
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     src = os.path.join(CSRC, "spconv_os.hip")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "os.s")
-        subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+        subprocess.check_call([hipcc, f"--offload-arch={ARCH}"] + CFLAGS + ["-S", "--cuda-device-only",
                                "-Wno-unused-command-line-argument", "-o", out, src], stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
 
@@ -118,11 +135,11 @@ def check_os_pipeline(verbose: bool = True) -> None:
                 continue
             if in_asm and ops[0] == "global_load_dwordx4":
                 loaded[k] |= regs(ops[1])
-            elif not in_asm and ops[0] in ("v_mov_b32_e32", "v_mov_b64_e32", "v_accvgpr_write_b32", "v_accvgpr_mov_b32"):
+            elif not in_asm and (ops[0] in COPY_OPS or ops[0].startswith(SPILL_PREFIXES)):
                 moves.append((ops, t))
         for ops, t in moves:
             src_regs = set()
-            for tok in ops[2:]:
+            for tok in (ops[1:] if ops[0].startswith(SPILL_PREFIXES) or ops[0].startswith("v_swap") else ops[2:]):
                 src_regs |= regs(tok)
             if src_regs & loaded[k]:
                 bad.append(f"{t}    [{k[:48]}]")

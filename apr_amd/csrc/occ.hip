@@ -19,7 +19,15 @@ namespace {
 struct OccGrid {
   int minx, miny, minz;      // cell (x, y, z) lives at (x - minx, y - miny, z - minz); the box is padded by ks / 2
   int dy, dz, wx;            // rows per slab, slabs per frame, 32-bit words per row (one spare word at the end)
+  int nx, nb;                // cells along x (padding included), frames
 };
+
+// The box is host-supplied (CoordinateManager.set_bbox is public): a voxel outside it must neither write nor read past the
+// bitmap.  True if the voxel itself (not its padded neighbourhood) lies inside the unpadded box of `h`-padded grid g.
+__device__ inline bool occ_inside(const OccGrid& g, const int4& c, int h) {
+  const int x = c.y - g.minx, y = c.z - g.miny, z = c.w - g.minz;
+  return c.x >= 0 && c.x < g.nb && x >= h && x < g.nx - h && y >= h && y < g.dy - h && z >= h && z < g.dz - h;
+}
 
 __device__ inline int64_t occ_word(const OccGrid& g, int b, int x, int y, int z) {
   return (((int64_t)b * g.dz + (z - g.minz)) * g.dy + (y - g.miny)) * g.wx + ((x - g.minx) >> 5);
@@ -68,10 +76,11 @@ __global__ __launch_bounds__(kBboxThreads) void k_bbox(const int4* __restrict__ 
   }
 }
 
-__global__ void k_occ_set(const int4* __restrict__ coords, int n, OccGrid g, unsigned* __restrict__ bm) {
+__global__ void k_occ_set(const int4* __restrict__ coords, int n, OccGrid g, int h, unsigned* __restrict__ bm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = coords[i];
+  if (!occ_inside(g, c, h)) return;        // k_occ_conv poisons this voxel's output row
   atomicOr(&bm[occ_word(g, c.x, c.y, c.z, c.w)], 1u << ((c.y - g.minx) & 31));
 }
 
@@ -92,7 +101,12 @@ __global__ __launch_bounds__(256) void k_occ_conv(const int4* __restrict__ coord
   const int row = blockIdx.x * 64 + r;
   for (int t = tid; t < 64 * (MW + 1); t += 256) (&s_mask[0][0])[t] = 0u;
   __syncthreads();
+  bool inside = false;
   if (row < n) {
+    const int4 c = coords[row];
+    inside = occ_inside(g, c, H);
+  }
+  if (inside) {
     const int4 c = coords[row];
     const int x0 = c.y - H - g.minx;                 // >= 0: the box is padded by H
     const int sh = x0 & 31;
@@ -111,6 +125,10 @@ __global__ __launch_bounds__(256) void k_occ_conv(const int4* __restrict__ coord
   }
   __syncthreads();
   if (row >= n) return;
+  if (!inside) {       // voxel outside the caller's box: a NaN row (loud downstream), never an out-of-bounds access
+    for (int c = cg; c < cout; c += 4) out[(int64_t)row * ldo + c] = __int_as_float(0x7fc00000);
+    return;
+  }
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   for (int c0 = cg * 8; c0 < cout; c0 += 32) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -162,6 +180,8 @@ OccLayout occ_layout(const int32_t* bbox, int32_t ks) {
   L.g.dy = (int)dy;
   L.g.dz = (int)dz;
   L.g.wx = (int)wx;
+  L.g.nx = (int)dx;
+  L.g.nb = bbox[6] + 1;
   L.words = words;
   L.ok = true;
   return L;
@@ -183,18 +203,29 @@ APR_API int apr_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox_dev,
   return APR_OK;
 }
 
-// Bytes of the occupancy bitmap for the box bbox_host (the 8 ints of apr_coords_bbox) and an odd kernel size; 0 = the
-// box is empty or unreasonably large (the caller takes the kernel-map path).
+// Bytes of the occupancy bitmap for the box bbox_host (the 8 ints of apr_coords_bbox, VOXEL units) and an odd kernel
+// size; 0 = the box is empty or unreasonably large (the caller takes the kernel-map path).
 APR_API size_t apr_occ_conv_scratch_bytes(const int32_t* bbox_host, int32_t kernel_size) {
   if (!bbox_host || kernel_size < 1 || !(kernel_size & 1)) return 0;
   const OccLayout L = occ_layout(bbox_host, kernel_size);
   return L.ok ? (size_t)L.words * 4 + 256 : 0;
 }
 
+// 1 if the occupancy form pays for n voxels in this box: the bitmap (cleared and probed per call) must stay small
+// against the structure it replaces -- the [n, ks^3] int32 kernel map: a KITTI batch needs ~90 B of bitmap per voxel;
+// one outlier voxel or two far-apart frames can blow the box up to gigabytes, and then the kernel-map path is the
+// cheaper one.  Cap: 1 KB of bitmap per voxel (+ 4 MB).
+APR_API int apr_occ_conv_pays(const int32_t* bbox_host, int32_t kernel_size, int64_t n) {
+  const size_t b = apr_occ_conv_scratch_bytes(bbox_host, kernel_size);
+  return b > 0 && n > 0 && b <= (size_t)n * 1024 + ((size_t)4 << 20);
+}
+
 // out[j, :] = act((sum_{k : cell(coords[j] + offset_k) occupied} w[k, :]) * scale + shift (+ residual[j, :])):
 // a stride-1, dilation-1, ks^3 sparse convolution of the constant-1 feature over the voxels `coords` (unique rows;
 // offsets x-fastest as apr_kernel_map), w f32[ks^3, cout] (the reference's [K, 1, cout] kernel), cout % 8 == 0,
-// ks in {3, 5, 7}.  Every voxel must lie inside bbox_host (apr_coords_bbox of the same rows or a superset).
+// ks in {3, 5, 7}.  Every voxel must lie inside bbox_host (apr_coords_bbox of the same rows or a superset, in VOXEL
+// units, batch index <= bbox_host[6]); a voxel outside it is not counted as anybody's neighbour and its own output row is
+// NaN (checked per voxel: no access leaves the bitmap whatever the box).
 APR_API int apr_occ_conv(const int32_t* coords, int64_t n, const int32_t* bbox_host, int32_t kernel_size,
                          const float* w, int32_t cout, const float* scale, const float* shift, const float* residual,
                          int64_t ldr, int32_t relu, float* out, int64_t ldo, void* scratch, size_t scratch_bytes,
@@ -211,7 +242,8 @@ APR_API int apr_occ_conv(const int32_t* coords, int64_t n, const int32_t* bbox_h
   hipStream_t st = (hipStream_t)stream;
   unsigned* bm = (unsigned*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
   APR_HIP(hipMemsetAsync(bm, 0, (size_t)L.words * 4, st));
-  hipLaunchKernelGGL(k_occ_set, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (const int4*)coords, (int)n, L.g, bm);
+  hipLaunchKernelGGL(k_occ_set, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (const int4*)coords, (int)n, L.g,
+                     kernel_size / 2, bm);
   const dim3 grid((unsigned)cdiv64(n, 64));
   if (kernel_size == 3)
     hipLaunchKernelGGL(k_occ_conv<3>, grid, dim3(256), 0, st, (const int4*)coords, (int)n, L.g, bm, w, cout, scale, shift,

@@ -138,6 +138,16 @@ def finalize_maps(maps, extras=()):
     return out
 
 
+# Fetch events are created with hipEventBlockingSync: a host thread waiting for a step's bytes sleeps in the driver instead
+# of spinning on the event (3 waiting threads per rank x 8 ranks would otherwise burn the node's CPU quota idling;
+# APR_BLOCKING_EVENTS=0 restores the spin wait for A/B runs).
+BLOCKING_EVENTS = os.environ.get("APR_BLOCKING_EVENTS", "1") != "0"
+
+
+def fetch_event():
+    return torch.cuda.Event(blocking=BLOCKING_EVENTS)
+
+
 class PendingFetch:
     """A small device -> pinned-host copy in flight on the current stream: `event` completes when the bytes have
     landed, `finish()` then runs the host-side continuation and returns its value.  Lets ONE host thread keep several
@@ -148,7 +158,7 @@ class PendingFetch:
     def __init__(self, dev_tensor, then, keep=()):
         self._host = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True)
         self._host.copy_(dev_tensor, non_blocking=True)
-        self.event = torch.cuda.Event()
+        self.event = fetch_event()
         self.event.record()
         self._then, self._keep = then, keep
 
@@ -793,18 +803,22 @@ def coords_bbox(coords):
     return bbox
 
 
-def occ_conv_supported(bbox, kernel_size, cout):
-    """True if `occ_conv` takes this case (odd kernel 3 / 5 / 7, cout % 8 == 0, a box whose bitmap stays under 2 GB)."""
+def occ_conv_supported(bbox, kernel_size, cout, n=None):
+    """True if `occ_conv` takes this case (odd kernel 3 / 5 / 7, cout % 8 == 0, a box whose bitmap stays under 2 GB and --
+    with the voxel count `n` given -- under 1 KB per voxel + 4 MB: one outlier voxel can stretch the box until the bitmap
+    costs more than the kernel map it replaces)."""
     if bbox is None or kernel_size not in (3, 5, 7) or cout % 8 != 0:
         return False
     box = (C.c_int32 * 8)(*[int(v) for v in bbox])
+    if n is not None:
+        return bool(_lib_().apr_occ_conv_pays(box, int(kernel_size), int(n)))
     return int(_lib_().apr_occ_conv_scratch_bytes(box, int(kernel_size))) > 0
 
 
 def occ_conv(coords, n, bbox, kernel_size, w, scale=None, shift=None, relu=False, residual=None, out=None):
     """Stride-1 ks^3 convolution of the constant-1 feature over the voxels coords[:n] (apr_occ_conv): w f32 [ks^3, cout];
-    bbox: the 8 host ints of `coords_bbox` for these rows (or a superset).  Same bits as `spconv` over the kernel map on
-    all-ones features."""
+    bbox: the 8 host ints of `coords_bbox` for these rows (or a superset; voxel units).  Same bits as `spconv` over the
+    kernel map on all-ones features; a row outside the box comes out as NaN."""
     lib = _lib_()
     w = _f32(w, "occ_conv.w").contiguous()
     K, cout = w.shape
@@ -865,7 +879,7 @@ def match_pose_batch_async(feats0, feats1, pts0, pts1, max_dist, edge_ratio=0.9,
                                            sb, C.c_void_p(slots.data_ptr()), st))
     pf = PendingFetch.__new__(PendingFetch)
     pf._host = slots
-    pf.event = torch.cuda.Event()
+    pf.event = fetch_event()
     pf.event.record()
     pf._keep = (keep, scratch, descs)
 

@@ -8,6 +8,9 @@ rank (pairs done, seconds, max errors) -- RCCL over xGMI on the GPU box
 """
 from __future__ import annotations
 
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -73,3 +76,63 @@ def gather_poses(poses, n_total: int, device):
         a, b = shard_range(n_total, r, world)
         parts.append(out[r][:b - a].cpu())
     return torch.cat(parts)
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(rank: int, world: int, port: int, base=None):
+    """Environment of rank `rank` of a one-node job of `world` ranks: the variables torch.distributed.run would set."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    return env
+
+
+def launch_ranks(cmd, world: int, timeout_s: float = None, grace_s: float = 20.0) -> int:
+    """Start `world` child processes of `cmd` (one per GPU; rank r gets rank_env(r)), wait for all of them and return 0
+    if every one exited 0, else the first non-zero exit code.  Rank 0 inherits stdout (its JSON line is the job's
+    output); the other ranks' stdout is folded into stderr.  The caller must not have initialised the GPU: children
+    are fresh processes (subprocess.Popen), nothing is exec'ed over a process that holds a HIP context.  When a rank
+    fails, the others get `grace_s` seconds (they usually fail the same way or hang in a collective) and are then
+    killed by PID."""
+    import subprocess
+    import time
+    if world < 1:
+        raise ValueError("launch_ranks: world must be >= 1")
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(list(cmd), env=rank_env(r, world, port),
+                                      stdout=None if r == 0 else sys.stderr))
+    t0 = time.monotonic()
+    first_bad, bad_at = 0, None
+    live = set(range(world))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and first_bad == 0:
+                first_bad, bad_at = rc, time.monotonic()
+                print(f"[launch_ranks] rank {r} exited with code {rc}", file=sys.stderr, flush=True)
+        now = time.monotonic()
+        expired = timeout_s is not None and now - t0 > timeout_s
+        if live and (expired or (bad_at is not None and now - bad_at > grace_s)):
+            for r in sorted(live):
+                procs[r].kill()
+                procs[r].wait()
+            live.clear()
+            if first_bad == 0:
+                first_bad = 124
+        if live:
+            time.sleep(0.05)
+    return first_bad

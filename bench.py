@@ -6,7 +6,7 @@ voxel hash -> sparse ResUNet encode (both frames) -> feature NN -> RANSAC(4 M
 iterations, the reference's criteria) + Kabsch, with the raw xyz of the pair
 already resident in HBM when the timed region starts (BASELINE config[1]).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts its N ranks itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, independent pairs per rank (no data-path
@@ -338,6 +338,22 @@ def extra_workloads(dev, log):
         return F
 
     base_rate, _ = pipelined_rate(ppipe)
+    # ---- BASELINE config 2 read literally (FCGF_APR/scripts/test_apr.py:111-163 runs batch size 1): ONE pair per call, one
+    # stream, nothing else in flight -- voxelise both frames, one encoder call on the two frames, NN, RANSAC(4 M), pose
+    # fetched before the next pair starts
+    for i_ in range(6):
+        ppipe.register_batch([pool6[i_]], seeds=[i_])
+    n1 = 60
+    t0 = sync()
+    for i_ in range(n1):
+        ppipe.register_batch([pool6[i_ % 6]], seeds=[i_])
+    t1 = sync()
+    out["fcgf_one_pair"] = {
+        "workload": "BASELINE config 2 literally: FCGF_APR encode+match+SVD (ResUNetBN2C / 32, RANSAC 4 M), ONE 2 x 118 k-point "
+                    "pair per call on one stream, the pose on the host before the next pair starts (the reference loop's "
+                    "shape, test_apr.py:111-163); 6 distinct pairs cycled",
+        "value": n1 / (t1 - t0), "unit": "pairs/s", "ms_per_pair": 1e3 * (t1 - t0) / n1}
+    log(f"workloads: one pair at a time {n1 / (t1 - t0):.1f} pairs/s ({1e3 * (t1 - t0) / n1:.3f} ms per pair)")
     ppipe.feature_hook = plant
     plant_rate, res_p = pipelined_rate(ppipe)
     errs = []
@@ -463,9 +479,20 @@ def extra_workloads(dev, log):
 
 def main():
     args = parse()
+    # --gpus N without a launcher around it: start the N ranks ourselves, one fresh child process of this script per GPU
+    # (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), relay rank 0's JSON line and
+    # fail if any rank does.  Nothing has touched the GPU in this process yet, and it never will: children only, no exec.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from apr_amd import shard
+        print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks of this script",
+              file=sys.stderr, flush=True)
+        raise SystemExit(shard.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must "
+                         "agree (the JSON line reports n_gpus = WORLD_SIZE)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # rehearsal switches (1-GPU box): APR_BENCH_BACKEND=gloo + APR_BENCH_SINGLE_DEVICE=1 run N ranks on cuda:0
@@ -482,7 +509,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from apr_amd import ops, shard, synth
+    from apr_amd import _host, ops, shard, synth
     if args.match_lanes > 0:
         ops.set_match_lanes(args.match_lanes)
     from apr_amd.fcgf.pipeline import PairRegistration
@@ -651,12 +678,14 @@ def main():
     first = nprime + args.warmup
     poses4.clear()
     barrier()
+    cpu0 = time.process_time()               # CPU seconds of ALL threads of this rank (user + system)
     t0 = time.perf_counter()
     run_steps(first, first + args.steps)     # EXACTLY `steps` steps, `streams` in flight
     T, info = results[first + args.steps - 1]
     torch.cuda.synchronize()
     barrier()
     elapsed_local = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0
     elapsed = shard.max_over_ranks(elapsed_local, dev if backend == "nccl" else torch.device("cpu"))   # all-reduce(MAX)
     if not pipelined:
         job["stop"] = True
@@ -678,7 +707,7 @@ def main():
             log(f"  step {i - first:4d} worker {w} start {1e3 * (ta - t0):8.2f} ms  host {1e3 * (tb - ta):7.2f} ms")
     log(f"steady state: median step-completion interval {steady_ms:.3f} ms vs mean {1e3 * elapsed / args.steps:.3f} ms")
     # end-of-run stats of every rank: one all_gather of a few floats
-    stats = shard.gather_stats([len(pairs) if cfg4 else args.steps * B, elapsed_local, float(info["n_valid"])],
+    stats = shard.gather_stats([len(pairs) if cfg4 else args.steps * B, elapsed_local, float(info["n_valid"]), host_cpu_s],
                                dev if backend == "nccl" else torch.device("cpu"))
     out = {
         "metric": "point-cloud pairs/sec (120k-pt KITTI frame, FCGF encode+match+SVD)",
@@ -709,6 +738,12 @@ def main():
                        "poses_gathered": list(all_poses.shape),
                        "mode": "BASELINE config 4: the pair list cut into contiguous blocks over the ranks, seeds = global "
                                "pair index, every pair registered once, poses gathered at the end"} if cfg4 else {}),
+                   # host cost of a rank: CPU seconds (all threads, user + system) per step and as a share of one CPU over
+                   # the timed region; 8 ranks need 8 x host_cpus_busy CPUs of the node's quota
+                   "host_cpu_s_per_step": host_cpu_s / args.steps,
+                   "host_cpus_busy": host_cpu_s / elapsed_local,
+                   "host_cpu_quota": _host.cpu_quota(), "blocking_fetch_events": ops.BLOCKING_EVENTS,
+                   "per_rank_host_cpus_busy": [float(r[3] / r[1]) for r in stats.tolist()],
                    "per_rank_pairs_per_s": [float(r[0] / r[1]) for r in stats.tolist()]},
     }
 

@@ -122,11 +122,16 @@ int apr_kernel_map(const int32_t* out_coords, int64_t n_out, const int32_t* n_ou
  * and needs occupancy, not a neighbour table.  apr_coords_bbox: bbox_dev int32[8] <- {min x, y, z, max x, y, z, max
  * batch index, 0} of coords int32[n,4] (batch, x, y, z).  apr_occ_conv: the voxels are scattered into a bitmap over
  * that box (scratch: apr_occ_conv_scratch_bytes(bbox, ks), 0 = box empty / too large -> use apr_kernel_map +
- * apr_spconv) and every voxel reads the ks x-neighbours of a (dy, dz) row with one 8-byte load.  coords: unique rows,
- * all inside bbox_host; offsets x-fastest as apr_kernel_map; w f32[ks^3, cout], cout % 8 == 0, ks in {3, 5, 7}; same
- * bits as apr_spconv over the apr_kernel_map table on all-ones features. */
+ * apr_spconv; apr_occ_conv_pays(bbox, ks, n): 1 if the bitmap is also small against the n voxels it serves, at most
+ * 1 KB per voxel + 4 MB -- an outlier voxel can stretch the box to gigabytes, and then the kernel map is the cheaper
+ * structure) and every voxel reads the ks x-neighbours of a (dy, dz) row with one 8-byte load.  coords: unique rows;
+ * bbox_host is in VOXEL units (the coords' own units) and must contain every row -- a row outside it is skipped as a
+ * neighbour and gets a NaN output row, no access ever leaves the bitmap; offsets x-fastest as apr_kernel_map;
+ * w f32[ks^3, cout], cout % 8 == 0, ks in {3, 5, 7}; same bits as apr_spconv over the apr_kernel_map table on all-ones
+ * features. */
 int apr_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox_dev, void* stream);
 size_t apr_occ_conv_scratch_bytes(const int32_t* bbox_host, int32_t kernel_size);
+int apr_occ_conv_pays(const int32_t* bbox_host, int32_t kernel_size, int64_t n);
 int apr_occ_conv(const int32_t* coords, int64_t n, const int32_t* bbox_host, int32_t kernel_size, const float* w,
                  int32_t cout, const float* scale, const float* shift, const float* residual, int64_t ldr,
                  int32_t relu, float* out, int64_t ldo, void* scratch, size_t scratch_bytes, void* stream);

@@ -57,3 +57,47 @@ def test_shard_range_edge_cases():
     assert shard.shard_range(512, 7, 8) == (448, 512)
     assert shard.gather_stats([1, 2], torch.device("cpu")).shape == (1, 2)   # no process group: world of one
     assert shard.gather_poses(torch.eye(4).repeat(3, 1, 1), 3, torch.device("cpu")).shape == (3, 4, 4)
+
+
+# ---- bench.py --gpus N starts its own ranks (apr_amd.shard.launch_ranks) ----
+
+def test_launch_ranks_env_plumbing(tmp_path, capfd):
+    import json
+    import sys
+    code = ("import os, json, sys; r = os.environ['RANK'];"
+            "json.dump({k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',"
+            " 'HSA_ENABLE_IPC_MODE_LEGACY')}, open(os.path.join(sys.argv[1], r + '.json'), 'w'));"
+            "print('line from rank ' + r)")
+    assert shard.launch_ranks([sys.executable, "-c", code, str(tmp_path)], 3, timeout_s=60) == 0
+    envs = [json.load(open(tmp_path / f"{r}.json")) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert {e["WORLD_SIZE"] for e in envs} == {"3"} and {e["MASTER_ADDR"] for e in envs} == {"127.0.0.1"}
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and envs[0]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out, err = capfd.readouterr()
+    assert out.strip() == "line from rank 0"                      # only rank 0 owns stdout (the JSON line)
+    assert "line from rank 1" in err and "line from rank 2" in err
+
+
+def test_launch_ranks_failure_propagates_and_stragglers_are_killed():
+    import sys
+    import time
+    code = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(120)"
+    t0 = time.monotonic()
+    assert shard.launch_ranks([sys.executable, "-c", code], 2, grace_s=0.5) == 3
+    assert time.monotonic() - t0 < 30
+
+
+def test_bench_gpus_flag_plumbing():
+    """bench.py --gpus 2 with no launcher around it starts two ranks itself (here they stop at "needs a GPU", non-zero);
+    a launcher whose WORLD_SIZE disagrees with --gpus is refused before anything else happens."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if not torch.cuda.is_available():
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and "launching 2 ranks" in p.stderr and p.stderr.count("needs a GPU") == 2, p.stderr
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in p.stderr, p.stderr

@@ -366,6 +366,33 @@ def test_occupancy_conv_equals_kernel_map_path(dev, ks, cout, n, nbatch, lo, hi,
     # a box that would need more than 2 GB of bitmap is declined (the caller keeps the kernel-map path)
     assert not ops.occ_conv_supported([0, 0, 0, 1 << 20, 1 << 20, 64, 0, 0], ks, cout)
     assert not ops.occ_conv_supported(bbox, ks, cout + 1)
+    # a box stretched by one far outlier voxel: still under 2 GB, but far more bitmap than voxels -> declined when the
+    # caller states the voxel count (the kernel-map path is cheaper there)
+    far, ext = list(bbox), 64
+    while ops.occ_conv_supported(far, ks, cout, n=N) and ext < (1 << 22):
+        ext *= 2
+        far[3], far[4] = bbox[3] + ext, bbox[4] + ext // 8
+    assert ops.occ_conv_supported(far, ks, cout) and not ops.occ_conv_supported(far, ks, cout, n=N)
+    assert ops.occ_conv_supported(bbox, ks, cout, n=N)
+    # a box that MISSES voxels (host-supplied, so it can be wrong): no access leaves the bitmap; the missed voxels come out
+    # as NaN rows, voxels whose whole neighbourhood avoids the missed ones are unchanged
+    if n > 1:
+        small = list(bbox)
+        small[3] = bbox[3] - 3                       # cut the top 3 x-layers
+        small[6] = bbox[6]
+        out_small = ops.occ_conv(m.coords, N, small, ks, W.view(K, cout).to(dev))
+        ref_full = ops.spconv(ones, nbr, K, 1, cout, wp, n_out=N)
+        cx = m.coords[:N, 1]
+        missed = cx > small[3]
+        assert bool(missed.any()) and bool(torch.isnan(out_small[missed]).all())
+        safe = cx <= small[3] - ks // 2
+        assert bool(torch.isfinite(out_small[~missed]).all()) and torch.equal(out_small[safe], ref_full[safe])
+        if nbatch > 1:                               # a batch index above the box's: NaN rows as well
+            nb_small = list(bbox)
+            nb_small[6] = bbox[6] - 1
+            out_b = ops.occ_conv(m.coords, N, nb_small, ks, W.view(K, cout).to(dev))
+            gone = m.coords[:N, 0] > nb_small[6]
+            assert bool(torch.isnan(out_b[gone]).all()) and torch.equal(out_b[~gone], ref_full[~gone])
 
 
 @pytest.mark.parametrize("cin,cout,n,K", [(64, 32, 5000, 1), (64, 32, 70001, 1), (96, 64, 3000, 1), (32, 32, 2500, 27),
