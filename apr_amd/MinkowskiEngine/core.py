@@ -65,6 +65,7 @@ class CoordinateManager:
         self._kmaps = {}
         self._plists = {}
         self._plist_counters = None
+        self._tpool = None
         self._bbox = None
         self.device = self.maps[1].keys.device
 
@@ -86,7 +87,7 @@ class CoordinateManager:
             strides = [ts for ts in self.maps if ts != 1]
             self.maps = {1: self._dedup}
             self._dedup = None
-            self._kmaps, self._plists = {}, {}
+            self._kmaps, self._plists, self._tpool = {}, {}, None
             self.build_pyramid(strides)
         m1 = self.maps[1]
         if not self._adopted and m1.n != m1.n_in:
@@ -104,7 +105,11 @@ class CoordinateManager:
         pend = [m for m in self.maps.values() if m.n is None]
         if self._dedup is not None and self._dedup.n is None:
             pend.append(self._dedup)
-        pf = ops.finalize_maps_async(pend, extras)
+        if self._plist_counters is None:      # cleared by the launch that gathers the sizes (no fill of their own)
+            self._plist_counters = torch.empty((16, ops.pair_counter_ints()), dtype=torch.int32, device=self.device)
+            pf = ops.finalize_maps_async(pend, extras, zero=self._plist_counters)
+        else:
+            pf = ops.finalize_maps_async(pend, extras)
         inner = pf._then
 
         def then(host):
@@ -168,13 +173,31 @@ class CoordinateManager:
                 # coarse -> fine: the transpose of the strided fine -> coarse table (same (fine, coarse, offset)
                 # triples), which the encoder builds anyway: a scatter instead of n_fine * K hash probes
                 fwd = self.kernel_map(ts_out, ts_in, kernel_size, False)
-                nbr = ops.kernel_map_transpose(fwd, out_map.n)
+                nbr = ops.kernel_map_transpose(fwd, out_map.n, prefilled=self._transposed_table(ts_out, kernel_size))
             else:
                 # regular: c_in = c_out + o*ts_in ; transposed (coarse->fine): c_coarse = c_fine - o*ts_fine
                 scale = -ts_out if transpose else ts_in
                 nbr = ops.kernel_map(out_map, in_map, kernel_size, scale)
             self._kmaps[key] = nbr
         return nbr
+
+    def _transposed_table(self, ts_fine, kernel_size):
+        """A -1-filled int32 [n(ts_fine), kernel_size^3] table for the transposed map onto level ts_fine.  The tables of
+        ALL levels that have a coarser level above them come out of one allocation cleared by ONE fill (an encoder asks for
+        three of them, one per decoder level); None when the pool does not cover the request."""
+        if kernel_size != 3:
+            return None
+        if self._tpool is None:
+            self._finalize()
+            levels = [ts for ts in sorted(self.maps) if 2 * ts in self.maps]
+            sizes = [self.maps[ts].n * 27 for ts in levels]
+            buf = torch.empty(max(sum(sizes), 1), dtype=torch.int32, device=self.device)
+            ops.fill_bytes(buf, 0xFF)
+            self._tpool, pos = {}, 0
+            for ts, sz in zip(levels, sizes):
+                self._tpool[ts] = buf[pos:pos + sz].view(-1, 27)
+                pos += sz
+        return self._tpool.pop(ts_fine, None)      # handed out once: the table is written into
 
     def pair_list(self, ts_in, ts_out, kernel_size, transpose=False):
         """Per-offset pair lists of kernel_map(...) for the weight-stationary conv path (cached per map)."""

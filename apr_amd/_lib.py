@@ -123,6 +123,11 @@ PROTOTYPES = {
     "apr_edge_features": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "apr_group_max": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _f32, _p, _i64, _p]),
     "apr_coords_bbox": (C.c_int, [_p, _i64, _p, _p]),
+    "apr_voxelize_frames": (C.c_int, [_p, _p, _i32, _f32, _p, _p, _p]),
+    "apr_gather_frame_points": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p]),
+    "apr_pack_i32": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p]),
+    "apr_fill_bytes": (C.c_int, [_p, _i32, _sz, _p]),
+    "apr_kernel_map_transpose_prefilled": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     "apr_occ_conv_scratch_bytes": (_sz, [_p, _i32]),
     "apr_occ_conv_pays": (C.c_int, [_p, _i32, _i64]),
     "apr_occ_conv": (C.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _p, _i64, _p, _sz, _p]),

@@ -278,6 +278,63 @@ __global__ void k_map_transpose(const int* __restrict__ nbr, int64_t total, int 
   if (i >= 0) nbr_t[(int64_t)i * K + (int)(t % K)] = (int)(t / K);
 }
 
+// ---- a batch of frames without a concatenated copy: the frame pointers and start offsets travel in the kernel arguments ----
+constexpr int kMaxFrames = APR_MAX_FRAMES;
+struct FrameTable {
+  const float* ptr[kMaxFrames];
+  long long off[kMaxFrames + 1];      // off[b] = points before frame b; off[nseg] = total
+  int nseg;
+};
+
+__device__ inline int frame_of(const FrameTable& ft, long long i) {
+  int b = 0;
+  while (b + 1 < ft.nseg && i >= ft.off[b + 1]) ++b;
+  return b;
+}
+
+// coords[i] = (frame of point i, floor(xyz / vs)) over the virtual concatenation of the frames; thread 0 also leaves the
+// offsets on the device for the kernels behind it (apr_segment_counts)
+__global__ void k_voxelize_frames(FrameTable ft, int64_t n, float vs, int4* __restrict__ coords,
+                                  long long* __restrict__ offsets_out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x <= ft.nseg && offsets_out) offsets_out[threadIdx.x] = ft.off[threadIdx.x];
+  if (i >= n) return;
+  const int b = frame_of(ft, i);
+  const float* p = ft.ptr[b] + 3 * (i - ft.off[b]);
+  float x = p[0] / vs, y = p[1] / vs, z = p[2] / vs;
+  coords[i] = make_int4(b, (int)floorf(x), (int)floorf(y), (int)floorf(z));
+}
+
+// pts[r] = the point (of the virtual concatenation) that first[r] names, r < *n_dev
+__global__ void k_gather_frame_points(FrameTable ft, const long long* __restrict__ first, const int* __restrict__ n_dev,
+                                      float* __restrict__ pts) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_dev) return;
+  const long long i = first[r];
+  const int b = frame_of(ft, i);
+  const float* p = ft.ptr[b] + 3 * (i - ft.off[b]);
+  pts[3 * r + 0] = p[0];
+  pts[3 * r + 1] = p[1];
+  pts[3 * r + 2] = p[2];
+}
+
+// Small int32 device arrays -> one contiguous block (the sizes / flags a step fetches in one copy), and a block of words
+// cleared on the way (the pair-list counters of the encode that follows)
+constexpr int kMaxPack = APR_MAX_PACK;
+struct PackTable {
+  const int* src[kMaxPack];
+  int begin[kMaxPack + 1];
+  int nsrc;
+};
+__global__ void k_pack_i32(PackTable pt, int* __restrict__ dst, int* __restrict__ zero_ptr, long long zero_words) {
+  for (int s = 0; s < pt.nsrc; ++s) {
+    const int n = pt.begin[s + 1] - pt.begin[s];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) dst[pt.begin[s] + e] = pt.src[s][e];
+  }
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < zero_words; e += (long long)gridDim.x * blockDim.x)
+    zero_ptr[e] = 0;
+}
+
 }  // namespace
 
 APR_API int64_t apr_hash_capacity(int64_t n) {
@@ -341,16 +398,34 @@ APR_API int apr_map_build(const int32_t* coords_in, int64_t n, const int32_t* n_
   return APR_OK;
 }
 
-APR_API int apr_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t,
-                                     void* stream) {
+static int map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t, bool prefilled,
+                         void* stream) {
   APR_CHECK_ARG(n_out >= 0 && n_in >= 0 && K >= 1 && (nbr || n_out == 0) && (nbr_t || n_in == 0),
                 "apr_kernel_map_transpose: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (n_in > 0) APR_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * K * 4, st));      // -1 everywhere
+  if (n_in > 0 && !prefilled) APR_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * K * 4, st));      // -1 everywhere
   if (n_out > 0)
     hipLaunchKernelGGL(k_map_transpose, dim3((unsigned)cdiv64(n_out * K, kBlock)), dim3(kBlock), 0, st, nbr,
                        n_out * (int64_t)K, K, nbr_t);
   APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t,
+                                     void* stream) {
+  return map_transpose(nbr, n_out, K, n_in, nbr_t, false, stream);
+}
+
+// the same into a table the caller has already filled with -1 (apr_fill_bytes 0xFF): the transposed tables of an encoder's
+// three decoder levels then share ONE fill
+APR_API int apr_kernel_map_transpose_prefilled(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t,
+                                               void* stream) {
+  return map_transpose(nbr, n_out, K, n_in, nbr_t, true, stream);
+}
+
+APR_API int apr_fill_bytes(void* ptr, int32_t byte_value, size_t bytes, void* stream) {
+  APR_CHECK_ARG(ptr || bytes == 0, "apr_fill_bytes: null pointer");
+  if (bytes) APR_HIP(hipMemsetAsync(ptr, byte_value, bytes, (hipStream_t)stream));
   return APR_OK;
 }
 
@@ -360,6 +435,77 @@ APR_API int apr_voxelize_segments(const float* xyz, int64_t n, float voxel_size,
   if (n == 0) return APR_OK;
   hipLaunchKernelGGL(k_voxelize_segments, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, xyz, n,
                      voxel_size, (const long long*)offsets, nseg, (int4*)coords);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+
+static int fill_frame_table(FrameTable& ft, const float* const* frames, const int64_t* offsets, int32_t nseg) {
+  APR_CHECK_ARG(frames && offsets && nseg >= 1 && nseg <= kMaxFrames, "frame table: 1 <= frames <= %d", kMaxFrames);
+  APR_CHECK_ARG(offsets[0] == 0, "frame table: offsets[0] must be 0");
+  for (int b = 0; b < nseg; ++b) {
+    APR_CHECK_ARG(offsets[b + 1] >= offsets[b] && (frames[b] || offsets[b + 1] == offsets[b]), "frame table: bad frame %d", b);
+    ft.ptr[b] = frames[b];
+    ft.off[b] = offsets[b];
+  }
+  ft.off[nseg] = offsets[nseg];
+  ft.nseg = nseg;
+  return APR_OK;
+}
+
+// The voxelisation of a BATCH of frames (FCGF_APR/lib/complement_data_loader.py:788-812 per frame) without first copying
+// them into one array: frames_host[b] = device pointer of frame b (f32 [n_b, 3], contiguous), offsets_host[b] = points
+// before frame b (offsets_host[nseg] = total).  coords int32 [total, 4] <- (b, floor(xyz / voxel_size)) in frame order;
+// offsets_dev (optional, int64 [nseg + 1]) receives the offsets for apr_segment_counts.
+APR_API int apr_voxelize_frames(const float* const* frames_host, const int64_t* offsets_host, int32_t nseg, float voxel_size,
+                                int32_t* coords, int64_t* offsets_dev, void* stream) {
+  FrameTable ft;
+  if (int rc = fill_frame_table(ft, frames_host, offsets_host, nseg)) return rc;
+  APR_CHECK_ARG(voxel_size > 0.f && coords, "apr_voxelize_frames: bad arguments");
+  const int64_t n = offsets_host[nseg];
+  hipLaunchKernelGGL(k_voxelize_frames, dim3((unsigned)(n > 0 ? cdiv64(n, kBlock) : 1)), dim3(kBlock), 0, (hipStream_t)stream, ft,
+                     n, voxel_size, (int4*)coords, (long long*)offsets_dev);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// pts f32 [*n_dev, 3] <- the input point behind every row of a map built with want_first over the same frames (first:
+// index into their virtual concatenation); n_max = rows allocated (upper bound of *n_dev, sizes the grid).
+APR_API int apr_gather_frame_points(const float* const* frames_host, const int64_t* offsets_host, int32_t nseg,
+                                    const int64_t* first, const int32_t* n_dev, int64_t n_max, float* pts, void* stream) {
+  FrameTable ft;
+  if (int rc = fill_frame_table(ft, frames_host, offsets_host, nseg)) return rc;
+  APR_CHECK_ARG(first && n_dev && pts && n_max >= 0, "apr_gather_frame_points: bad arguments");
+  if (n_max == 0) return APR_OK;
+  hipLaunchKernelGGL(k_gather_frame_points, dim3((unsigned)cdiv64(n_max, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, ft,
+                     (const long long*)first, n_dev, pts);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// dst <- srcs_host[0][0 .. counts_host[0]) ++ srcs_host[1][...] ++ ... (device int32 arrays, nsrc <= APR_MAX_PACK), and
+// zero_words int32 words at zero_ptr cleared (NULL / 0: nothing): the map sizes, status flags, frame row counts and bounding
+// box a step brings to the host travel as ONE block, gathered by ONE launch.
+APR_API int apr_pack_i32(const int32_t* const* srcs_host, const int32_t* counts_host, int32_t nsrc, int32_t* dst,
+                         int32_t* zero_ptr, int64_t zero_words, void* stream) {
+  APR_CHECK_ARG(nsrc >= 0 && nsrc <= kMaxPack && (nsrc == 0 || (srcs_host && counts_host && dst)) && zero_words >= 0 &&
+                    (zero_words == 0 || zero_ptr),
+                "apr_pack_i32: bad arguments (at most %d sources)", kMaxPack);
+  PackTable pt;
+  pt.nsrc = nsrc;
+  pt.begin[0] = 0;
+  int64_t words = 0;
+  for (int s = 0; s < nsrc; ++s) {
+    APR_CHECK_ARG(counts_host[s] >= 0 && (srcs_host[s] || counts_host[s] == 0), "apr_pack_i32: bad source %d", s);
+    pt.src[s] = srcs_host[s];
+    words += counts_host[s];
+    APR_CHECK_ARG(words < (1 << 30), "apr_pack_i32: too many words");
+    pt.begin[s + 1] = (int)words;
+  }
+  if (nsrc == 0 && zero_words == 0) return APR_OK;
+  int64_t nblk = cdiv64(zero_words > words ? zero_words : words, 256 * 8);
+  nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
+  hipLaunchKernelGGL(k_pack_i32, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pt, dst, zero_ptr, (long long)zero_words);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

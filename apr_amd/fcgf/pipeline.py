@@ -35,6 +35,7 @@ class PairRegistration:
         # (bench.py: descriptors with a controlled share of true matches stand in for a trained checkpoint's output; the
         # encoder still runs)
         self.feature_hook = None
+        self._ones_cache = {}
 
     @torch.no_grad()
     def voxelize_pair(self, xyz0, xyz1):
@@ -62,24 +63,32 @@ class PairRegistration:
         host sync fetches every size (12 + 4 builds and 2 syncs per step become 4 builds and 1 sync)."""
         if len(clouds) > 1023:
             raise ValueError("at most 1023 frames per batch (10-bit batch index in the voxel key; 1023 is reserved for the empty-slot key)")
-        dev = clouds[0].device
-        npts = [int(c.shape[0]) for c in clouds]
-        offs = [0]
-        for n in npts:
-            offs.append(offs[-1] + n)
-        xyz_all = torch.cat(clouds) if len(clouds) > 1 else clouds[0].contiguous()     # one 17 MB copy per 12-frame step
-        offs_dev = torch.tensor(offs, dtype=torch.int64).to(dev, non_blocking=True)
-        coords_all = ops.voxelize_segments(xyz_all, self.voxel_size, offs_dev)         # one launch for all frames
+        coords_all, offs_dev, offs, gather = self._voxelize_frames(clouds)
         m = ops.build_map(coords_all, want_first=True)
         counts_dev = ops.segment_counts(m, offs_dev)
         bbox_dev = ops.coords_bbox(coords_all)         # for conv1 on occupancy (ops.occ_conv); fetched with the sizes
-        cm = ME.CoordinateManager(base_map=m)
+        pts_all = gather(m)                            # representative point of every voxel row (frame b = rows
+        cm = ME.CoordinateManager(base_map=m)          # sum(counts[:b]) .. + counts[b], contiguous)
         counts, bbox = cm.build_pyramid([2, 4, 8], extras=[counts_dev, bbox_dev])
         cm.set_bbox(bbox)
-        # representative point of every voxel row: ONE gather over the concatenated points (frame b = rows
-        # sum(counts[:b]) .. + counts[b], contiguous)
-        pts_all = xyz_all[m.first]
+        pts_all = pts_all[:m.n]
         return cm, [int(c) for c in counts], m.first, offs, pts_all
+
+    def _voxelize_frames(self, clouds):
+        """-> (coords int32 [sum n, 4] with the frame index as batch id, offsets on the device, offsets as a list, gather):
+        `gather(m)` returns the input point behind every row of the map `m` built over these coords (f32 [rows, 3], rows =
+        the allocation's upper bound until the map is finalised).  Up to ops.MAX_FRAMES frames go through the library's
+        frame-table kernels (no concatenated copy of the points, no torch op); beyond that the frames are concatenated."""
+        if len(clouds) <= ops.MAX_FRAMES:
+            coords_all, offs_dev, offs = ops.voxelize_frames(clouds, self.voxel_size)
+            return coords_all, offs_dev, offs, lambda m: ops.gather_frame_points(clouds, m)
+        offs = [0]
+        for c in clouds:
+            offs.append(offs[-1] + int(c.shape[0]))
+        xyz_all = torch.cat(clouds)
+        offs_dev = torch.tensor(offs, dtype=torch.int64).to(clouds[0].device, non_blocking=True)
+        coords_all = ops.voxelize_segments(xyz_all, self.voxel_size, offs_dev)
+        return coords_all, offs_dev, offs, lambda m: xyz_all[m.first]
 
     @torch.no_grad()
     def register_batch_phases(self, pairs, seeds=None):
@@ -92,23 +101,18 @@ class PairRegistration:
         if len(clouds) > 1023:
             raise ValueError("at most 1023 frames per batch (10-bit batch index in the voxel key; 1023 is reserved "
                              "for the empty-slot key)")
-        dev = clouds[0].device
-        offs = [0]
-        for c in clouds:
-            offs.append(offs[-1] + int(c.shape[0]))
-        xyz_all = torch.cat(clouds) if len(clouds) > 1 else clouds[0].contiguous()
-        offs_dev = torch.tensor(offs, dtype=torch.int64).to(dev, non_blocking=True)
-        coords_all = ops.voxelize_segments(xyz_all, self.voxel_size, offs_dev)
+        coords_all, offs_dev, offs, gather = self._voxelize_frames(clouds)
         m = ops.build_map(coords_all, want_first=True)
         counts_dev = ops.segment_counts(m, offs_dev)
         bbox_dev = ops.coords_bbox(coords_all)         # for conv1 on occupancy (ops.occ_conv); fetched with the sizes
+        pts_all = gather(m)                            # enqueued before the fetch: the host does not wait for it
         cm = ME.CoordinateManager(base_map=m)
         pending = cm.build_pyramid_async([2, 4, 8], extras=[counts_dev, bbox_dev])
         yield pending
         counts, bbox = pending.finish()
         cm.set_bbox(bbox)
         counts = [int(c) for c in counts]
-        pts_all = xyz_all[m.first]
+        pts_all = pts_all[:m.n]
         F = self.encode_batch(cm)
         if self.feature_hook is not None:
             F = self.feature_hook(F, counts, pairs)
@@ -127,10 +131,18 @@ class PairRegistration:
             out.append((T, info))
         return out
 
+    def _ones(self, n, dev):
+        """[n, 1] view of a cached all-ones column (FCGF's input features, complement_data_loader.py:805-812): no fill per
+        step.  Read-only by contract (SparseTensor(unit_features=True))."""
+        cache = self._ones_cache.get(dev)
+        if cache is None or cache.shape[0] < n:
+            cache = self._ones_cache[dev] = torch.ones((max(n, 1 << 18), 1), dtype=torch.float32, device=dev)
+        return cache[:n]
+
     @torch.no_grad()
     def encode_batch(self, cm):
         n = cm.size(1)
-        feats = torch.ones((n, 1), dtype=torch.float32, device=cm.device)
+        feats = self._ones(n, cm.device)
         return self.model(ME.SparseTensor(feats, coordinate_map_key=ME.CoordinateMapKey(1), coordinate_manager=cm,
                                           unit_features=True)).F
 

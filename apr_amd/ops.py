@@ -52,14 +52,102 @@ def voxelize(xyz: torch.Tensor, voxel_size: float, batch: int = 0, out=None) -> 
     return coords
 
 
-def kernel_map_transpose(nbr: torch.Tensor, n_in: int) -> torch.Tensor:
-    """nbr int32 [n_out, K] over an n_in-row input map -> its transpose int32 [n_in, K] (see apr_kernel_map_transpose)."""
+def kernel_map_transpose(nbr: torch.Tensor, n_in: int, prefilled=None) -> torch.Tensor:
+    """nbr int32 [n_out, K] over an n_in-row input map -> its transpose int32 [n_in, K] (see apr_kernel_map_transpose).
+    `prefilled`: a contiguous int32 [n_in, K] tensor that already holds -1 everywhere (fill_bytes(.., 0xFF)); the scatter
+    then runs without a fill of its own."""
     if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2:
         raise _lib.AprHipError("kernel_map_transpose: nbr must be a contiguous int32 [n_out, K] tensor")
     n_out, K = nbr.shape
+    if prefilled is not None:
+        if prefilled.dtype != torch.int32 or tuple(prefilled.shape) != (n_in, K) or not prefilled.is_contiguous():
+            raise _lib.AprHipError("kernel_map_transpose: prefilled table must be contiguous int32 [n_in, K]")
+        check(_lib_().apr_kernel_map_transpose_prefilled(ptr(nbr), n_out, K, n_in, ptr(prefilled), stream()))
+        return prefilled
     out = torch.empty((n_in, K), dtype=torch.int32, device=nbr.device)
     check(_lib_().apr_kernel_map_transpose(ptr(nbr), n_out, K, n_in, ptr(out), stream()))
     return out
+
+
+def fill_bytes(t: torch.Tensor, byte_value: int):
+    """Every byte of the contiguous GPU tensor `t` <- byte_value (hipMemsetAsync on the current stream)."""
+    if not t.is_cuda or not t.is_contiguous():
+        raise _lib.AprHipError("fill_bytes: need a contiguous GPU tensor")
+    check(_lib_().apr_fill_bytes(ptr(t), int(byte_value), t.numel() * t.element_size(), stream()))
+    return t
+
+
+MAX_FRAMES = 64      # APR_MAX_FRAMES
+
+
+def _frame_table(clouds):
+    n = len(clouds)
+    ptrs = (C.c_void_p * n)()
+    offs = (C.c_int64 * (n + 1))()
+    keep = []
+    for b, c in enumerate(clouds):
+        c = _f32(c, "frames").contiguous()
+        if c.dim() != 2 or c.shape[1] != 3:
+            raise _lib.AprHipError("frames: every frame must be float32 [n, 3]")
+        keep.append(c)
+        ptrs[b] = c.data_ptr()
+        offs[b + 1] = offs[b] + c.shape[0]
+    return ptrs, offs, keep
+
+
+def voxelize_frames(clouds, voxel_size: float):
+    """Frames (list of f32 [n_b, 3] GPU tensors, at most MAX_FRAMES) -> (coords int32 [sum n_b, 4] with the frame index as
+    batch id, offsets int64 GPU [len + 1], offsets as a Python list).  No concatenated copy of the points is made: the frame
+    pointers travel in the kernel arguments (apr_voxelize_frames)."""
+    if not 1 <= len(clouds) <= MAX_FRAMES:
+        raise _lib.AprHipError(f"voxelize_frames: 1 .. {MAX_FRAMES} frames")
+    ptrs, offs, keep = _frame_table(clouds)
+    n = int(offs[len(clouds)])
+    dev = keep[0].device
+    coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    offs_dev = torch.empty(len(clouds) + 1, dtype=torch.int64, device=dev)
+    check(_lib_().apr_voxelize_frames(ptrs, offs, len(clouds), float(voxel_size), ptr(coords), ptr(offs_dev), stream()))
+    return coords, offs_dev, [int(o) for o in offs]
+
+
+def gather_frame_points(clouds, m):
+    """The input point behind every row of map `m` (built with want_first over voxelize_frames(clouds)): f32 [rows, 3], rows =
+    m.n when known, else the allocation's upper bound (only the first *m.n_dev rows are written).  No sync."""
+    if m.first is None:
+        raise _lib.AprHipError("gather_frame_points: build the map with want_first=True")
+    ptrs, offs, keep = _frame_table(clouds)
+    n_max = int(m.first.shape[0])
+    pts = torch.empty((n_max, 3), dtype=torch.float32, device=m.first.device)
+    check(_lib_().apr_gather_frame_points(ptrs, offs, len(clouds), ptr(m.first), ptr(m.n_dev), n_max, ptr(pts), stream()))
+    return pts
+
+
+def pack_i32(parts, zero=None):
+    """Small int32 GPU tensors -> one int32 GPU vector (their concatenation), by ONE launch (apr_pack_i32); `zero`: an int32
+    GPU tensor cleared by the same launch."""
+    parts = [p.reshape(-1) for p in parts]
+    for p in parts:
+        if p.dtype != torch.int32 or not p.is_cuda or not p.is_contiguous():
+            raise _lib.AprHipError("pack_i32: parts must be contiguous int32 GPU tensors")
+    dev = parts[0].device if parts else zero.device
+    total = sum(p.numel() for p in parts)
+    dst = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    lib = _lib_()
+    zp, zw = (ptr(zero), zero.numel()) if zero is not None else (None, 0)
+    if zero is not None and (zero.dtype != torch.int32 or not zero.is_contiguous()):
+        raise _lib.AprHipError("pack_i32: `zero` must be a contiguous int32 GPU tensor")
+    done = 0
+    while True:          # APR_MAX_PACK sources per launch
+        chunk = parts[done:done + 96]
+        srcs = (C.c_void_p * max(len(chunk), 1))(*[p.data_ptr() for p in chunk])
+        cnts = (C.c_int32 * max(len(chunk), 1))(*[p.numel() for p in chunk])
+        off = sum(p.numel() for p in parts[:done])
+        check(lib.apr_pack_i32(srcs, cnts, len(chunk), C.c_void_p(dst.data_ptr() + 4 * off), zp, zw, stream()))
+        done += len(chunk)
+        zp, zw = None, 0
+        if done >= len(parts):
+            break
+    return dst[:total] if total else dst[:0]
 
 
 def voxelize_segments(xyz_all: torch.Tensor, voxel_size: float, offsets: torch.Tensor) -> torch.Tensor:
@@ -128,8 +216,7 @@ def finalize_maps(maps, extras=()):
     pend = [m for m in maps if m.n is None]
     if not pend and not extras:
         return []
-    parts = [torch.cat([m.n_dev, m.status]) for m in pend] + [e.reshape(-1).to(torch.int32) for e in extras]
-    host = torch.cat(parts).cpu().numpy()
+    host = pack_i32(_finalize_parts(pend, extras)).cpu().numpy()
     out, pos = [], 2 * len(pend)
     for e in extras:
         out.append(host[pos:pos + e.numel()].copy())
@@ -179,13 +266,21 @@ def drive(gen):
         return stop.value
 
 
-def finalize_maps_async(maps, extras=()):
+def _finalize_parts(pend, extras):
+    parts = []
+    for m in pend:
+        parts += [m.n_dev, m.status]
+    return parts + [e.reshape(-1) if e.dtype == torch.int32 else e.reshape(-1).to(torch.int32) for e in extras]
+
+
+def finalize_maps_async(maps, extras=(), zero=None):
     """`finalize_maps` without the host synchronisation -> PendingFetch whose finish() applies the counts and returns
-    the extras (numpy arrays)."""
+    the extras (numpy arrays).  The sizes, flags and extras are gathered by ONE launch (pack_i32), which also clears the
+    int32 tensor `zero` if given."""
     pend = [m for m in maps if m.n is None]
-    parts = [torch.cat([m.n_dev, m.status]) for m in pend] + [e.reshape(-1).to(torch.int32) for e in extras]
+    parts = _finalize_parts(pend, extras)
     if not parts:
-        parts = [torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))]
+        parts = [torch.empty(1, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))]
 
     def then(host):
         out, pos = [], 2 * len(pend)
@@ -195,7 +290,7 @@ def finalize_maps_async(maps, extras=()):
         _apply_finalize(pend, host)
         return out
 
-    return PendingFetch(torch.cat(parts), then)
+    return PendingFetch(pack_i32(parts, zero=zero), then)
 
 
 def _apply_finalize(pend, host):

@@ -91,6 +91,33 @@ int apr_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64
 int apr_voxelize_segments(const float* xyz, int64_t n, float voxel_size, const int64_t* offsets, int32_t nseg,
                           int32_t* coords, void* stream);
 
+/* The same WITHOUT the concatenated copy (the reference voxelises frame by frame, FCGF_APR/lib/complement_data_loader.py:
+ * 788-812; a batched step used to torch.cat its 2B frames first: 17 MB per 12-frame step): frames_host[b] = DEVICE pointer
+ * of frame b (f32 [n_b, 3], contiguous), offsets_host[b] = points before frame b, offsets_host[nseg] = total; both arrays
+ * live on the HOST and travel in the kernel arguments (nseg <= APR_MAX_FRAMES).  coords i32[total, 4] as
+ * apr_voxelize_segments writes them; offsets_dev (nullable, i64[nseg + 1]) receives the offsets for apr_segment_counts.
+ * apr_gather_frame_points: pts f32[*n_dev, 3] <- the input point behind every row of a map built with out_first over the
+ * same frames (the representative point of each voxel, `xyz[sel]` of sparse_quantize(return_index=True)); n_max = rows
+ * allocated for pts (>= *n_dev). */
+#define APR_MAX_FRAMES 64
+int apr_voxelize_frames(const float* const* frames_host, const int64_t* offsets_host, int32_t nseg, float voxel_size,
+                        int32_t* coords, int64_t* offsets_dev, void* stream);
+int apr_gather_frame_points(const float* const* frames_host, const int64_t* offsets_host, int32_t nseg,
+                            const int64_t* out_first, const int32_t* n_dev, int64_t n_max, float* pts, void* stream);
+
+/* Host-side glue of a step done by one launch instead of a chain of tensor ops: dst <- the concatenation of nsrc small
+ * DEVICE int32 arrays (srcs_host[s][0 .. counts_host[s]); pointer and count arrays on the host, nsrc <= APR_MAX_PACK) --
+ * the map sizes, status flags, per-frame row counts and bounding box that one device->host copy then brings over -- and
+ * zero_words int32 words at zero_ptr cleared (nullable: the pair-list counters of the encode that follows).
+ * apr_fill_bytes: hipMemsetAsync behind the C ABI (one fill for the three transposed tables of an encode, which
+ * apr_kernel_map_transpose_prefilled then scatters into without a fill of its own). */
+#define APR_MAX_PACK 96
+int apr_pack_i32(const int32_t* const* srcs_host, const int32_t* counts_host, int32_t nsrc, int32_t* dst,
+                 int32_t* zero_ptr, int64_t zero_words, void* stream);
+int apr_fill_bytes(void* ptr, int32_t byte_value, size_t bytes, void* stream);
+int apr_kernel_map_transpose_prefilled(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t,
+                                       void* stream);
+
 /* Rows per input segment of a map built over CONCATENATED point sets (a batch of frames voxelised in one build):
  * counts[b] = #{rows r < *n_dev : offsets[b] <= out_first[r] < offsets[b+1]}; out_first is ascending, the count
  * stays on the device so that it can be fetched together with the map sizes in the caller's single sync. */

@@ -141,3 +141,50 @@ def test_batched_dedup_map_compaction_and_fallback(dev):
         assert torch.equal(cm.kernel_map(1, 1, 3), ref.kernel_map(1, 1, 3))
         assert torch.equal(cm.kernel_map(2, 4, 3), ref.kernel_map(2, 4, 3))
         assert torch.equal(cm.kernel_map(4, 2, 3, True), ref.kernel_map(4, 2, 3, True))
+
+
+def test_frame_table_front_end_equals_the_concatenated_path(dev):
+    """apr_voxelize_frames / apr_gather_frame_points / apr_pack_i32 (the step's front end without torch glue): the same
+    coordinates, offsets, representative points and fetched words as torch.cat + apr_voxelize_segments + indexing; ragged
+    frames, an empty frame in the middle, one frame, MAX_FRAMES frames."""
+    rng = np.random.default_rng(5)
+    for sizes in ([5000, 1, 0, 7321, 256], [4097], [37] * ops.MAX_FRAMES):
+        clouds = [torch.from_numpy((rng.standard_normal((n, 3)) * 20).astype(np.float32)).to(dev) for n in sizes]
+        coords, offs_dev, offs = ops.voxelize_frames(clouds, 0.3)
+        assert offs == [0] + list(np.cumsum(sizes)) and offs_dev.tolist() == offs
+        xyz_all = torch.cat(clouds)
+        ref = ops.voxelize_segments(xyz_all, 0.3, torch.tensor(offs, dtype=torch.int64, device=dev))
+        assert torch.equal(coords, ref)
+        m = ops.build_map(coords, want_first=True)
+        pts = ops.gather_frame_points(clouds, m)            # before the sizes are known on the host
+        counts = ops.segment_counts(m, offs_dev)
+        bbox = ops.coords_bbox(coords)
+        zero = torch.full((777,), 5, dtype=torch.int32, device=dev)
+        packed = ops.pack_i32([m.n_dev, m.status, counts, bbox], zero=zero)
+        assert torch.equal(packed, torch.cat([m.n_dev, m.status, counts, bbox])) and int(zero.abs().sum()) == 0
+        ops.finalize_maps([m])
+        assert torch.equal(pts[:m.n], xyz_all[m.first])
+        assert int(counts.sum()) == m.n
+    many = [torch.arange(i, i + 3, dtype=torch.int32, device=dev) for i in range(250)]       # more sources than one launch takes
+    assert torch.equal(ops.pack_i32(many), torch.cat(many))
+    with pytest.raises(AprHipError):
+        ops.voxelize_frames([clouds[0]] * (ops.MAX_FRAMES + 1), 0.3)
+
+
+def test_transposed_tables_from_one_prefilled_pool(dev):
+    """The three coarse -> fine tables of an encoder come out of ONE -1-filled allocation
+    (apr_kernel_map_transpose_prefilled): equal to the stand-alone transpose and to hash probing."""
+    from apr_amd.MinkowskiEngine.core import CoordinateManager
+    xyz = synth.make_small_frame(2)
+    c = ops.voxelize(torch.from_numpy(xyz).to(dev), 0.3, 0)
+    m = ops.build_map(c)
+    ops.finalize_maps([m])
+    cm = CoordinateManager(m.coords.contiguous())
+    cm.build_pyramid([2, 4, 8])
+    for ts in (4, 2, 1):
+        got = cm.kernel_map(2 * ts, ts, 3, True)
+        fwd = cm.kernel_map(ts, 2 * ts, 3, False)
+        assert torch.equal(got, ops.kernel_map_transpose(fwd, cm.size(ts)))
+        probe = ops.kernel_map(cm.get_map(ts), cm.get_map(2 * ts), 3, -ts)
+        assert torch.equal(got, probe)
+    assert cm._tpool == {}                      # every table handed out exactly once
