@@ -76,6 +76,7 @@ PROTOTYPES = {
     "apr_spconv_os_pairs_bytes": (_sz, [_i64, _i32, _i32]),
     "apr_spconv_os_pairs_build": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
     "apr_spconv_os_trace": (C.c_int, [_p, _i32]),
+    "apr_spconv_os_set_debug": (C.c_int, [_i32]),
     "apr_spconv_os_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_norm_backward_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_norm_backward": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),

@@ -1277,6 +1277,27 @@ BatchLayout batch_layout(int32_t B, int64_t n0_max, int64_t n1_max, int32_t c, i
   return L;
 }
 
+// Scratch layout: [result slots][correspondences of the B pairs][lane 0][lane 1] ...  Everything apr_match_pose_batch_finish
+// reads (slots, correspondences, lane 0's RANSAC scratch for the overflow replay) sits at positions that do NOT depend on
+// the lane count, and the enqueue call uses as many lanes as the scratch it was handed holds -- so a change of
+// apr_match_pose_set_lanes between scratch_bytes / enqueue / finish of a batch in flight can cost lanes, never correctness.
+struct BatchViews {
+  char *slots, *corr_base, *lane_base;
+  int lanes;
+};
+
+BatchViews batch_views(const BatchLayout& L, int32_t B, void* scratch, size_t scratch_bytes) {
+  BatchViews v;
+  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  v.slots = p;                          p += L.slots;
+  v.corr_base = p;                      p += (size_t)B * L.corr_each;
+  v.lane_base = p;
+  const size_t used = (size_t)(p - (char*)scratch);
+  const size_t fit = scratch_bytes > used ? (scratch_bytes - used) / L.lane : 0;
+  v.lanes = (int)(fit < (size_t)L.lanes ? fit : (size_t)L.lanes);
+  return v;
+}
+
 // Library-owned side streams, kMaxLanes - 1 per (device, caller stream), created on first use and kept for the life of
 // the process (a caller stream's side streams carry only work forked from it, so two caller streams never share one).
 struct SideStreams { hipStream_t s[kMaxLanes - 1]; };
@@ -1299,8 +1320,9 @@ int side_streams(hipStream_t caller, SideStreams* out) {
 
 }  // namespace
 
-// Streams the pairs of a batch are dealt over (1 .. 4; see match_lanes above).  Takes effect for the calls that follow:
-// set it before apr_match_pose_batch_scratch_bytes, whose answer depends on it.
+// Streams the pairs of a batch are dealt over (1 .. 4; see match_lanes above).  Takes effect for the calls that follow; a
+// batch enqueued with a scratch sized under a smaller setting simply runs on the lanes that scratch holds, and the finish
+// call of a batch in flight does not depend on the setting (layout above).
 APR_API int apr_match_pose_set_lanes(int32_t lanes) {
   APR_CHECK_ARG(lanes >= 1 && lanes <= kMaxLanes, "apr_match_pose_set_lanes: 1 .. %d lanes", kMaxLanes);
   g_match_lanes.store(lanes, std::memory_order_relaxed);
@@ -1331,32 +1353,36 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
     n1_max = pairs[i].n1 > n1_max ? pairs[i].n1 : n1_max;
   }
   const BatchLayout L = batch_layout(B, n0_max, n1_max, c, max_iter);
-  APR_CHECK_ARG(scratch_bytes >= L.total, "apr_match_pose_batch: scratch too small");
-  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-  char* lane_base = p;                  p += (size_t)L.lanes * L.lane;
-  char* slots = p;                      p += L.slots;
-  char* corr_base = p;
+  const BatchViews V = batch_views(L, B, scratch, scratch_bytes);
+  APR_CHECK_ARG(V.lanes >= 1, "apr_match_pose_batch: scratch too small");
+  const int nlanes = V.lanes;
+  char* const lane_base = V.lane_base;
+  char* const slots = V.slots;
+  char* const corr_base = V.corr_base;
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const double thr_lt = sqrt_lt_threshold(max_dist);
   const bool fast_nn = (c == 32 || c == 64 || c == 128);
   // fork: the side lanes start behind everything the caller has queued so far (the descriptors, the points)
   hipStream_t lane_st[kMaxLanes] = {st};
-  hipEvent_t fork = nullptr;
-  if (L.lanes > 1) {
+  struct EventGuard {      // destroyed on every exit path (the runtime releases an event once it has completed)
+    hipEvent_t e = nullptr;
+    ~EventGuard() { if (e) (void)hipEventDestroy(e); }
+  } fork;
+  if (nlanes > 1) {
     SideStreams ss;
     const int rc = side_streams(st, &ss);
     if (rc != APR_OK) return rc;
-    APR_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    APR_HIP(hipEventRecord(fork, st));
-    for (int l = 1; l < L.lanes; ++l) {
+    APR_HIP(hipEventCreateWithFlags(&fork.e, hipEventDisableTiming));
+    APR_HIP(hipEventRecord(fork.e, st));
+    for (int l = 1; l < nlanes; ++l) {
       lane_st[l] = ss.s[l - 1];
-      APR_HIP(hipStreamWaitEvent(lane_st[l], fork, 0));
+      APR_HIP(hipStreamWaitEvent(lane_st[l], fork.e, 0));
     }
   }
   int rc = APR_OK;
   for (int i = 0; i < B && rc == APR_OK; ++i) {
     const apr_pair_desc& d = pairs[i];
-    const int l = i % L.lanes;
+    const int l = i % nlanes;
     hipStream_t ls = lane_st[l];
     char* lp = lane_base + (size_t)l * L.lane;
     void* nn_scratch = lp;
@@ -1378,15 +1404,13 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
     launch_scoring(r, d.n0, thr_lt, (int)cap, ls);
   }
   // join (also on an error above: whatever reached a side lane is ordered before the caller's next work)
-  if (L.lanes > 1) {
-    for (int l = 1; l < L.lanes; ++l) {
-      hipEvent_t join = nullptr;
-      APR_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-      APR_HIP(hipEventRecord(join, lane_st[l]));
-      APR_HIP(hipStreamWaitEvent(st, join, 0));
-      APR_HIP(hipEventDestroy(join));      // released by the runtime once it has completed
+  if (nlanes > 1) {
+    for (int l = 1; l < nlanes; ++l) {
+      EventGuard join;
+      APR_HIP(hipEventCreateWithFlags(&join.e, hipEventDisableTiming));
+      APR_HIP(hipEventRecord(join.e, lane_st[l]));
+      APR_HIP(hipStreamWaitEvent(st, join.e, 0));
     }
-    APR_HIP(hipEventDestroy(fork));
   }
   if (rc != APR_OK) return rc;
   APR_LAUNCH_CHECK();
@@ -1407,11 +1431,10 @@ APR_API int apr_match_pose_batch_finish(const apr_pair_desc* pairs, int32_t B, i
     n1_max = pairs[i].n1 > n1_max ? pairs[i].n1 : n1_max;
   }
   const BatchLayout L = batch_layout(B, n0_max, n1_max, c, max_iter);
-  APR_CHECK_ARG(scratch_bytes >= L.total, "apr_match_pose_batch: scratch too small");
-  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-  void* ransac_scratch = p + L.nn_scratch + L.best;      // lane 0's
-  p += (size_t)L.lanes * L.lane + L.slots;
-  char* corr_base = p;
+  const BatchViews V = batch_views(L, B, scratch, scratch_bytes);
+  APR_CHECK_ARG(V.lanes >= 1, "apr_match_pose_batch: scratch too small");
+  void* ransac_scratch = V.lane_base + L.nn_scratch + L.best;      // lane 0's
+  char* const corr_base = V.corr_base;
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const size_t slot_bytes = sizeof(Hyp) + 64;
   const char* host = (const char*)slots_host;

@@ -17,6 +17,7 @@
 //   * the epilogue (scale / shift / residual / ReLU) streams the tile out of LDS with 256-B coalesced row stores.
 // Traffic per launch: the gathered rows (L2 / Infinity-Cache resident), the weight slices (L2 resident, K x cin x 384 B per
 // tile) and the output rows, once.
+#include <atomic>
 #include <mutex>
 
 #include "common.h"
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
   // (read from LDS five items ahead of its use; the value is the same in every lane)
   auto item = [&](int i) {
     const unsigned w = __builtin_amdgcn_readfirstlane(s_sched[i < nitems ? i : nitems - 1]);
-    return i < nitems ? w : (w & 31u);
+    return i < nitems ? w : ((w & 31u) | (31u << 9));      // no group, no next offset (31): nothing is staged for it
   };
   // this wave's 16 pair words of an item -> ring slot (LDS-DMA, lanes 0-15); lanes past the list's end (and waves without a
   // group in the slot) fetch the offset's first word: a valid pair, masked at the accumulator write-back
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
       const bool valid = g16 + r16 < cnt_k;                                                                        \
       const unsigned char* const wbuf = s_w + buf * kSlice + frag_off;                                             \
       stamp(4);                                                                                                    \
+      if (DBG && (ablate & 16)) { APR_OS_WAIT_ALL(CUR); } /* checking mode: full drain instead of the counted wait */ \
       APR_OS_WAIT_ITEM(CUR);                                                                                       \
       const unsigned wd_i = ring_word(i & 7), wd_i2 = ring_word((i + 2) & 7);                                      \
       const int orow = (int)(wd_i >> kInBits);                                                                     \
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_os_conv(const float* __restrict
 }
 
 unsigned long long* g_trace = nullptr;   // device buffer of the diagnostics trace (8 waves x 512 stamps)
+std::atomic<int> g_os_debug{0};          // apr_spconv_os_set_debug
 
 // LDS: two slices (48 KB per 64 input channels) + the pair-word ring (4 KB) + the schedule (512 B) + 256 B per
 // accumulator row, <= 156 KB
@@ -455,11 +458,24 @@ APR_API int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs
     APR_HIP(hipMalloc(&g_trace, 8 * 512 * sizeof(unsigned long long)));
     APR_HIP(hipMemset(g_trace, 0, 8 * 512 * sizeof(unsigned long long)));
   }
-  const bool dbg = s_trace || s_ablate;
+  const int dbg_mode = g_os_debug.load(std::memory_order_relaxed);
+  const bool dbg = s_trace || s_ablate || dbg_mode;
+  const int ablate = s_ablate | (dbg_mode == 2 ? 16 : 0);
   auto kern = cin == 64 ? (dbg ? k_os_conv<1, true> : k_os_conv<1, false>) : (dbg ? k_os_conv<2, true> : k_os_conv<2, false>);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, in, ldi, v, (int)n_out, R, K, cout, (const unsigned char*)w_bf3,
-                     scale, shift, residual, ldr, relu, out, ldo, s_ablate, s_trace ? g_trace : nullptr);
+                     scale, shift, residual, ldr, relu, out, ldo, ablate, s_trace ? g_trace : nullptr);
   APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// Run-time guard of the hand-counted row pipeline (tests/test_spconv_gpu.py): mode 1 launches the diagnostics
+// instantiation k_os_conv<*, true> with no ablation (other registers, other schedule, the same counted waits), mode 2
+// the same with every counted wait preceded by a full drain (s_waitcnt vmcnt(0): no load can be in flight when its
+// registers are read, whatever the compiler did around the asm statements); mode 0 = production.  All three must give
+// the same bits.  Process-wide; not for concurrent use with other callers of apr_spconv_os_fwd.
+APR_API int apr_spconv_os_set_debug(int32_t mode) {
+  APR_CHECK_ARG(mode >= 0 && mode <= 2, "apr_spconv_os_set_debug: mode 0, 1 or 2");
+  g_os_debug.store(mode, std::memory_order_relaxed);
   return APR_OK;
 }
 

@@ -14,6 +14,8 @@ checkers, Kabsch without scaling, hypotheses scored on the correspondence set.
 open3d's RNG is unseeded / thread dependent; here the hypothesis stream is a
 counter-based RNG of (seed, iteration) so runs are reproducible and the CPU
 oracle can replay it.  open3d is absent from this image: parity unpinned.
+`max_validation=None` (default) is that reading; an integer selects the open3d <= 0.11 reading of the same criteria
+object (stop after max_validation validated hypotheses, geometric inlier scoring), as `ops.ransac_pose_geometric`.
 """
 import numpy as np
 import torch
@@ -37,7 +39,17 @@ def ransac_feature_matching(xyz0, xyz1, F0, F1, distance_threshold, ransac_n=4, 
         raise NotImplementedError("the HIP RANSAC kernel is specialised for ransac_n = 4 (both call sites)")
     x0, x1 = _dev(xyz0), _dev(xyz1)
     corr = feature_correspondences(F0, F1)
-    T, info = ops.ransac_pose(x0, x1, corr, distance_threshold, edge_length, max_iteration, seed)
+    if max_validation is not None:
+        # open3d <= 0.11 reading of RANSACConvergenceCriteria(max_iteration, max_validation): the loop stops after
+        # `max_validation` hypotheses have passed both checkers, and a hypothesis is scored by the source points that have a
+        # target point within distance_threshold after the transform (not on the correspondence set) -- the flavour
+        # Predator_APR's tester pins (requirements.txt: open3d 0.10; lib/benchmark_utils.py:213-225), on the same kernels
+        if int(max_validation) < 1:
+            raise ValueError("ransac_feature_matching: max_validation must be >= 1 (None: open3d >= 0.12 semantics)")
+        T, info = ops.ransac_pose_geometric(x0, x1, corr, distance_threshold, edge_length, max_iteration,
+                                            int(max_validation), seed)
+    else:
+        T, info = ops.ransac_pose(x0, x1, corr, distance_threshold, edge_length, max_iteration, seed)
     return (T, info) if return_info else T
 
 

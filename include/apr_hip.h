@@ -232,6 +232,10 @@ int apr_spconv_os_pairs_build(const int32_t* nbr, int64_t n_out, int64_t n_in, i
 /* Diagnostics for apr_spconv_os_fwd (APR_OS_TRACE=1 in the environment): per-wave s_memtime stamps of one workgroup of
  * the last launch, host_out[8 * 512] (tag << 56 | cycles; entry 511 of each wave = count). */
 int apr_spconv_os_trace(uint64_t* host_out, int32_t n);
+/* Run-time guard of k_os_conv's hand-counted load pipeline: 0 = production kernel, 1 = the diagnostics instantiation with
+ * no ablation, 2 = the same with a full drain (s_waitcnt vmcnt(0)) in front of every counted wait.  The three must give
+ * identical bits (tests/test_spconv_gpu.py::test_os_conv_debug_pipeline_matches_production); process-wide switch. */
+int apr_spconv_os_set_debug(int32_t mode);
 int apr_spconv_os_fwd(const float* in, int64_t ldi, const void* os_pairs, int64_t n_out, int32_t K, int32_t R,
                       int32_t cin, int32_t cout, const void* w_bf3, const float* scale, const float* shift,
                       const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, void* stream);

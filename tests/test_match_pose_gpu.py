@@ -116,6 +116,26 @@ def test_ransac_matches_oracle_and_ground_truth(dev, seed, inlier):
     assert rte < 0.3 and rre < 1.0
 
 
+def test_ransac_feature_matching_honours_max_validation(dev):
+    """`max_validation` (open3d <= 0.11 reading of RANSACConvergenceCriteria(max_iteration, max_validation)) is no longer
+    accepted and ignored: an integer selects the stop-after-N-validations / geometric-scoring flavour (== the oracle's
+    restatement of it), None keeps the open3d >= 0.12 reading, nonsense raises."""
+    xyz0, xyz1, F0, F1, T_gt = _synthetic_pair(4, inlier=0.5)
+    corr_o, _ = MO.feature_nn(F0, F1)
+    for mv in (50, 1000):
+        T_o, info_o = MO.ransac_feature_matching_geometric(xyz0, xyz1, corr_o, 0.3, 0.9, 60000, mv, seed=2)
+        T, info = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, max_iteration=60000, max_validation=mv,
+                                                        seed=2, return_info=True)
+        assert info["best_iteration"] == info_o["best_iteration"] and info["inliers"] == info_o["inliers"]
+        rte, rre = registration.rte_rre(T, T_o)
+        assert rte < 1e-3 and rre < 1e-3
+    T_all, info_all = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, max_iteration=60000, seed=2,
+                                                            return_info=True)
+    assert info_all["n_valid"] > 0 and registration.rte_rre(T_all, T_gt)[0] < 0.3
+    with pytest.raises(ValueError):
+        registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, max_validation=0)
+
+
 def test_ransac_no_valid_hypothesis_returns_identity(dev):
     rng = np.random.default_rng(0)
     xyz0 = rng.uniform(-30, 30, (500, 3)).astype(np.float32)

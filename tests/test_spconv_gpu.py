@@ -307,6 +307,36 @@ def test_output_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
         assert torch.equal(again, out)
 
 
+@pytest.mark.parametrize("cin,cout,n,density", [(64, 64, 30011, 0.27), (128, 128, 9000, 0.3), (64, 64, 3000, 0.05),
+                                                 (64, 128, 5000, 1.0)])
+def test_os_conv_debug_pipeline_matches_production(dev, cin, cout, n, density):
+    """Run-time guard of k_os_conv's hand-counted row pipeline (inline-asm loads + s_waitcnt vmcnt(N); the build only checks
+    the disassembly): the production kernel, the diagnostics instantiation (other registers and schedule, same counted
+    waits) and the diagnostics instantiation with a FULL DRAIN in front of every counted wait give the same bits.  A
+    toolchain that moves a row-register read above its wait breaks this equality.  Odd item counts per tile included
+    (the loop is unrolled twice: the surplus item must be empty)."""
+    from apr_amd import _lib
+    rng = np.random.default_rng(cin + cout + n)
+    x = torch.from_numpy((rng.standard_normal((n, cin)) * np.exp(rng.uniform(-3, 3, (n, 1)))).astype(np.float32)).to(dev)
+    W = torch.from_numpy((rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32)).to(dev)
+    nbr = torch.from_numpy(_random_map(rng, n, n, 27, density)).to(dev)
+    w3 = ops.pack_weights_bf3(W)
+    lib = _lib.load()
+    outs = []
+    try:
+        for rows in (ops.os_tile_rows(n, cin, cout), 64):
+            pairs = ops.build_os_pairs(nbr, n, rows)
+            items = pairs.blob[: 4 * 32 * ((n + rows - 1) // rows)].view(torch.int32).view(-1, 32)[:, 31]
+            assert bool((items % 2 == 1).any()) or density == 1.0      # tiles with an odd item count exist
+            for mode in (0, 1, 2):
+                _lib.check(lib.apr_spconv_os_set_debug(mode))
+                outs.append(ops.spconv_os(x, pairs, cin, cout, w3, relu=True))
+            assert torch.equal(outs[-3], outs[-2]) and torch.equal(outs[-3], outs[-1])
+    finally:
+        _lib.check(lib.apr_spconv_os_set_debug(0))
+    assert torch.equal(outs[0], outs[3])                 # tile height does not change the bits either (fixed offset order)
+
+
 def _clustered_coords(rng, n, nbatch, lo, hi, spread):
     """Unique int32 (batch, x, y, z) rows: blobs with plenty of occupied neighbour cells, some isolated voxels, the box
     corners occupied (the bitmap's padding is exercised), negative coordinates."""
