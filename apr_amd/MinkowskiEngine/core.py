@@ -191,7 +191,7 @@ class CoordinateManager:
             self._finalize()
             levels = [ts for ts in sorted(self.maps) if 2 * ts in self.maps]
             sizes = [self.maps[ts].n * 27 for ts in levels]
-            buf = torch.empty(max(sum(sizes), 1), dtype=torch.int32, device=self.device)
+            buf = torch.empty((sum(sizes) + 63) // 64 * 64 + 64, dtype=torch.int32, device=self.device)   # whole 256-B lines: one fill kernel
             ops.fill_bytes(buf, 0xFF)
             self._tpool, pos = {}, 0
             for ts, sz in zip(levels, sizes):

@@ -199,16 +199,12 @@ __device__ inline bool edge_reject(double a2, double b2, double r, double r2) {
 
 constexpr int kCandLists = 64;     // candidate sub-lists (power of two)
 
-__global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__ rec, uint32_t n0, double edge_ratio,
-                                                      long long it0, long long it1, uint64_t seed,
-                                                      long long* __restrict__ cand, int* __restrict__ n_cand,
-                                                      int sub_cap) {
-  const long long it = it0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool ok = it < it1;
-  // Staged: the checker is a conjunction over the 6 edges, so its value does not depend on the order they are
-  // looked at.  Correspondences 0 and 1 first; only the lanes whose first edge passes (a few per cent on real
-  // correspondence sets) fetch the third, and only the survivors of its two edges the fourth: ~4.3 instead of 8
-  // 16-B gathers per iteration, on the kernel that is bound by the L1's line rate.
+// The exact staged checker of one iteration: the checker is a conjunction over the 6 edges, so its value does not depend on
+// the order they are looked at.  Correspondences 0 and 1 first; only the lanes whose first edge passes (a few per cent on
+// real correspondence sets) fetch the third, and only the survivors of its two edges the fourth: ~4.3 instead of 8 16-B
+// gathers per iteration.
+__device__ inline bool sample_passes(const float4* __restrict__ rec, uint32_t n0, double edge_ratio, long long it,
+                                     uint64_t seed) {
   double s[4][3], t[4][3];
   const double r2 = edge_ratio * edge_ratio;
   auto fetch = [&](int j) {
@@ -224,24 +220,22 @@ __global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__
                        (t[a][2] - t[b][2]) * (t[a][2] - t[b][2]);
     return !(edge_reject(ds2, dt2, edge_ratio, r2) || edge_reject(dt2, ds2, edge_ratio, r2));
   };
-  if (ok) {
-    fetch(0);
-    fetch(1);
-    ok = edge_ok(0, 1);
-  }
-  if (ok) {
-    fetch(2);
-    ok = edge_ok(0, 2) && edge_ok(1, 2);
-  }
-  if (ok) {
-    fetch(3);
-    ok = edge_ok(0, 3) && edge_ok(1, 3) && edge_ok(2, 3);
-  }
-  // wave-aggregated append of the survivors' iteration numbers.  kCandLists sub-lists, each with its own counter (one
-  // per 4 B of a 256-B block: different L2 atomic slots are not needed, different ADDRESSES are): with trained
-  // descriptors nearly every wave has a survivor, and 62 k reservations on ONE counter serialise at ~10 ns each
-  // (0.63 ms of a 0.70 ms kernel at 50 % true matches).  Workgroup b appends to sub-list b % kCandLists, which can
-  // receive at most sub_cap = ceil(#workgroups / kCandLists) * 256 entries.
+  fetch(0);
+  fetch(1);
+  if (!edge_ok(0, 1)) return false;
+  fetch(2);
+  if (!(edge_ok(0, 2) && edge_ok(1, 2))) return false;
+  fetch(3);
+  return edge_ok(0, 3) && edge_ok(1, 3) && edge_ok(2, 3);
+}
+
+// wave-aggregated append of the survivors' iteration numbers.  kCandLists sub-lists, each with its own counter (one
+// per 4 B of a 256-B block: different L2 atomic slots are not needed, different ADDRESSES are): with trained
+// descriptors nearly every wave has a survivor, and 62 k reservations on ONE counter serialise at ~10 ns each
+// (0.63 ms of a 0.70 ms kernel at 50 % true matches).  Workgroup b appends to sub-list b % kCandLists, which can
+// receive at most sub_cap entries.
+__device__ inline void append_candidate(bool ok, long long it, long long* __restrict__ cand, int* __restrict__ n_cand,
+                                        int sub_cap) {
   const unsigned long long m = __ballot(ok);
   if (m) {
     const int lane = threadIdx.x & 63;
@@ -250,6 +244,107 @@ __global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__
     if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_cand + list, __popcll(m));
     base = __shfl(base, __ffsll((long long)m) - 1);
     if (ok) cand[(int64_t)list * sub_cap + base + __popcll(m & ((1ull << lane) - 1ull))] = it;
+  }
+}
+
+// sub_cap = ceil(#workgroups / kCandLists) * 256 entries per sub-list
+__global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__ rec, uint32_t n0, double edge_ratio,
+                                                      long long it0, long long it1, uint64_t seed,
+                                                      long long* __restrict__ cand, int* __restrict__ n_cand,
+                                                      int sub_cap) {
+  const long long it = it0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = it < it1 && sample_passes(rec, n0, edge_ratio, it, seed);
+  append_candidate(ok, it, cand, n_cand, sub_cap);
+}
+
+// ---- the same selection with the FIRST edge screened out of LDS (4 M iterations: the FCGF call) ----------------------
+// k_sample_check is bound by the L2's request rate: every iteration gathers at least correspondences 0 and 1 (4 random 16-B
+// loads from a 450 KB table that no L1 holds), 16 M line requests per pair = 44.6 us whatever the features are, and with
+// random-init features 95 % of the iterations die on that first edge.  Here every correspondence also exists as ONE 8-byte
+// word -- source and target point quantised to 10 bits per axis over [-R, R], R^2 = maxn2 -- and the whole table (14 k
+// correspondences: 112 KB) sits in the LDS of a 1024-thread workgroup (one per CU).  A thread screens its iteration's first
+// edge on the quantised points; the band is rigorous: a coordinate is off by at most 0.5001 cells (floor of an fp32 product),
+// so a distance by at most sqrt(3) * 1.0002 < 1.75 cells =: E, and "Ds + E < r (Dt - E)" in cell units implies ds < r dt for
+// the exact lengths with 0.03 cells to spare (fp32 / sqrt rounding here: 1e-4 cells).  Only an iteration that is CERTAINLY
+// rejected is dropped; the others (the passes plus a band of ~2 %) are queued in LDS and run sample_passes -- the exact
+// checker on the full-precision records -- densely.  Same candidate set as k_sample_check, bit for bit.
+constexpr int kScreenThreads = 1024;
+constexpr int kScreenPer = 4;                                   // iterations per thread and round
+constexpr int kScreenRound = kScreenThreads * kScreenPer;       // = queue capacity
+constexpr int kScreenBits = 10;
+constexpr int64_t kScreenMaxN0 = (160 * 1024 - kScreenRound * 4 - 256) / 8;     // 18 400 correspondences
+
+// rec8[i] = source (x | y << 10 | z << 20) | target (same) << 32, cells of size 2 R / 1023 (R = 0: everything in cell 0 and
+// the screen passes every iteration)
+__global__ void k_pack_small(const float4* __restrict__ rec, int64_t n0, const unsigned* __restrict__ maxn2,
+                             unsigned long long* __restrict__ rec8) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n0) return;
+  const float R = sqrtf(__uint_as_float(*maxn2)) * 1.000001f;
+  const float inv_h = R > 0.f ? (float)((1 << kScreenBits) - 1) / (2.f * R) : 0.f;
+  auto q = [&](float c) {
+    int u = (int)floorf((c + R) * inv_h);
+    u = u < 0 ? 0 : (u > (1 << kScreenBits) - 1 ? (1 << kScreenBits) - 1 : u);
+    return (unsigned)u;
+  };
+  const float4 a = rec[2 * i], b = rec[2 * i + 1];
+  const unsigned lo = q(a.x) | (q(a.y) << kScreenBits) | (q(a.z) << (2 * kScreenBits));
+  const unsigned hi = q(b.x) | (q(b.y) << kScreenBits) | (q(b.z) << (2 * kScreenBits));
+  rec8[i] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+
+__device__ inline float cell_dist(unsigned a, unsigned b) {
+  constexpr unsigned M = (1u << kScreenBits) - 1u;
+  const int dx = (int)(a & M) - (int)(b & M), dy = (int)((a >> kScreenBits) & M) - (int)((b >> kScreenBits) & M),
+            dz = (int)((a >> (2 * kScreenBits)) & M) - (int)((b >> (2 * kScreenBits)) & M);
+  return __builtin_sqrtf((float)(dx * dx + dy * dy + dz * dz));      // exact integer < 2^24 under a 1-ulp sqrt
+}
+
+// workgroup b owns iterations [it0 + b * per_wg, .. + per_wg) and appends to sub-list b % kCandLists (capacity sub_cap)
+__global__ __launch_bounds__(kScreenThreads) void k_sample_screen(const float4* __restrict__ rec,
+                                                                  const unsigned long long* __restrict__ rec8, uint32_t n0,
+                                                                  double edge_ratio, long long it0, long long it1,
+                                                                  long long per_wg, uint64_t seed,
+                                                                  long long* __restrict__ cand, int* __restrict__ n_cand,
+                                                                  int sub_cap) {
+  extern __shared__ unsigned long long s_rec[];          // [n0] records | queue [kScreenRound] u32
+  unsigned* const s_q = reinterpret_cast<unsigned*>(s_rec + ((n0 + 31u) & ~31u));
+  __shared__ int s_nq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (uint32_t i = tid; i < n0; i += kScreenThreads) s_rec[i] = rec8[i];
+  const long long base = it0 + (long long)blockIdx.x * per_wg;
+  const long long end = (base + per_wg < it1) ? base + per_wg : it1;
+  const float r = (float)edge_ratio, E = 1.75f;
+  for (long long rb = base; rb < end; rb += kScreenRound) {
+    if (tid == 0) s_nq = 0;
+    __syncthreads();                                      // table staged (first round) / queue drained; counter cleared
+#pragma unroll
+    for (int u = 0; u < kScreenPer; ++u) {
+      const long long it = rb + u * kScreenThreads + tid;
+      bool pass = false;
+      if (it < end) {
+        const unsigned long long a = s_rec[sample_index(seed, (uint64_t)it, 0, n0)];
+        const unsigned long long b = s_rec[sample_index(seed, (uint64_t)it, 1, n0)];
+        const float Ds = cell_dist((unsigned)a, (unsigned)b), Dt = cell_dist((unsigned)(a >> 32), (unsigned)(b >> 32));
+        pass = !(Ds + E < r * (Dt - E)) && !(Dt + E < r * (Ds - E));
+      }
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        int qb = 0;
+        if (lane == __ffsll((long long)m) - 1) qb = atomicAdd(&s_nq, __popcll(m));
+        qb = __shfl(qb, __ffsll((long long)m) - 1);
+        if (pass) s_q[qb + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(it - base);
+      }
+    }
+    __syncthreads();
+    const int nq = s_nq;
+    for (int c0 = 0; c0 < nq; c0 += kScreenThreads) {     // the exact checker, densely over the queue
+      const int c = c0 + tid;
+      const long long it = c < nq ? base + (long long)s_q[c] : 0;
+      const bool ok = c < nq && sample_passes(rec, n0, edge_ratio, it, seed);
+      append_candidate(ok, it, cand, n_cand, sub_cap);
+    }
+    __syncthreads();                                      // queue read before the next round refills it
   }
 }
 
@@ -997,6 +1092,7 @@ struct RansacScratch {
   int* sel;        // [cap] picked hypotheses
   unsigned* band;  // [cap][band_words(n0)] flagged mini-chunks
   SelPart* selp;   // [kSelParts]
+  unsigned long long* rec8;   // [n0] quantised correspondences for k_sample_screen
   char* end;
 };
 
@@ -1010,7 +1106,7 @@ static size_t ransac_core_bytes(int64_t n0, int64_t max_iter) {
   return 512 + align256(c1 * sizeof(Hyp)) + align256((size_t)n0 * 32) +
          align256(((size_t)(max_iter < 1 ? 1 : max_iter) + kCandLists * 256) * 8) + align256(kGeoGrid * sizeof(GeoPart)) +
          align256((size_t)rec2_rows(n0) * 48) + 256 + align256(c1 * 4) + align256(c1 * band_words(n0) * 4) +
-         align256(kSelParts * sizeof(SelPart)) + 256;
+         align256(kSelParts * sizeof(SelPart)) + align256((size_t)n0 * 8) + 256;
 }
 
 static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
@@ -1041,6 +1137,8 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   p += align256((size_t)cap * band_words(n0) * 4);
   r.selp = (SelPart*)p;
   p += align256(kSelParts * sizeof(SelPart));
+  r.rec8 = (unsigned long long*)p;
+  p += align256((size_t)n0 * 8);
   r.end = p;
   return r;
 }
@@ -1050,6 +1148,21 @@ static void launch_pack(const RansacScratch& r, const float* xyz0, const float* 
                         int64_t n0, hipStream_t st) {
   hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(2 * rec2_rows(n0), 256)), dim3(256), 0, st, xyz0, xyz1, n1,
                      (const long long*)corr, n0, r.rec, r.rec2, r.maxn2);
+  if (n0 <= kScreenMaxN0)      // the 8-byte records of k_sample_screen (needs the finished norm bound: its own launch)
+    hipLaunchKernelGGL(k_pack_small, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, r.rec, n0, r.maxn2, r.rec8);
+}
+
+// k_sample_screen's dynamic LDS (up to 160 KB) needs the per-device opt-in, once, under a lock (several host threads call in)
+static bool screen_ready() {
+  static std::mutex s_mu;
+  static int s_state[64] = {};      // 0 = not tried, 1 = ok, 2 = failed
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lk(s_mu);
+  if (s_state[dev] == 0)
+    s_state[dev] = hipFuncSetAttribute((const void*)k_sample_screen, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024) == hipSuccess ? 1 : 2;
+  return s_state[dev] == 1;
 }
 
 // inlier counts + squared errors of the hypothesis list, then the running best (see the comment above k_count)
@@ -1076,8 +1189,19 @@ static int counter_words(const RansacScratch& r) { return (int)((r.n_cand + kCan
 static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dist, double edge_ratio, int64_t it0,
                               int64_t it1, uint64_t seed, int cap, hipStream_t st, bool counters_cleared = false) {
   const int64_t nwg = cdiv64(it1 - it0, 256);
-  const int sub_cap = (int)(cdiv64(nwg, kCandLists) * 256);
+  int sub_cap = (int)(cdiv64(nwg, kCandLists) * 256);
   if (!counters_cleared) (void)hipMemsetAsync(r.n_valid, 0, (size_t)counter_words(r) * 4, st);
+  // many iterations over a table that fits the LDS: the first edge is screened there (k_sample_screen; same candidates).
+  // APR_RANSAC_SCREEN=0 (read per call: the A/B and test hook) keeps the plain kernel.
+  const int64_t niter = it1 - it0;
+  if (niter >= 64 * kScreenRound && n0 <= kScreenMaxN0 && env_int("APR_RANSAC_SCREEN", 1) && screen_ready()) {
+    const int64_t swg = 256;                                     // one 1024-thread workgroup per CU; a multiple of kCandLists
+    const int64_t per_wg = cdiv64(niter, swg);
+    sub_cap = (int)((swg / kCandLists) * per_wg);                // <= niter / 64 + 4: inside the candidate region
+    const size_t lds = (size_t)((n0 + 31) & ~(int64_t)31) * 8 + (size_t)kScreenRound * 4;
+    hipLaunchKernelGGL(k_sample_screen, dim3((unsigned)swg), dim3(kScreenThreads), lds, st, r.rec, r.rec8, (uint32_t)n0,
+                       edge_ratio, (long long)it0, (long long)it1, (long long)per_wg, seed, r.cand, r.n_cand, sub_cap);
+  } else
   hipLaunchKernelGGL(k_sample_check, dim3((unsigned)nwg), dim3(256), 0, st, r.rec, (uint32_t)n0, edge_ratio,
                      (long long)it0, (long long)it1, seed, r.cand, r.n_cand, sub_cap);
   hipLaunchKernelGGL(k_fit_check, dim3(512), dim3(256), 0, st, r.rec, (uint32_t)n0, sqrt_gt_threshold(max_dist), seed,

@@ -220,5 +220,8 @@ def run_pipelined(make_step, indices, streams):
         if not live and exhausted:
             run_pipelined.last_host_busy_s = host_busy      # read by bench.py (host enqueue time per step)
             return results, done_at
-        if not moved and live:
-            min(live, key=lambda sl: sl[0])[2].event.synchronize()      # nothing ready: wait for the oldest step
+        if not moved and live:      # nothing ready: sleep one poll interval (ops.wait_event: hipEventSynchronize spins)
+            if ops.FETCH_WAIT == "sync":
+                min(live, key=lambda sl: sl[0])[2].event.synchronize()
+            else:
+                time.sleep(ops.FETCH_POLL_S)

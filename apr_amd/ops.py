@@ -229,10 +229,27 @@ def finalize_maps(maps, extras=()):
 # of spinning on the event (3 waiting threads per rank x 8 ranks would otherwise burn the node's CPU quota idling;
 # APR_BLOCKING_EVENTS=0 restores the spin wait for A/B runs).
 BLOCKING_EVENTS = os.environ.get("APR_BLOCKING_EVENTS", "1") != "0"
+# ... which turned out not to be enough on this stack: measured per worker thread (scripts/host_cpu_split.py), a thread inside
+# hipEventSynchronize burns CPU for the whole wall time of the wait with the blocking flag set or not (0.254 s of CPU over
+# 0.254 s of waiting; 3.06 CPUs busy per rank for 0.3 CPUs' worth of enqueue work).  The fetch wait therefore POLLS:
+# event.query() + time.sleep(APR_FETCH_POLL_US, default 50 us; the sleep releases the GIL).  APR_FETCH_WAIT=sync restores
+# hipEventSynchronize.
+FETCH_WAIT = os.environ.get("APR_FETCH_WAIT", "poll")
+FETCH_POLL_S = float(os.environ.get("APR_FETCH_POLL_US", "50")) * 1e-6
 
 
 def fetch_event():
     return torch.cuda.Event(blocking=BLOCKING_EVENTS)
+
+
+def wait_event(ev):
+    """Host wait for a fetch event without spinning on a CPU (see FETCH_WAIT above)."""
+    if FETCH_WAIT == "sync":
+        ev.synchronize()
+        return
+    import time
+    while not ev.query():
+        time.sleep(FETCH_POLL_S)
 
 
 class PendingFetch:
@@ -249,8 +266,11 @@ class PendingFetch:
         self.event.record()
         self._then, self._keep = then, keep
 
+    def wait(self):
+        wait_event(self.event)
+
     def finish(self):
-        self.event.synchronize()
+        wait_event(self.event)
         return self._then(self._host.numpy())
 
 
@@ -260,7 +280,7 @@ def drive(gen):
     try:
         pending = next(gen)
         while True:
-            pending.event.synchronize()
+            pending.wait()
             pending = gen.send(None)
     except StopIteration as stop:
         return stop.value

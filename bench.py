@@ -742,7 +742,7 @@ def main():
                    # the timed region; 8 ranks need 8 x host_cpus_busy CPUs of the node's quota
                    "host_cpu_s_per_step": host_cpu_s / args.steps,
                    "host_cpus_busy": host_cpu_s / elapsed_local,
-                   "host_cpu_quota": _host.cpu_quota(), "blocking_fetch_events": ops.BLOCKING_EVENTS,
+                   "host_cpu_quota": _host.cpu_quota(), "fetch_wait": (f"poll {1e6 * ops.FETCH_POLL_S:.0f} us" if ops.FETCH_WAIT != "sync" else "hipEventSynchronize"),
                    "per_rank_host_cpus_busy": [float(r[3] / r[1]) for r in stats.tolist()],
                    "per_rank_pairs_per_s": [float(r[0] / r[1]) for r in stats.tolist()]},
     }

@@ -30,7 +30,7 @@ def run(w, first, last, rec):
                 pending = next(gen)
                 while True:
                     a, ta = time.thread_time(), time.perf_counter()
-                    pending.event.synchronize()
+                    pending.wait()
                     if rec:
                         st["wait_cpu"] += time.thread_time() - a
                         st["wait_wall"] += time.perf_counter() - ta
@@ -55,7 +55,7 @@ loop(24, 24 + steps, True)
 torch.cuda.synchronize()
 p1, t1 = time.process_time(), time.perf_counter()
 wall = t1 - t0
-print(f"blocking_events={ops.BLOCKING_EVENTS} steps={steps} wall={wall:.3f}s pairs/s={steps * B / wall:.0f}")
+print(f"fetch_wait={ops.FETCH_WAIT} poll_us={1e6 * ops.FETCH_POLL_S:.0f} blocking_events={ops.BLOCKING_EVENTS} steps={steps} wall={wall:.3f}s pairs/s={steps * B / wall:.0f}")
 print(f"process CPU {p1 - p0:.3f}s = {(p1 - p0) / wall:.2f} CPUs busy; per step {1e3 * (p1 - p0) / steps:.2f} ms")
 tot = 0.0
 for w, st in enumerate(stat):

@@ -411,3 +411,73 @@ def test_count_path_edge_cases_equal_full_fp64_scoring(dev, n, scale, noise):
     assert i1["inliers"] == i0["inliers"] and i1["rmse"] == i0["rmse"] and i1["best_iteration"] == i0["best_iteration"]
     assert np.array_equal(T1, T0)
     assert i1["inliers"] >= 0.7 * n
+
+
+def _screen_ab(fn):
+    """fn() under APR_RANSAC_SCREEN = 1 (LDS-screened sampling kernel, the default) and 0 (plain kernel)."""
+    import os
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["APR_RANSAC_SCREEN"] = mode
+        try:
+            out[mode] = fn()
+        finally:
+            os.environ.pop("APR_RANSAC_SCREEN", None)
+    return out["1"], out["0"]
+
+
+@pytest.mark.parametrize("share,iters,seed", [(0.0, 4000000, 1), (0.3, 4000000, 2), (0.55, 600000, 3), (0.1, 262144, 4)])
+def test_lds_screened_sampling_equals_the_plain_kernel(dev, share, iters, seed):
+    """k_sample_screen (first RANSAC edge tested on 10-bit quantised points out of LDS, rigorous guard band, survivors
+    re-checked exactly) selects THE SAME candidates as k_sample_check: identical transform bits, inliers, rmse, best
+    iteration and n_valid, from no true matches (the bench's random-init features) to a majority of them; full-size pair,
+    the reference's 4 M iterations (FCGF_APR/scripts/test_apr.py:148-156)."""
+    from apr_amd.fcgf.lib import apg
+    from apr_amd.fcgf.pipeline import PairRegistration
+    from tests.helpers import model_pair
+    a_h, b_h, T_gt = synth.make_pair(seed)
+    ta, tb = torch.from_numpy(a_h).to(dev), torch.from_numpy(b_h).to(dev)
+    _, hm = model_pair("ResUNetBN2C")
+    _, pts0, pts1, n0, n1 = PairRegistration(hm, voxel_size=0.3).voxelize_pair(ta, tb)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    F1 = torch.nn.functional.normalize(torch.randn(n1, 32, generator=g), dim=1).to(dev)
+    F0 = torch.nn.functional.normalize(torch.randn(n0, 32, generator=g), dim=1).to(dev)
+    if share > 0:
+        pairs_gt = apg.get_matching_indices(pts0, pts1, T_gt, 0.3, K=1)
+        pick = pairs_gt[torch.randperm(len(pairs_gt), generator=g)[:int(share * n0)].to(dev)]
+        F0[pick[:, 0]] = torch.nn.functional.normalize(
+            F1[pick[:, 1]] + 0.02 * torch.randn(len(pick), 32, generator=g).to(dev), dim=1)
+    (T1, i1), (T0, i0) = _screen_ab(
+        lambda: ops.match_pose_batch([F0], [F1], [pts0], [pts1], 0.3, 0.9, iters, seeds=[seed])[0])
+    assert i1 == i0 and np.array_equal(T1, T0), (i1, i0)
+    if share >= 0.3:
+        rte, rre = registration.rte_rre(T1, T_gt)
+        assert i1["n_valid"] > 1000 and rte < 0.1 and rre < 0.2
+
+
+@pytest.mark.parametrize("case", ["one_point", "tiny", "huge_coords", "collinear", "too_many_for_lds"])
+def test_lds_screened_sampling_edge_cases(dev, case):
+    """Degenerate tables for the quantised screen: every point the same (R = 0: the screen must pass everything), 5
+    correspondences, coordinates of 1e6 m (cells of 2 km), points on a line, and more correspondences than the LDS holds
+    (plain kernel taken silently): always the plain kernel's result."""
+    rng = np.random.default_rng(11)
+    n = {"one_point": 300, "tiny": 5, "huge_coords": 4000, "collinear": 2000, "too_many_for_lds": 19000}[case]
+    src = rng.uniform(-40, 40, (n, 3))
+    if case == "one_point":
+        src[:] = 0.0
+    if case == "huge_coords":
+        src *= 25000.0
+    if case == "collinear":
+        src[:, 1:] = 0.0
+    ang = 0.4
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    tgt = src @ R.T + np.array([1.0, 2.0, -0.5])
+    corr = np.arange(n, dtype=np.int64)
+    bad = rng.random(n) < 0.5
+    corr[bad] = rng.integers(0, n, int(bad.sum()))
+    s_d, t_d, c_d = (torch.from_numpy(x).to(dev) for x in (src.astype(np.float32), tgt.astype(np.float32), corr))
+    thr = 0.3 if case != "huge_coords" else 7500.0
+    (T1, i1), (T0, i0) = _screen_ab(lambda: ops.ransac_pose(s_d, t_d, c_d, thr, 0.9, 300000, 5))
+    assert i1 == i0 and np.array_equal(T1, T0), (i1, i0)
+    if case in ("huge_coords", "too_many_for_lds"):
+        assert i1["inliers"] >= 0.4 * n
