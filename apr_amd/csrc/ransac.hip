@@ -269,17 +269,23 @@ __global__ __launch_bounds__(256) void k_sample_check(const float4* __restrict__
 // rejected is dropped; the others (the passes plus a band of ~2 %) are queued in LDS and run sample_passes -- the exact
 // checker on the full-precision records -- densely.  Same candidate set as k_sample_check, bit for bit.
 constexpr int kScreenThreads = 1024;
-constexpr int kScreenPer = 4;                                   // iterations per thread and round
-constexpr int kScreenRound = kScreenThreads * kScreenPer;       // = queue capacity
+constexpr int kScreenPer = 2;                                   // iterations per thread and round
+constexpr int kScreenRound = kScreenThreads * kScreenPer;
+constexpr int kScreenQueue = 2 * kScreenRound;                  // survivors wait here for the exact checker; drained when a
+                                                                // further round might not fit (random features: once, at the end)
 constexpr int kScreenBits = 10;
-constexpr int64_t kScreenMaxN0 = (160 * 1024 - kScreenRound * 4 - 256) / 8;     // 18 400 correspondences
+constexpr int64_t kScreenMaxN0 = (160 * 1024 - kScreenQueue * 4 - 512) / 8;     // 18 368 correspondences
 
 // rec8[i] = source (x | y << 10 | z << 20) | target (same) << 32, cells of size 2 R / 1023 (R = 0: everything in cell 0 and
 // the screen passes every iteration)
 __global__ void k_pack_small(const float4* __restrict__ rec, int64_t n0, const unsigned* __restrict__ maxn2,
                              unsigned long long* __restrict__ rec8) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n0) return;
+  if (i >= ((n0 + 31) & ~(int64_t)31)) return;
+  if (i >= n0) {            // padding of the staged table (never sampled)
+    rec8[i] = 0ull;
+    return;
+  }
   const float R = sqrtf(__uint_as_float(*maxn2)) * 1.000001f;
   const float inv_h = R > 0.f ? (float)((1 << kScreenBits) - 1) / (2.f * R) : 0.f;
   auto q = [&](float c) {
@@ -300,6 +306,14 @@ __device__ inline float cell_dist(unsigned a, unsigned b) {
   return __builtin_sqrtf((float)(dx * dx + dy * dy + dz * dz));      // exact integer < 2^24 under a 1-ulp sqrt
 }
 
+// the two 64-bit multiplications of splitmix64's finaliser, from a pre-mixed counter z0 = seed + (4 it + slot + 1) * golden
+__device__ inline uint32_t sample_index_from(uint64_t z, uint32_t n) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(((z >> 32) * (uint64_t)n) >> 32);
+}
+
 // workgroup b owns iterations [it0 + b * per_wg, .. + per_wg) and appends to sub-list b % kCandLists (capacity sub_cap)
 __global__ __launch_bounds__(kScreenThreads) void k_sample_screen(const float4* __restrict__ rec,
                                                                   const unsigned long long* __restrict__ rec8, uint32_t n0,
@@ -307,27 +321,56 @@ __global__ __launch_bounds__(kScreenThreads) void k_sample_screen(const float4* 
                                                                   long long per_wg, uint64_t seed,
                                                                   long long* __restrict__ cand, int* __restrict__ n_cand,
                                                                   int sub_cap) {
-  extern __shared__ unsigned long long s_rec[];          // [n0] records | queue [kScreenRound] u32
-  unsigned* const s_q = reinterpret_cast<unsigned*>(s_rec + ((n0 + 31u) & ~31u));
-  __shared__ int s_nq;
+  extern __shared__ unsigned long long s_rec[];          // [n0 padded] records | queue [kScreenQueue] u32 | queue length
+  const uint32_t n0p = (n0 + 31u) & ~31u;
+  unsigned* const s_q = reinterpret_cast<unsigned*>(s_rec + n0p);
+  int& s_nq = *reinterpret_cast<int*>(s_q + kScreenQueue);      // no static LDS: the dynamic opt-in covers all of it
   const int tid = threadIdx.x, lane = tid & 63;
-  for (uint32_t i = tid; i < n0; i += kScreenThreads) s_rec[i] = rec8[i];
+  {   // stage the table: 16-B loads, 8 in flight per thread before the first LDS store (rec8 is padded to n0p entries)
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2* src = reinterpret_cast<const u64x2*>(rec8);
+    u64x2* dst = reinterpret_cast<u64x2*>(s_rec);
+    const uint32_t nv = n0p >> 1;
+    for (uint32_t i0 = tid; i0 < nv; i0 += 8 * kScreenThreads) {
+      u64x2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * kScreenThreads < nv) t[u] = src[i0 + u * kScreenThreads];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * kScreenThreads < nv) dst[i0 + u * kScreenThreads] = t[u];
+    }
+  }
+  if (tid == 0) s_nq = 0;
   const long long base = it0 + (long long)blockIdx.x * per_wg;
   const long long end = (base + per_wg < it1) ? base + per_wg : it1;
   const float r = (float)edge_ratio, E = 1.75f;
+  constexpr uint64_t G = 0x9E3779B97F4A7C15ull;
+  auto drain = [&]() {      // the exact checker, densely over the queue; callers synchronise before and after
+    const int nq = s_nq;
+    for (int c0 = 0; c0 < nq; c0 += kScreenThreads) {
+      const int c = c0 + tid;
+      const long long it = c < nq ? base + (long long)s_q[c] : 0;
+      const bool ok = c < nq && sample_passes(rec, n0, edge_ratio, it, seed);
+      append_candidate(ok, it, cand, n_cand, sub_cap);
+    }
+  };
+  __syncthreads();                                        // table staged, counter cleared
+  // counter of (iteration, slot 0): seed + (4 it + 1) G; slot 1 is one G further, the next iteration of this thread
+  // 4 * kScreenThreads * G further -- additions only
+  uint64_t z0 = seed + (uint64_t)(4 * (base + tid) + 1) * G;
   for (long long rb = base; rb < end; rb += kScreenRound) {
-    if (tid == 0) s_nq = 0;
-    __syncthreads();                                      // table staged (first round) / queue drained; counter cleared
 #pragma unroll
     for (int u = 0; u < kScreenPer; ++u) {
       const long long it = rb + u * kScreenThreads + tid;
       bool pass = false;
       if (it < end) {
-        const unsigned long long a = s_rec[sample_index(seed, (uint64_t)it, 0, n0)];
-        const unsigned long long b = s_rec[sample_index(seed, (uint64_t)it, 1, n0)];
+        const unsigned long long a = s_rec[sample_index_from(z0, n0)];
+        const unsigned long long b = s_rec[sample_index_from(z0 + G, n0)];
         const float Ds = cell_dist((unsigned)a, (unsigned)b), Dt = cell_dist((unsigned)(a >> 32), (unsigned)(b >> 32));
         pass = !(Ds + E < r * (Dt - E)) && !(Dt + E < r * (Ds - E));
       }
+      z0 += (uint64_t)(4 * kScreenThreads) * G;
       const unsigned long long m = __ballot(pass);
       if (m) {
         int qb = 0;
@@ -337,15 +380,16 @@ __global__ __launch_bounds__(kScreenThreads) void k_sample_screen(const float4* 
       }
     }
     __syncthreads();
-    const int nq = s_nq;
-    for (int c0 = 0; c0 < nq; c0 += kScreenThreads) {     // the exact checker, densely over the queue
-      const int c = c0 + tid;
-      const long long it = c < nq ? base + (long long)s_q[c] : 0;
-      const bool ok = c < nq && sample_passes(rec, n0, edge_ratio, it, seed);
-      append_candidate(ok, it, cand, n_cand, sub_cap);
+    const int nq_now = s_nq;                              // read by everybody BEFORE anybody appends again
+    __syncthreads();
+    if (nq_now > kScreenQueue - kScreenRound) {           // the next round might not fit: run the exact checker now
+      drain();
+      __syncthreads();
+      if (tid == 0) s_nq = 0;
+      __syncthreads();
     }
-    __syncthreads();                                      // queue read before the next round refills it
   }
+  drain();
 }
 
 // dense over the compacted candidates (grid-stride: the count only exists on the device)
@@ -1106,7 +1150,7 @@ static size_t ransac_core_bytes(int64_t n0, int64_t max_iter) {
   return 512 + align256(c1 * sizeof(Hyp)) + align256((size_t)n0 * 32) +
          align256(((size_t)(max_iter < 1 ? 1 : max_iter) + kCandLists * 256) * 8) + align256(kGeoGrid * sizeof(GeoPart)) +
          align256((size_t)rec2_rows(n0) * 48) + 256 + align256(c1 * 4) + align256(c1 * band_words(n0) * 4) +
-         align256(kSelParts * sizeof(SelPart)) + align256((size_t)n0 * 8) + 256;
+         align256(kSelParts * sizeof(SelPart)) + align256((size_t)(n0 + 32) * 8) + 256;
 }
 
 static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
@@ -1138,7 +1182,7 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   r.selp = (SelPart*)p;
   p += align256(kSelParts * sizeof(SelPart));
   r.rec8 = (unsigned long long*)p;
-  p += align256((size_t)n0 * 8);
+  p += align256((size_t)(n0 + 32) * 8);
   r.end = p;
   return r;
 }
@@ -1149,7 +1193,7 @@ static void launch_pack(const RansacScratch& r, const float* xyz0, const float* 
   hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(2 * rec2_rows(n0), 256)), dim3(256), 0, st, xyz0, xyz1, n1,
                      (const long long*)corr, n0, r.rec, r.rec2, r.maxn2);
   if (n0 <= kScreenMaxN0)      // the 8-byte records of k_sample_screen (needs the finished norm bound: its own launch)
-    hipLaunchKernelGGL(k_pack_small, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, r.rec, n0, r.maxn2, r.rec8);
+    hipLaunchKernelGGL(k_pack_small, dim3((unsigned)cdiv64(n0 + 32, 256)), dim3(256), 0, st, r.rec, n0, r.maxn2, r.rec8);
 }
 
 // k_sample_screen's dynamic LDS (up to 160 KB) needs the per-device opt-in, once, under a lock (several host threads call in)
@@ -1159,9 +1203,11 @@ static bool screen_ready() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   std::lock_guard<std::mutex> lk(s_mu);
-  if (s_state[dev] == 0)
+  if (s_state[dev] == 0) {
     s_state[dev] = hipFuncSetAttribute((const void*)k_sample_screen, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024) == hipSuccess ? 1 : 2;
+    if (s_state[dev] == 2) (void)hipGetLastError();      // the plain kernel takes over: do not leave the error for its check
+  }
   return s_state[dev] == 1;
 }
 
@@ -1198,7 +1244,7 @@ static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dis
     const int64_t swg = 256;                                     // one 1024-thread workgroup per CU; a multiple of kCandLists
     const int64_t per_wg = cdiv64(niter, swg);
     sub_cap = (int)((swg / kCandLists) * per_wg);                // <= niter / 64 + 4: inside the candidate region
-    const size_t lds = (size_t)((n0 + 31) & ~(int64_t)31) * 8 + (size_t)kScreenRound * 4;
+    const size_t lds = (size_t)((n0 + 31) & ~(int64_t)31) * 8 + (size_t)kScreenQueue * 4 + 16;
     hipLaunchKernelGGL(k_sample_screen, dim3((unsigned)swg), dim3(kScreenThreads), lds, st, r.rec, r.rec8, (uint32_t)n0,
                        edge_ratio, (long long)it0, (long long)it1, (long long)per_wg, seed, r.cand, r.n_cand, sub_cap);
   } else
