@@ -270,6 +270,11 @@ def test_cpu_tensors_fail_loudly():
     (64, 64, 27, 100, 1000, 1.0), (64, 64, 27, 40, 2000, 0.02), (64, 64, 27, 3000, 3000, 0.9),
     (128, 128, 27, 2500, 2500, 0.3), (128, 64, 27, 1000, 9000, 0.12), (128, 128, 27, 20000, 20000, 0.27),
     (128, 64, 27, 100, 700, 1.0),
+    # 128 input channels (k_os_conv<2>): every group count per offset from 0 to 13 (density 1.0), an odd number of items, one
+    # item, no item, K = 8 and K = 1, 256 output columns, a strided map, a 60 k-row map
+    (128, 128, 27, 100, 700, 1.0), (128, 128, 27, 31, 31, 0.3), (128, 128, 27, 500, 500, 0.0), (128, 128, 8, 700, 257, 0.5),
+    (128, 256, 27, 3000, 1100, 0.3), (128, 128, 27, 40, 2000, 0.02), (128, 128, 27, 60000, 60000, 0.27),
+    (128, 128, 1, 1000, 1000, 1.0),
 ])
 def test_output_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, density):
     """apr_spconv_os_pairs_build + apr_spconv_os_fwd (accumulators in LDS, no product rows) against the fp64 oracle:
