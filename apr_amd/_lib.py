@@ -124,6 +124,8 @@ PROTOTYPES = {
     "apr_edge_features": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "apr_group_max": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _f32, _p, _i64, _p]),
     "apr_coords_bbox": (C.c_int, [_p, _i64, _p, _p]),
+    "apr_kp_resnet_scratch_bytes": (_sz, [_p]),
+    "apr_kp_resnet_block": (C.c_int, [_p, _p]),
     "apr_voxelize_frames": (C.c_int, [_p, _p, _i32, _f32, _p, _p, _p]),
     "apr_gather_frame_points": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p]),
     "apr_pack_i32": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p]),
@@ -143,6 +145,19 @@ PROTOTYPES = {
     "apr_crop_to_radius": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
     "apr_chamfer_sum": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _sz, _p]),
 }
+
+class KpResnetDesc(C.Structure):
+    """apr_kp_resnet_desc (include/apr_hip.h)."""
+    _fields_ = [("x", _p), ("ldx", _i64), ("n_in", _i64),
+                ("in_dim", _i32), ("mid", _i32), ("out_dim", _i32), ("strided", _i32),
+                ("q_pts", _p), ("s_pts", _p), ("n_out", _i64),
+                ("nbr", _p), ("H", _i32), ("n_kp", _i32),
+                ("kernel_points", _p), ("extent", _f32), ("eps", _f32), ("slope", _f32), ("nseg", _i32),
+                ("w_unary1", _p), ("w_kpconv", _p), ("w_unary2", _p), ("w_shortcut", _p),
+                ("seg_in", _p), ("seg_out", _p),
+                ("out", _p), ("ldo", _i64),
+                ("scratch", _p), ("scratch_bytes", _sz)]
+
 
 _lib = None
 

@@ -224,4 +224,5 @@ def run_pipelined(make_step, indices, streams):
             if ops.FETCH_WAIT == "sync":
                 min(live, key=lambda sl: sl[0])[2].event.synchronize()
             else:
+                ops.fine_sleep_slack()
                 time.sleep(ops.FETCH_POLL_S)

@@ -234,14 +234,18 @@ class KPConvFunction(torch.autograd.Function):
         return None, None, None, dx, dw, None, None
 
 
-def gather_pool(x, inds, mode):
-    """mode 'max' -> max_pool(x, inds); 'closest' -> closest_pool(x, inds)."""
+def gather_pool(x, inds, mode, out=None):
+    """mode 'max' -> max_pool(x, inds); 'closest' -> closest_pool(x, inds).  `out`: a [nq, c] column slice to write into."""
     inds = _i32(inds, "gather_pool.inds")
     x, ldx = ops._rows(x, "gather_pool.x")
     nq, c = inds.shape[0], x.shape[1]
-    out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+    out, ldo = ops._rows(out, "gather_pool.out")
+    if tuple(out.shape) != (nq, c):
+        raise _lib.AprHipError("gather_pool: output shape mismatch")
     check(_lib.load().apr_gather_pool(ptr(x), ldx, x.shape[0], c, ptr(inds), inds.shape[1], nq,
-                                      1 if mode == "closest" else 0, ptr(out), c, stream()))
+                                      1 if mode == "closest" else 0, ptr(out), ldo, stream()))
     return out
 
 

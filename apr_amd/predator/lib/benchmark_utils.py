@@ -73,15 +73,27 @@ def weighted_choice(rng, n, size, p):
     return found
 
 
-def sample_by_score(pcd, feats, scores, n_points, rng=np.random):
-    """Score-weighted sampling without replacement (lib/tester.py:80-92); the draw stays on the host RNG."""
-    if pcd.shape[0] <= n_points:
-        return pcd, feats, None
+def draw_by_score(n, scores, n_points, rng=np.random):
+    """The host half of `sample_by_score`: the indices `rng.choice` draws for CPU float32 `scores` (None: keep every point)."""
+    if n <= n_points:
+        return None
     # lib/tester.py:85: `(scores / scores.sum()).numpy().flatten()` on the CPU float32 tensor (torch's float32 sum);
     # np.random.choice widens p to float64 itself
     s = scores.detach().cpu().float()
     probs = (s / s.sum()).numpy().flatten()
-    idx = weighted_choice(rng, pcd.shape[0], n_points, probs)
+    return weighted_choice(rng, n, n_points, probs)
+
+
+def take_drawn(pcd, feats, idx):
+    """The device half: rows `idx` of the cloud and its features (idx None: everything)."""
+    if idx is None:
+        return pcd, feats
     # pinned + non_blocking: a pageable host->device copy blocks the host until the stream gets to it
     idx_t = torch.from_numpy(idx).pin_memory().to(pcd.device, non_blocking=True) if torch.is_tensor(pcd) else idx
-    return pcd[idx_t], feats[idx_t], idx
+    return pcd[idx_t], feats[idx_t]
+
+
+def sample_by_score(pcd, feats, scores, n_points, rng=np.random):
+    """Score-weighted sampling without replacement (lib/tester.py:80-92); the draw stays on the host RNG."""
+    idx = draw_by_score(pcd.shape[0], scores, n_points, rng)
+    return take_drawn(pcd, feats, idx) + (idx,)

@@ -6,16 +6,19 @@ follow /root/reference/Predator_APR/models/architectures.py:9-212; a reference `
 unchanged.  `batch` is the dict built by `collate_fn_descriptor` (points / neighbors / pools /
 upsamples / stack_lengths / features), index tensors int32 or int64, everything on the GPU.
 """
-import numpy as np
+import os
 import threading
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from ... import ops
 from .. import kp_ops
-from .blocks import block_decider
+from .blocks import NearestUpsampleBlock, ResnetBottleneckBlock, _layer_inputs, block_decider
 from .gcn import GCN, _Packed, conv1x1
+
+CAT_BUFFERS = os.environ.get("APR_KP_CAT_BUFFERS", "1") != "0"     # A/B switch: 0 = torch.cat in front of the decoder's unary blocks
 
 
 def _is_level_change(name):
@@ -125,6 +128,29 @@ class KPFCNN(nn.Module):
         self._drop_temperature()
         return super()._apply(fn, *args, **kwargs)
 
+    def _cat_plan(self):
+        """{encoder block index: (skip width, upsampled width, buffer width)} for the decoder's concats: the k-th concat from
+        the END of the decoder consumes the k-th recorded skip, i.e. the output of the encoder block in front of it."""
+        plan = getattr(self, "_cat_plan_cache", None)
+        if plan is None:
+            plan = {}
+            skips = [i for i in self.encoder_skips if i < len(self.encoder_blocks)]      # inputs of these blocks are kept
+            for k, dec_i in enumerate(self.decoder_concats):
+                if k >= len(skips):
+                    break
+                src = skips[len(skips) - 1 - k] - 1                                      # the block that PRODUCES that input
+                dec = self.decoder_blocks[dec_i]
+                up = self.decoder_blocks[dec_i - 1] if dec_i > 0 else None
+                if src < 0 or not isinstance(up, NearestUpsampleBlock) or not hasattr(dec, "mlp"):
+                    continue
+                cs = self.encoder_blocks[src].out_dim
+                cx = dec.mlp.in_features - cs
+                if cx <= 0 or cs % 4 != 0:
+                    continue
+                plan[src] = (cs, cx, (cs + cx + 31) // 32 * 32)
+            self._cat_plan_cache = plan
+        return plan
+
     def regular_score(self, score):
         score = torch.where(torch.isnan(score), torch.zeros_like(score), score)
         return torch.where(torch.isinf(score), torch.zeros_like(score), score)
@@ -145,12 +171,24 @@ class KPFCNN(nn.Module):
             raise ValueError("KPFCNN: the batch must hold whole (source, target) pairs")
         pcd_c = batch['points'][-1]
 
-        # 1. joint encoder
-        skip_x = []
+        # 1. joint encoder.  Inference: an encoder output that the decoder later concatenates with an upsampled tensor
+        # (architectures.py:188-190) is written straight into the front columns of that concat buffer [skip | x | pad]
+        # (blocks.UnaryBlock._weight_cat); the three torch.cat copies and two padding copies of the decoder go away
+        skip_x, cat_bufs = [], []
+        plan = self._cat_plan() if (not grad and CAT_BUFFERS) else {}
         for block_i, block_op in enumerate(self.encoder_blocks):
             if block_i in self.encoder_skips:
                 skip_x.append(x)
-            x = block_op(x, batch)
+            if block_i in plan and isinstance(block_op, ResnetBottleneckBlock):
+                cs, cx, width = plan[block_i]
+                rows = _layer_inputs(block_op.block_name, block_op.layer_ind, batch)[0].shape[0]
+                buf = torch.empty((rows, width), dtype=torch.float32, device=x.device)
+                if width > cs + cx:
+                    buf[:, cs + cx:].zero_()
+                cat_bufs.append((buf, cs, cx))
+                x = block_op(x, batch, out=buf[:, :cs])
+            else:
+                x = block_op(x, batch)
 
         # 2. bottleneck projection (rows: [N_c, C])
         unconditioned_feats = conv1x1(x, self.bottle, self._c[0])
@@ -225,7 +263,16 @@ class KPFCNN(nn.Module):
 
         # 5. decoder
         for block_i, block_op in enumerate(self.decoder_blocks):
+            if cat_bufs and block_i + 1 in self.decoder_concats and isinstance(block_op, NearestUpsampleBlock):
+                buf, cs, cx = cat_bufs[-1]                       # the upsampled rows land behind the skip columns
+                block_op(x, batch, out=buf[:, cs:cs + cx])
+                continue
             if block_i in self.decoder_concats:
+                if cat_bufs:
+                    buf, cs, cx = cat_bufs.pop()
+                    skip_x.pop()
+                    x = block_op(buf, batch, cat=(cx, cs))
+                    continue
                 x = torch.cat([x, skip_x.pop()], dim=1)
             x = block_op(x, batch)
         x = x.contiguous()

@@ -9,16 +9,32 @@ state_dict loads unchanged.  Only the rigid KPConv the APR configs use is implem
 Inference runs the HIP kernels; when autograd is recording (training) every block switches
 to differentiable torch ops with the reference's formulation — KPConv backward kernels are a later round.
 """
+import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
 from torch.nn.init import kaiming_uniform_
 from torch.nn.parameter import Parameter
 
-from ... import ops
+from ... import _lib, ops
 from .. import kp_ops
 from ..kernels.kernel_points import load_kernels
+
+FUSED_BLOCK = os.environ.get("APR_KP_FUSED_BLOCK", "1") != "0"     # A/B switch: 0 = one library call per op of a block
+_SEG_ARRAYS = {}
+
+
+def _seg_array(seg):
+    """ctypes int64 array of a pair-offset list, cached by value (the same few lists recur at every block of a batch)."""
+    key = tuple(seg)
+    a = _SEG_ARRAYS.get(key)
+    if a is None:
+        if len(_SEG_ARRAYS) > 4096:
+            _SEG_ARRAYS.clear()
+        a = _SEG_ARRAYS[key] = (C.c_int64 * len(key))(*key)
+    return a
 
 
 def _param_key(*ts):
@@ -31,10 +47,10 @@ def max_pool(x, inds):
     return kp_ops.gather_pool(x, inds, "max")
 
 
-def closest_pool(x, inds):
+def closest_pool(x, inds, out=None):
     if kp_ops.tracking(x):
         return kp_ops.gather_pad(x, inds[:, 0])
-    return kp_ops.gather_pool(x, inds, "closest")
+    return kp_ops.gather_pool(x, inds, "closest", out=out)
 
 
 class KPConv(nn.Module):
@@ -113,14 +129,15 @@ class BatchNormBlock(nn.Module):
         else:
             self.bias = Parameter(torch.zeros(in_dim, dtype=torch.float32), requires_grad=True)
 
-    def forward(self, x, leaky=None, residual=None, segments=None):
+    def forward(self, x, leaky=None, residual=None, segments=None, out=None):
+        """`out` (inference only): a column slice that receives the result (a decoder concat buffer)."""
         if self.use_bn:
             return kp_ops.instance_norm_act(x, eps=self.batch_norm.eps, leaky=leaky, residual=residual,
-                                            segments=segments)
+                                            segments=segments, out=None if kp_ops.tracking(x, residual) else out)
         if kp_ops.tracking(x, self.bias, residual):
             y = x + self.bias
             return kp_ops._act(y if residual is None else y + residual, leaky, False)
-        return ops.affine_act(x, shift=self.bias, leaky=leaky, residual=residual)
+        return ops.affine_act(x, shift=self.bias, leaky=leaky, residual=residual, out=out)
 
 
 class UnaryBlock(nn.Module):
@@ -141,9 +158,25 @@ class UnaryBlock(nn.Module):
             self._key = key
         return self._packed
 
-    def forward(self, x, batch=None):
-        y = (kp_ops.linear_train(x, self.mlp.weight, self._weight()) if kp_ops.tracking(x, self.mlp.weight)
-             else kp_ops.linear(x, self._weight()))
+    def _weight_cat(self, cx, cs, width):
+        """The weight for a `[skip (cs) | x (cx) | zero pad]` concat buffer of `width` columns: the reference concatenates
+        [x, skip] (architectures.py:188-190), so the skip rows of W move to the front -- then both parts of the buffer start
+        on a 16-byte boundary and neither the torch.cat nor the padding copy is needed."""
+        key = (_param_key(self.mlp.weight), cx, cs, width)
+        if key != getattr(self, "_cat_key", None):
+            w = self.mlp.weight.detach().t()                                   # [cx + cs, out]
+            wp = torch.zeros((width, w.shape[1]), dtype=w.dtype, device=w.device)
+            wp[:cs], wp[cs:cs + cx] = w[cx:cx + cs], w[:cx]
+            self._cat_packed, self._cat_key = kp_ops.pack_linear(wp), key
+        return self._cat_packed
+
+    def forward(self, x, batch=None, cat=None):
+        """`cat = (cx, cs)`: x is a concat buffer laid out [skip | x | pad] (see _weight_cat)."""
+        if cat is not None:
+            y = kp_ops.linear(x, self._weight_cat(cat[0], cat[1], x.shape[1]))
+        else:
+            y = (kp_ops.linear_train(x, self.mlp.weight, self._weight()) if kp_ops.tracking(x, self.mlp.weight)
+                 else kp_ops.linear(x, self._weight()))
         return self.batch_norm(y, leaky=None if self.no_relu else 0.1, segments=pair_segments(batch, y))
 
 
@@ -154,7 +187,11 @@ class LastUnaryBlock(nn.Module):
         self.mlp = nn.Linear(in_dim, out_dim, bias=False)
         self._packed, self._key = None, None
 
-    def forward(self, x, batch=None):
+    _weight_cat = UnaryBlock._weight_cat
+
+    def forward(self, x, batch=None, cat=None):
+        if cat is not None:
+            return kp_ops.linear(x, self._weight_cat(cat[0], cat[1], x.shape[1]))
         if kp_ops.tracking(x, self.mlp.weight):
             return self.mlp(x)
         key = _param_key(self.mlp.weight)
@@ -217,8 +254,67 @@ class ResnetBottleneckBlock(nn.Module):
             if in_dim != out_dim else nn.Identity()
         self.leaky_relu = nn.LeakyReLU(0.1)
 
-    def forward(self, features, batch):
+    def _fused_ok(self, features, inds):
+        """One library call for the whole block (apr_kp_resnet_block): inference, InstanceNorm blocks, widths that the
+        bf16-split dense GEMM takes, rows 16-byte aligned.  APR_KP_FUSED_BLOCK=0 keeps the module-by-module path."""
+        return (FUSED_BLOCK and self.use_bn and not kp_ops.tracking(features, self.KPConv.weights) and kp_ops.PROFILE is None
+                and kp_ops.DENSE_BF3 and self.in_dim % 64 == 0 and self.out_dim % 256 == 0 and features.is_cuda
+                and features.dtype == torch.float32 and features.dim() == 2 and features.stride(1) == 1
+                and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0 and inds.dtype == torch.int32
+                and inds.is_contiguous() and features.shape[0] > 0 and inds.shape[0] > 0)
+
+    def _forward_fused(self, features, batch, q_pts, s_pts, inds, out=None):
+        """-> the block's output, or None when a weight has no bf16-split image (the caller takes the modular path)."""
+        w1 = self.unary1._weight()[5] if isinstance(self.unary1, UnaryBlock) else None
+        wk, w2 = self.KPConv._weight()[5], self.unary2._weight()[5]
+        ws = self.unary_shortcut._weight()[5] if isinstance(self.unary_shortcut, UnaryBlock) else None
+        if wk is None or w2 is None or (w1 is None) != isinstance(self.unary1, nn.Identity) \
+                or (ws is None) != isinstance(self.unary_shortcut, nn.Identity):
+            return None
+        lib = _lib.load()
+        strided = 'strided' in self.block_name
+        n_in, n_out = features.shape[0], q_pts.shape[0]
+        mid = self.out_dim // 4
+        d = _lib.KpResnetDesc()
+        d.x, d.ldx, d.n_in = features.data_ptr(), features.stride(0), n_in
+        d.in_dim, d.mid, d.out_dim, d.strided = self.in_dim, mid, self.out_dim, int(strided)
+        q_pts, s_pts = q_pts.contiguous(), s_pts.contiguous()
+        d.q_pts, d.s_pts, d.n_out = q_pts.data_ptr(), s_pts.data_ptr(), n_out
+        d.nbr, d.H, d.n_kp = inds.data_ptr(), inds.shape[1], self.KPConv.K
+        kpts = self.KPConv.kernel_points
+        d.kernel_points, d.extent = kpts.data_ptr(), float(self.KPConv.KP_extent)
+        d.eps, d.slope = float(self.unary2.batch_norm.batch_norm.eps), 0.1
+        d.w_unary1 = w1.data_ptr() if w1 is not None else None
+        d.w_kpconv, d.w_unary2 = wk.data_ptr(), w2.data_ptr()
+        d.w_shortcut = ws.data_ptr() if ws is not None else None
+        table = batch.get('pair_rows') if batch is not None else None
+        keep = [q_pts, s_pts, w1, wk, w2, ws]
+        if table:
+            seg_in, seg_out = table[n_in], table[n_out]
+            a_in, a_out = _seg_array(seg_in), _seg_array(seg_out)
+            d.seg_in, d.seg_out, d.nseg = C.addressof(a_in), C.addressof(a_out), len(seg_out) - 1
+            keep += [a_in, a_out]
+        else:
+            d.nseg = 1
+        if out is None:
+            out = torch.empty((n_out, self.out_dim), dtype=torch.float32, device=features.device)
+        d.out, d.ldo = out.data_ptr(), out.stride(0)
+        sb = int(lib.apr_kp_resnet_scratch_bytes(C.byref(d)))
+        scratch = torch.empty(sb, dtype=torch.uint8, device=features.device)
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), sb
+        _lib.check(lib.apr_kp_resnet_block(C.byref(d), _lib.stream()))
+        return out
+
+    def forward(self, features, batch, out=None):
+        """`out` (inference only): a [rows, out_dim] column slice of a decoder concat buffer that receives the result."""
         q_pts, s_pts, inds = _layer_inputs(self.block_name, self.layer_ind, batch)
+        if out is not None and (kp_ops.tracking(features, self.KPConv.weights) or tuple(out.shape) != (q_pts.shape[0], self.out_dim)
+                                or out.stride(1) != 1 or out.stride(0) % 4 != 0 or out.data_ptr() % 16 != 0):
+            raise ValueError("ResnetBottleneckBlock: `out` must be a 16-byte aligned [rows, out_dim] float32 slice (inference)")
+        if self._fused_ok(features, inds):
+            res = self._forward_fused(features, batch, q_pts, s_pts, inds, out)
+            if res is not None:
+                return res
         x = self.unary1(features, batch) if isinstance(self.unary1, UnaryBlock) else features
         x = self.KPConv(q_pts, s_pts, inds, x)
         seg = pair_segments(batch, x)
@@ -228,7 +324,7 @@ class ResnetBottleneckBlock(nn.Module):
             shortcut = self.unary_shortcut(shortcut, batch)
         # unary2 (no ReLU) + shortcut + LeakyReLU fused into the normalisation epilogue
         y = self.unary2.mlp(x) if kp_ops.tracking(x, self.unary2.mlp.weight) else kp_ops.linear(x, self.unary2._weight())
-        return self.unary2.batch_norm(y, leaky=0.1, residual=shortcut, segments=seg)
+        return self.unary2.batch_norm(y, leaky=0.1, residual=shortcut, segments=seg, out=out)
 
 
 class NearestUpsampleBlock(nn.Module):
@@ -236,8 +332,8 @@ class NearestUpsampleBlock(nn.Module):
         super().__init__()
         self.layer_ind = layer_ind
 
-    def forward(self, x, batch):
-        return closest_pool(x, batch['upsamples'][self.layer_ind - 1])
+    def forward(self, x, batch, out=None):
+        return closest_pool(x, batch['upsamples'][self.layer_ind - 1], out=out)
 
     def __repr__(self):
         return 'NearestUpsampleBlock(layer: {:d} -> {:d})'.format(self.layer_ind, self.layer_ind - 1)

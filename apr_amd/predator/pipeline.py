@@ -16,6 +16,39 @@ from .datasets.dataloader import calibrate_neighbors, collate_fn_descriptor   # 
 from .lib import benchmark_utils as BU
 
 
+_DRAW_POOL = None
+
+
+def _draw_pool():
+    """One helper thread per process for the host-RNG draws (see register_batch_phases)."""
+    global _DRAW_POOL
+    if _DRAW_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _DRAW_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="apr-draw")
+    return _DRAW_POOL
+
+
+class HostPending:
+    """A host job in flight on a helper thread, with the face of ops.PendingFetch: `.event.query()` / `.wait()` / `.finish()`
+    (apr_amd.fcgf.pipeline.run_pipelined and ops.drive treat both alike)."""
+
+    def __init__(self, future):
+        self._future = future
+        self.event = self
+
+    def query(self):
+        return self._future.done()
+
+    def synchronize(self):
+        self._future.result()
+
+    def wait(self):
+        self._future.result()
+
+    def finish(self):
+        return self._future.result()
+
+
 class PredatorRegistration:
     def __init__(self, model, config, neighborhood_limits, voxel_size=0.3, n_points=5000, distance_threshold=0.3,
                  max_iteration=50000, max_validation=1000):
@@ -94,13 +127,29 @@ class PredatorRegistration:
         wfetch = ops.PendingFetch(overlap * saliency, lambda host: host.copy())
         yield wfetch
         w_all = torch.from_numpy(wfetch.finish())
+        # the score-weighted draws of all pairs (NumPy's legacy choice on each pair's own RandomState: 0.39 ms of host time
+        # per pair, most of it inside the library's host function, which releases the GIL) run on a helper thread while the
+        # scheduler thread serves the other batches
+        spans = [(int(ends[2 * i] - lens[2 * i]), int(lens[2 * i]), int(lens[2 * i + 1])) for i in range(len(pairs))]
+
+        def draw_all():
+            out_ = []
+            for (a, n0, n1), seed in zip(spans, seeds):
+                rng = np.random.RandomState(seed)
+                i0 = BU.draw_by_score(n0, w_all[a:a + n0], self.n_points, rng)
+                i1 = BU.draw_by_score(n1, w_all[a + n0:a + n0 + n1], self.n_points, rng)
+                out_.append((i0, i1))
+            return out_
+
+        dfetch = HostPending(_draw_pool().submit(draw_all))
+        yield dfetch
+        drawn = dfetch.finish()
         raws, n01 = [], []
         for i, seed in enumerate(seeds):
-            a, b = int(ends[2 * i] - lens[2 * i]), int(ends[2 * i + 1])
-            n0, n1 = int(lens[2 * i]), int(lens[2 * i + 1])
-            rng = np.random.RandomState(seed)
-            s_p, s_f, _ = BU.sample_by_score(sub[2 * i], feats[a:a + n0], w_all[a:a + n0], self.n_points, rng=rng)
-            t_p, t_f, _ = BU.sample_by_score(sub[2 * i + 1], feats[a + n0:b], w_all[a + n0:b], self.n_points, rng=rng)
+            a, n0, n1 = spans[i]
+            b = a + n0 + n1
+            s_p, s_f = BU.take_drawn(sub[2 * i], feats[a:a + n0], drawn[i][0])
+            t_p, t_f = BU.take_drawn(sub[2 * i + 1], feats[a + n0:b], drawn[i][1])
             corr = ops.feature_nn(s_f.contiguous(), t_f.contiguous())
             raws.append(ops.ransac_pose_geometric_async(s_p, t_p, corr, self.distance_threshold, 0.9, self.max_iteration,
                                                         self.max_validation, seed))

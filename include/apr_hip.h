@@ -516,6 +516,29 @@ int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t cin, int
                        const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
                        float* out, int64_t ldo, void* stream);
 
+/* One ResnetBottleneckBlock of the KPConv encoder (Predator_APR/models/blocks.py:596-681; eval mode, use_batch_norm, rigid
+ * KPConv, widths multiples of 64) enqueued by ONE call: unary1 (Linear + InstanceNorm + LeakyReLU; absent when in_dim ==
+ * mid), KPConv (apr_row_sums, apr_kpconv_weighted, [n_out, n_kp mid] x [n_kp mid, mid]) + InstanceNorm + LeakyReLU, the
+ * shortcut (apr_gather_pool max over `nbr` when strided; Linear + InstanceNorm when in_dim != out_dim), unary2 (Linear) +
+ * InstanceNorm + shortcut + LeakyReLU -> out.  The same kernels in the same order as the single calls (same bits).
+ * Weights: apr_spconv_pack_weights_bf3(K = 1) images of the [cin, cout] matrices (w_kpconv: [n_kp * mid, mid]).  nbr:
+ * [n_out, H] rows of the n_in-row input level (the level's `neighbors`, or `pools` of the coarser level when strided);
+ * seg_in / seg_out: host row offsets (nseg + 1) of the scan pairs stacked at the input / output level (nseg <= 1: one
+ * statistic over all rows).  scratch: apr_kp_resnet_scratch_bytes(desc) device bytes. */
+typedef struct apr_kp_resnet_desc {
+  const float* x; int64_t ldx; int64_t n_in;
+  int32_t in_dim, mid, out_dim, strided;
+  const float* q_pts; const float* s_pts; int64_t n_out;
+  const int32_t* nbr; int32_t H; int32_t n_kp;
+  const float* kernel_points; float extent; float eps; float slope; int32_t nseg;
+  const void* w_unary1; const void* w_kpconv; const void* w_unary2; const void* w_shortcut;
+  const int64_t* seg_in; const int64_t* seg_out;
+  float* out; int64_t ldo;
+  void* scratch; size_t scratch_bytes;
+} apr_kp_resnet_desc;
+size_t apr_kp_resnet_scratch_bytes(const apr_kp_resnet_desc* desc);
+int apr_kp_resnet_block(const apr_kp_resnet_desc* desc, void* stream);
+
 /* Host-only (no device needed): ONE round of NumPy's legacy `RandomState.choice(n, size, replace=False, p=p)` loop
  * (Predator_APR/lib/tester.py:83-92 draws its 5000 interest points per cloud with it).  The caller owns the RNG: per
  * round it passes k = size - n_uniq uniforms from `random_sample`.  p: float64 working copy (zeroed in place for found

@@ -331,3 +331,49 @@ def test_softmax_matvec_kernels_agree(dev):
         assert torch.allclose(mid, old, rtol=2e-6, atol=2e-7) and torch.allclose(got, old, rtol=1e-5, atol=1e-6)
         ref = torch.softmax(a.double() @ b.double().t() / 0.0367, dim=1) @ w.double()
         assert rel_l2(got.cpu().double(), ref.cpu()) < 1e-5
+
+
+def test_fused_resnet_block_call_equals_the_modular_path(dev):
+    """apr_kp_resnet_block (a whole ResnetBottleneckBlock enqueued by ONE library call over one scratch arena) runs the
+    modules' own kernels in their order: the KPFCNN outputs are THE SAME BITS as with one library call per op
+    (blocks.FUSED_BLOCK = False), for one pair and for stacked pairs (per-pair InstanceNorm segments); every block shape
+    of the KITTI network takes part (plain, strided, with and without unary1 / shortcut Linear)."""
+    from apr_amd.predator.models import blocks
+    from apr_amd.predator.pipeline import PredatorRegistration
+    cfg = kitti_config()
+    np.random.seed(4)
+    torch.manual_seed(4)
+    model = KPFCNN(cfg).to(dev).eval()
+    pipe = PredatorRegistration(model, cfg, [38, 36, 36, 38], max_iteration=20000)
+    pairs = []
+    for s in range(2):
+        a, b, _ = synth.make_pair(40 + s, n_beams=32, n_azimuth=800 + 150 * s)
+        pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    kinds = {(isinstance(m.unary1, blocks.UnaryBlock), isinstance(m.unary_shortcut, blocks.UnaryBlock), 'strided' in m.block_name)
+             for m in model.modules() if isinstance(m, blocks.ResnetBottleneckBlock)}
+    assert len(kinds) >= 3
+    assert blocks.FUSED_BLOCK
+    fused_one = pipe.encode(*pairs[0])
+    fused_many = pipe.encode_batch(pairs)
+    blocks.FUSED_BLOCK = False
+    try:
+        plain_one = pipe.encode(*pairs[0])
+        plain_many = pipe.encode_batch(pairs)
+    finally:
+        blocks.FUSED_BLOCK = True
+    for a, b in zip(fused_one, plain_one):
+        assert torch.equal(a, b)
+    for fa, pa in zip(fused_many, plain_many):
+        for a, b in zip(fa, pa):
+            assert torch.equal(a, b)
+    # the decoder's concat buffers ([skip | upsampled | pad] written in place, weight rows permuted to match) change only the
+    # summation order of the three concat-consuming Linear layers
+    from apr_amd.predator.models import architectures
+    assert architectures.CAT_BUFFERS and model._cat_plan() == {7: (1024, 258, 1312), 4: (512, 129, 672), 1: (256, 64, 320)}
+    architectures.CAT_BUFFERS = False
+    try:
+        cat_one = pipe.encode(*pairs[0])
+    finally:
+        architectures.CAT_BUFFERS = True
+    assert torch.equal(cat_one[0], fused_one[0]) and rel_l2(fused_one[2].cpu().numpy(), cat_one[2].cpu().numpy()) < 1e-5
+    assert torch.allclose(fused_one[3], cat_one[3], atol=1e-5) and torch.allclose(fused_one[4], cat_one[4], atol=1e-5)
