@@ -459,34 +459,53 @@ __global__ __launch_bounds__(256) void k_radius(const float* __restrict__ q, int
   }
   const int total = __shfl(incl, 26);
   int nhit = 0;
-  for (int base = 0; base < total; base += 64) {
-    const int t = base + lane;
-    bool hit = false;
-    float d2 = 0.f;
-    int sidx = -1;
-    if (t < total) {
-      // cell range holding candidate t: first L with incl[L] > t (27 sorted entries: 5 LDS probes instead of a scan
-      // that averages 13)
-      int L = 0;
+  // Four 64-candidate batches per turn: a query has ~260 candidates in its 27 cells (6.4x the in-radius ones), and a batch
+  // is a chain of dependent fetches (cell range from LDS -> sorted[] -> the support point's coordinates).  Taken one batch
+  // at a time the wave sat through ~5 such chains back to back; here the index loads of four batches are issued together,
+  // then their coordinate loads, and the hits are appended in the same candidate order as before (same tables out).
+  for (int base = 0; base < total; base += 256) {
+    int sidx[4];
+    float px[4], py[4], pz[4];
 #pragma unroll
-      for (int step = 16; step >= 1; step >>= 1)
-        if (L + step <= 26 && s_incl[wave][L + step - 1] <= t) L += step;
-      const int before = L ? s_incl[wave][L - 1] : 0;
-      sidx = g.sorted[s_lo[wave][L] + (t - before)];
-      const float dx = __fsub_rn(qx, s[3 * (int64_t)sidx]), dy = __fsub_rn(qy, s[3 * (int64_t)sidx + 1]),
-                  dz = __fsub_rn(qz, s[3 * (int64_t)sidx + 2]);
-      d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      hit = d2 < r2;
-    }
-    const unsigned long long m = __ballot(hit);
-    if (MODE >= 1 && hit) {
-      const int pos = nhit + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < kHitCap) {
-        s_d[wave][pos] = d2;
-        s_i[wave][pos] = sidx;
+    for (int u = 0; u < 4; ++u) {
+      const int t = base + u * 64 + lane;
+      sidx[u] = -1;
+      if (t < total) {
+        // cell range holding candidate t: first L with incl[L] > t (27 sorted entries: 5 LDS probes instead of a scan
+        // that averages 13)
+        int L = 0;
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1)
+          if (L + step <= 26 && s_incl[wave][L + step - 1] <= t) L += step;
+        const int before = L ? s_incl[wave][L - 1] : 0;
+        sidx[u] = g.sorted[s_lo[wave][L] + (t - before)];
       }
     }
-    nhit += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      px[u] = py[u] = pz[u] = 0.f;
+      if (sidx[u] >= 0) {
+        px[u] = s[3 * (int64_t)sidx[u]];
+        py[u] = s[3 * (int64_t)sidx[u] + 1];
+        pz[u] = s[3 * (int64_t)sidx[u] + 2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (base + u * 64 >= total) break;               // wave-uniform
+      const float dx = __fsub_rn(qx, px[u]), dy = __fsub_rn(qy, py[u]), dz = __fsub_rn(qz, pz[u]);
+      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const bool hit = sidx[u] >= 0 && d2 < r2;
+      const unsigned long long m = __ballot(hit);
+      if (MODE >= 1 && hit) {
+        const int pos = nhit + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < kHitCap) {
+          s_d[wave][pos] = d2;
+          s_i[wave][pos] = sidx[u];
+        }
+      }
+      nhit += __popcll(m);
+    }
   }
   if (MODE == 0) {
     if (lane == 0) counts[qi] = nhit;
