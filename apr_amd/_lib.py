@@ -84,6 +84,7 @@ PROTOTYPES = {
     "apr_weighted_choice_round": (C.c_int64, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i32]),
     "apr_instance_norm_act_seg": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _i32, _p, _sz, _p]),
     "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _p]),
+    "apr_act_backward": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p]),
     "apr_l2_normalize": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
     "apr_feature_nn": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p]),
     "apr_feature_nn_fast_scratch_bytes": (_sz, [_i64, _i64, _i32]),
@@ -120,6 +121,7 @@ PROTOTYPES = {
     "apr_reverse_table_scratch_bytes": (_sz, [_i64, _i32, _i64]),
     "apr_reverse_table_build": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _sz, _p]),
     "apr_reverse_gather": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _i64, _p]),
+    "apr_reverse_gather_range": (C.c_int, [_p, _i32, _p, _p, _i64, _i64, _i64, _i32, _p, _i64, _p]),
     "apr_gather_pool": (C.c_int, [_p, _i64, _i64, _i32, _p, _i32, _i64, _i32, _p, _i64, _p]),
     "apr_edge_features": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "apr_group_max": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _f32, _p, _i64, _p]),

@@ -178,6 +178,19 @@ __global__ void k_affine_act(const float* __restrict__ x, int64_t ldx, int64_t n
   }
 }
 
+// dz = dy * act'(z) read off the activation's OUTPUT y (ReLU: y > 0; LeakyReLU with slope > 0: sign(y) = sign(z))
+__global__ void k_act_backward(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
+                               int64_t n, int c, int mode, float slope, float* __restrict__ dz, int64_t lddz) {
+  const int64_t total = n * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / c;
+    const int col = (int)(t - r * c);
+    const float g = dy[r * lddy + col];
+    const float o = y[r * ldy + col];
+    dz[r * lddz + col] = (mode == 0 || o > 0.f) ? g : (mode == 2 ? g * slope : 0.f);
+  }
+}
+
 // k_bn_finish + k_affine_act in one: a workgroup owns 64 columns x 64 rows; it first rebuilds the columns'
 // (scale, shift) from the block partials (every workgroup of a column repeats the same fixed-order sum: a few
 // hundred fp64 adds against a launch, a 4 KB round trip and a host-side call saved per normalisation), then
@@ -481,6 +494,22 @@ APR_API int apr_l2_normalize(const float* x, int64_t ldx, int64_t n, int32_t c, 
   if (n == 0) return APR_OK;
   hipLaunchKernelGGL(k_l2_normalize, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      n, c, y, ldy);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// Backward of the activation behind a normalisation (training path of KPFCNN's blocks, Predator_APR/models/blocks.py:459-468,
+// 489, 574 under lib/trainer.py:142-280): dz = dy where the forward's output y is positive, dy * negative_slope (mode 2,
+// LeakyReLU) or 0 (mode 1, ReLU) elsewhere; mode 0 copies.
+APR_API int apr_act_backward(const float* dy, int64_t lddy, const float* y, int64_t ldy, int64_t n, int32_t c, int32_t mode,
+                             float negative_slope, float* dz, int64_t lddz, void* stream) {
+  APR_CHECK_ARG(dy && y && dz && n >= 0 && c > 0 && lddy >= c && ldy >= c && lddz >= c && mode >= 0 && mode <= 2,
+                "apr_act_backward: bad arguments");
+  if (n == 0) return APR_OK;
+  int64_t nblk = cdiv64(n * c, 256);
+  if (nblk > 8192) nblk = 8192;
+  hipLaunchKernelGGL(k_act_backward, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, n, c, mode,
+                     negative_slope, dz, lddz);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

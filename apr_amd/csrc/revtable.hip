@@ -54,6 +54,44 @@ __global__ void k_rev_gather(const float* __restrict__ src, int c, const int* __
   *reinterpret_cast<f32x4*>(out + s * ldo + col) = acc;
 }
 
+// The same for the contributions of ONE CHUNK of the table: src holds the rows of flat positions [t_lo, t_hi) only (row
+// t - t_lo); a row's run is ascending in t, so the chunk's part of it is one contiguous piece, and with `accumulate` the
+// sum continues from the value the previous chunk left in out -- chunk after chunk in ascending t this performs exactly the
+// additions of k_rev_gather in exactly their order (same bits), with a contribution buffer 1 / nchunks the size.
+__global__ void k_rev_gather_range(const float* __restrict__ src, int c, const int* __restrict__ rev_t,
+                                   const int* __restrict__ start, int64_t ns, int t_lo, int t_hi, int accumulate,
+                                   float* __restrict__ out, int64_t ldo) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int c4 = c >> 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ns * c4) return;
+  const int64_t s = t / c4;
+  const int col = (int)(t - s * c4) * 4;
+  int e0 = start[s], e1 = start[s + 1];
+  // first entry with rev_t >= t_lo / >= t_hi (the run is sorted): two binary searches
+  auto lower = [&](int bound) {
+    int lo = e0, hi = e1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rev_t[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int a = lower(t_lo), b = lower(t_hi);
+  f32x4 acc = accumulate ? *reinterpret_cast<const f32x4*>(out + s * ldo + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int e = a; e < b; e += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = (e + u < b) ? *reinterpret_cast<const f32x4*>(src + (int64_t)(rev_t[e + u] - t_lo) * c + col)
+                         : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e + u < b) acc += v[u];
+  }
+  *reinterpret_cast<f32x4*>(out + s * ldo + col) = acc;
+}
+
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t sort_temp_bytes(int64_t total, int bits) {
@@ -110,6 +148,21 @@ APR_API int apr_reverse_gather(const float* src, int32_t c, const int32_t* rev_t
                 "apr_reverse_gather: needs c %% 4 == 0 and 16-byte aligned rows");
   hipLaunchKernelGGL(k_rev_gather, dim3((unsigned)cdiv64(ns * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, src, c, rev_t,
                      start, ns, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// apr_reverse_gather over the flat positions [t_lo, t_hi) of the table only: src f32 [t_hi - t_lo, c] holds their rows;
+// accumulate != 0 continues the sums already in out.  Calling it chunk by chunk in ascending t (first chunk with
+// accumulate = 0) gives the bits of one apr_reverse_gather over the whole table.
+APR_API int apr_reverse_gather_range(const float* src, int32_t c, const int32_t* rev_t, const int32_t* start, int64_t ns,
+                                     int64_t t_lo, int64_t t_hi, int32_t accumulate, float* out, int64_t ldo, void* stream) {
+  APR_CHECK_ARG(src && rev_t && start && out && ns > 0 && c > 0 && c % 4 == 0 && ldo >= c && ldo % 4 == 0 &&
+                    ((((uintptr_t)src) | ((uintptr_t)out)) & 15) == 0,
+                "apr_reverse_gather_range: needs c %% 4 == 0 and 16-byte aligned rows");
+  APR_CHECK_ARG(t_lo >= 0 && t_hi >= t_lo && t_hi < (1ll << 31), "apr_reverse_gather_range: bad position range");
+  hipLaunchKernelGGL(k_rev_gather_range, dim3((unsigned)cdiv64(ns * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, src, c,
+                     rev_t, start, ns, (int)t_lo, (int)t_hi, accumulate, out, ldo);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

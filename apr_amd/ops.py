@@ -752,13 +752,16 @@ def norm_params(x, eps):
     return ss[0], ss[1]
 
 
-def norm_backward(x, dy, mean, rstd, gamma=None, want_affine_grads=True):
-    """dx (and dgamma, dbeta) of y = (x - mean) * rstd * gamma + beta over all rows (apr_norm_backward)."""
+def norm_backward(x, dy, mean, rstd, gamma=None, want_affine_grads=True, out=None):
+    """dx (and dgamma, dbeta) of y = (x - mean) * rstd * gamma + beta over all rows (apr_norm_backward).  `out`: a contiguous
+    [n, c] tensor (e.g. a row slice) that receives dx."""
     x, ldx = _rows(x, "norm_backward.x")
     dy, lddy = _rows(dy, "norm_backward.dy")
     n, c = x.shape
     lib = _lib_()
-    dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    if out is not None and (tuple(out.shape) != (n, c) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise _lib.AprHipError("norm_backward: `out` must be a contiguous float32 [n, c] tensor")
+    dx = out if out is not None else torch.empty((n, c), dtype=torch.float32, device=x.device)
     dg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
     db = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine_grads else None
     sb = int(lib.apr_norm_backward_scratch_bytes(n, c))

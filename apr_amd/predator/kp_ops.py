@@ -106,9 +106,8 @@ class LinearFunction(torch.autograd.Function):
 
 
 def linear_train(x, weight, wp_info):
-    """The tracked (training) form of a bias-free Linear: HIP kernels when both widths are multiples of 64, torch otherwise."""
-    cout, cin = weight.shape
-    if HIP_TRAIN_LINEAR and cin % 64 == 0 and cout % 64 == 0 and x.shape[0] > 0:
+    """The tracked (training) form of a bias-free Linear: forward, d x and d W on the HIP kernels (LinearFunction)."""
+    if HIP_TRAIN_LINEAR and x.shape[0] > 0 and x.dim() == 2:      # any width: `linear` pads to the GEMM's granule
         return LinearFunction.apply(x, weight, wp_info)
     return torch.nn.functional.linear(x, weight)
 
@@ -178,6 +177,7 @@ def reverse_table(nbr, ns):
 
 
 DET_DX = os.environ.get("APR_KPCONV_DX", "det") != "atomic"     # A/B switch: "atomic" = round 2's float-atomic scatter
+DX_CHUNK_BYTES = int(os.environ.get("APR_KPCONV_DX_CHUNK_MB", "64")) << 20     # contribution rows in flight per chunk
 
 
 class KPConvFunction(torch.autograd.Function):
@@ -216,16 +216,24 @@ class KPConvFunction(torch.autograd.Function):
             rs = row_sums(x)
             lib = _lib.load()
             nq, H, ns = q_pts.shape[0], inds.shape[1], s_pts.shape[0]
-            if DET_DX and cin % 4 == 0 and nq * H * cin * 4 <= (8 << 30):
+            if DET_DX and cin % 4 == 0 and nq * H < (1 << 31):
                 # deterministic: one contribution row per (query, neighbour), summed per support row in the fixed order of the
-                # reverse table (no float atomics: the same bits every run)
+                # reverse table (no float atomics: the same bits every run).  The queries go through in chunks whose
+                # contribution rows fit DX_CHUNK_BYTES (64 MB; unchunked the finest level of one pair needs 400 MB): a
+                # support row's run is ascending in the flat position q * H + h, so chunk after chunk the gather continues
+                # the same sequence of additions -- the bits do not depend on the chunk size (tested).
                 rev_t, start = reverse_table(inds, ns)
-                contrib = torch.empty((nq * H, cin), dtype=torch.float32, device=x.device)
-                check(lib.apr_kpconv_dfeat_contrib(ptr(q_pts.contiguous()), nq, ptr(s_pts.contiguous()), ns, ptr(inds), H,
-                                                   ptr(dwf), lddwf, cin, ptr(kernel_points.contiguous()),
-                                                   kernel_points.shape[0], ctx.extent, ptr(rs), ptr(contrib), stream()))
+                qc = max(1, min(nq, DX_CHUNK_BYTES // max(1, H * cin * 4)))
+                contrib = torch.empty((min(nq, qc) * H, cin), dtype=torch.float32, device=x.device)
                 dx = torch.empty_like(x)
-                check(lib.apr_reverse_gather(ptr(contrib), cin, ptr(rev_t), ptr(start), ns, ptr(dx), dx.stride(0), stream()))
+                qp, sp, kp = q_pts.contiguous(), s_pts.contiguous(), kernel_points.contiguous()
+                for q0 in range(0, nq, qc):
+                    q1 = min(nq, q0 + qc)
+                    check(lib.apr_kpconv_dfeat_contrib(ptr(qp[q0:q1]), q1 - q0, ptr(sp), ns, ptr(inds[q0:q1]), H,
+                                                       ptr(dwf[q0:q1]), lddwf, cin, ptr(kp), kp.shape[0], ctx.extent, ptr(rs),
+                                                       ptr(contrib), stream()))
+                    check(lib.apr_reverse_gather_range(ptr(contrib), cin, ptr(rev_t), ptr(start), ns, q0 * H, q1 * H,
+                                                       int(q0 > 0), ptr(dx), dx.stride(0), stream()))
             else:
                 dx = torch.zeros_like(x)
                 check(lib.apr_kpconv_dfeat(ptr(q_pts.contiguous()), nq, ptr(s_pts.contiguous()), ns, ptr(inds), H, ptr(dwf),
@@ -313,14 +321,60 @@ def score_head(x_col):
     return out
 
 
+class NormActFunction(torch.autograd.Function):
+    """act(instance_norm(x) (+ residual)) -- KPFCNN's BatchNormBlock + LeakyReLU (+ shortcut), blocks.py:459-468, 489, 574,
+    653-681 -- with forward AND backward on the HIP kernels: the forward is the fused inference launch pair
+    (apr_instance_norm_act[_seg]); the backward turns dy into dz through the activation's own output (apr_act_backward), hands
+    dz to the residual branch as it is, and runs apr_norm_backward per pair segment with the segment's statistics
+    (apr_bn_stats, recomputed: nothing but x and the output is kept).  No torch op between them."""
+
+    @staticmethod
+    def forward(ctx, x, residual, eps, leaky, relu, segments):
+        x = x.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        with torch.no_grad():
+            y = instance_norm_act(x.detach(), eps=eps, leaky=leaky, relu=relu,
+                                  residual=None if res is None else res.detach(), segments=segments)
+        ctx.save_for_backward(x, y)
+        ctx.cfg = (float(eps), leaky, bool(relu), None if segments is None else list(segments), res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        eps, leaky, relu, segments, has_res = ctx.cfg
+        dy = dy.contiguous()
+        n, c = x.shape
+        mode = 2 if leaky is not None else int(relu)
+        dz = dy
+        if mode:
+            dz = torch.empty_like(dy)
+            check(_lib.load().apr_act_backward(ptr(dy), c, ptr(y), c, n, c, mode, float(leaky or 0.0), ptr(dz), c, stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            segs = segments if (segments is not None and len(segments) > 2) else [0, n]
+            dx = torch.empty_like(x)
+            for a, b in zip(segs[:-1], segs[1:]):
+                mean, var = ops.bn_stats(x[a:b])
+                rstd = torch.rsqrt(var + eps)
+                ops.norm_backward(x[a:b], dz[a:b], mean, rstd, None, want_affine_grads=False, out=dx[a:b])
+        return dx, (dz if has_res and ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+HIP_TRAIN_NORMACT = os.environ.get("APR_HIP_TRAIN_NORMACT", "1") != "0"   # A/B switch: 0 = norm on HIP, activation / residual add in torch
+
+
 def instance_norm_act(x, eps=1e-5, leaky=None, relu=False, residual=None, out=None, segments=None):
     """Per-channel normalisation over all rows, no affine (InstanceNorm1d on [1,C,N]) + activation.
     `segments`: row offsets [0, ..., n] of the scan pairs stacked in x (one statistic per pair and channel)."""
     if segments is not None and len(segments) <= 2:
         segments = None
     if tracking(x, residual):
-        # training: statistics, normalisation and its backward on the HIP kernels (ops.NormFunction, no affine); the
-        # activation / residual add stay elementwise torch ops
+        if HIP_TRAIN_NORM and HIP_TRAIN_NORMACT and x.dim() == 2 and x.shape[0] > 0:
+            # training: the fused forward launches, and a backward of apr_act_backward + apr_norm_backward (no torch op)
+            return NormActFunction.apply(x, residual, eps, leaky, relu, segments)
+        # statistics, normalisation and its backward on the HIP kernels (ops.NormFunction, no affine); the
+        # activation / residual add as elementwise torch ops
         nf = lambda t: ops.NormFunction.apply(t, None, None, eps)[0] if HIP_TRAIN_NORM else instance_norm_rows(t, eps)
         if segments is None:
             y = nf(x)

@@ -192,12 +192,12 @@ class LastUnaryBlock(nn.Module):
     def forward(self, x, batch=None, cat=None):
         if cat is not None:
             return kp_ops.linear(x, self._weight_cat(cat[0], cat[1], x.shape[1]))
-        if kp_ops.tracking(x, self.mlp.weight):
-            return self.mlp(x)
         key = _param_key(self.mlp.weight)
         if key != self._key:
             self._packed = kp_ops.pack_linear(self.mlp.weight.detach().t())
             self._key = key
+        if kp_ops.tracking(x, self.mlp.weight):
+            return kp_ops.linear_train(x, self.mlp.weight, self._packed)
         return kp_ops.linear(x, self._packed)
 
 

@@ -326,6 +326,10 @@ int apr_affine_act(const float* x, int64_t ldx, int64_t n, int32_t c,
                    const float* scale, const float* shift,
                    const float* residual, int64_t ldr, int32_t relu, float negative_slope,
                    float* y, int64_t ldy, void* stream);
+/* Backward of that activation from its OUTPUT y: dz = dy where y > 0, dy * negative_slope (mode 2) or 0 (mode 1) elsewhere;
+ * mode 0 copies (training path: Predator_APR/models/blocks.py:459-468 under lib/trainer.py:142-280). */
+int apr_act_backward(const float* dy, int64_t lddy, const float* y, int64_t ldy, int64_t n, int32_t c, int32_t mode,
+                     float negative_slope, float* dz, int64_t lddz, void* stream);
 
 /* Row L2 normalisation F / ||F||_2 (FCGF_APR/model/resunet.py:187-191). */
 int apr_l2_normalize(const float* x, int64_t ldx, int64_t n, int32_t c,
@@ -578,6 +582,11 @@ int apr_reverse_table_build(const int32_t* nbr, int64_t nq, int32_t H, int64_t n
                             void* scratch, size_t scratch_bytes, void* stream);
 int apr_reverse_gather(const float* src, int32_t c, const int32_t* rev_t, const int32_t* start, int64_t ns, float* out,
                        int64_t ldo, void* stream);
+/* The same over the flat positions [t_lo, t_hi) only (src f32 [t_hi - t_lo, c]: their rows), continuing the sums in `out`
+ * when accumulate != 0: chunk after chunk in ascending t this is bit for bit one apr_reverse_gather over the whole table
+ * with a contribution buffer the size of ONE chunk (the finest KPConv level of one pair needs 400 MB unchunked). */
+int apr_reverse_gather_range(const float* src, int32_t c, const int32_t* rev_t, const int32_t* start, int64_t ns,
+                             int64_t t_lo, int64_t t_hi, int32_t accumulate, float* out, int64_t ldo, void* stream);
 
 /* mode 0: max_pool(x, inds) (blocks.py:86-102); mode 1: closest_pool(x, inds) (blocks.py:71-83).
  * Index ns addresses an implicit all-zero shadow row. */

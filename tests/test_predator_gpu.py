@@ -224,6 +224,17 @@ def test_kpconv_backward_kernels_match_autograd_through_oracle(dev):
         out2 = kp_ops.KPConvFunction.apply(q.to(dev), s.to(dev), inds.to(dev), xg, Wg, kp.to(dev), 1.2)
         (out2 * proj.to(dev)).sum().backward()
         assert torch.equal(xg.grad, g1), (cin, cout)
+        # ... and on any chunking of the queries (apr_reverse_gather_range continues the same sequence of additions): one
+        # chunk, ragged chunks of a few dozen queries, a chunk per query block of 1 MB
+        for chunk_bytes in (1 << 40, 37 * H * cin * 4, 1 << 20):
+            old_chunk, kp_ops.DX_CHUNK_BYTES = kp_ops.DX_CHUNK_BYTES, chunk_bytes
+            try:
+                xc = x.to(dev).requires_grad_(True)
+                (kp_ops.KPConvFunction.apply(q.to(dev), s.to(dev), inds.to(dev), xc, W.to(dev), kp.to(dev), 1.2)
+                 * proj.to(dev)).sum().backward()
+            finally:
+                kp_ops.DX_CHUNK_BYTES = old_chunk
+            assert torch.equal(xc.grad, g1), (cin, cout, chunk_bytes)
         kp_ops.DET_DX = False
         try:
             xa = x.to(dev).requires_grad_(True)
@@ -377,3 +388,55 @@ def test_fused_resnet_block_call_equals_the_modular_path(dev):
         architectures.CAT_BUFFERS = True
     assert torch.equal(cat_one[0], fused_one[0]) and rel_l2(fused_one[2].cpu().numpy(), cat_one[2].cpu().numpy()) < 1e-5
     assert torch.allclose(fused_one[3], cat_one[3], atol=1e-5) and torch.allclose(fused_one[4], cat_one[4], atol=1e-5)
+
+
+@pytest.mark.parametrize("n,c,segs,leaky,relu,with_res", [
+    (3000, 64, None, 0.1, False, False), (2501, 129, [0, 1000, 2501], 0.1, False, True), (700, 34, [0, 300, 700], None, False, True),
+    (1500, 256, [0, 400, 900, 1500], None, True, False), (257, 32, None, None, False, False)])
+def test_norm_act_training_function_gradients(dev, n, c, segs, leaky, relu, with_res):
+    """kp_ops.NormActFunction (KPFCNN's InstanceNorm + activation + shortcut in training: fused HIP forward, backward =
+    apr_act_backward + apr_norm_backward per pair segment) against fp64 torch autograd of the reference's formulation
+    (Predator_APR/models/blocks.py:459-468, 489, 574): value, d x and d residual; odd widths, ragged segments."""
+    rng = np.random.default_rng(n + c)
+    x = torch.from_numpy((rng.standard_normal((n, c)) * 2 + 0.5).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)) if with_res else None
+    proj = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32))
+    xd = x.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True) if with_res else None
+    parts = []
+    for a, b in zip((segs or [0, n])[:-1], (segs or [0, n])[1:]):
+        t = xd[a:b]
+        parts.append((t - t.mean(0, keepdim=True)) / torch.sqrt(t.var(0, unbiased=False, keepdim=True) + 1e-5))
+    z = torch.cat(parts, 0)
+    if with_res:
+        z = z + rd
+    ref = torch.nn.functional.leaky_relu(z, leaky) if leaky is not None else (torch.relu(z) if relu else z)
+    (ref * proj.double()).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    rg = res.to(dev).requires_grad_(True) if with_res else None
+    assert kp_ops.HIP_TRAIN_NORM and kp_ops.HIP_TRAIN_NORMACT
+    out = kp_ops.instance_norm_act(xg, eps=1e-5, leaky=leaky, relu=relu, residual=rg, segments=segs)
+    assert out.requires_grad and out.grad_fn is not None and "NormAct" in type(out.grad_fn).__name__
+    (out * proj.to(dev)).sum().backward()
+    assert rel_l2(out.detach().cpu(), ref.detach()) < 2e-6
+    assert rel_l2(xg.grad.cpu(), xd.grad) < 2e-5
+    if with_res:
+        assert rel_l2(rg.grad.cpu(), rd.grad) < 2e-6
+
+
+@pytest.mark.parametrize("n,cin,cout", [(2000, 1282, 129), (900, 641, 64), (5000, 320, 34), (333, 64, 64), (100, 129, 258)])
+def test_linear_training_function_any_width(dev, n, cin, cout):
+    """kp_ops.LinearFunction for widths that are not multiples of 64 (the decoder's 1282 -> 129, 641 -> 64, 320 -> 34 of
+    Predator_APR/models/architectures.py:96-123): forward, d x and d W on the HIP kernels against fp64 autograd."""
+    rng = np.random.default_rng(cin + cout)
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32))
+    W = torch.from_numpy((rng.standard_normal((cout, cin)) / np.sqrt(cin)).astype(np.float32))
+    proj = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32))
+    xd, Wd = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    (torch.nn.functional.linear(xd, Wd) * proj.double()).sum().backward()
+    xg, Wg = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    y = kp_ops.linear_train(xg, Wg, kp_ops.pack_linear(Wg.detach().t()))
+    assert "LinearFunction" in type(y.grad_fn).__name__
+    (y * proj.to(dev)).sum().backward()
+    assert rel_l2(y.detach().cpu(), torch.nn.functional.linear(x.double(), W.double())) < 2e-6
+    assert rel_l2(xg.grad.cpu(), xd.grad) < 2e-6 and rel_l2(Wg.grad.cpu(), Wd.grad) < 2e-6
