@@ -434,6 +434,7 @@ class PairList:
 
     def __init__(self, counters, blob, nbr, built):
         self.counters, self.blob, self.nbr, self.built = counters, blob, nbr, built
+        self.queued = False      # its build rides in a SpconvBatch that has not been launched yet
         self.n_out, self.K = nbr.shape
 
     def prod_scratch(self, cout):
@@ -441,6 +442,8 @@ class PairList:
         return torch.empty(self.n_out * self.K * cout, dtype=torch.float32, device=self.blob.device)
 
     def build(self):
+        if self.queued:      # a second build would add to the (already reserved) range counters
+            raise _lib.AprHipError("PairList: its build is queued in a SpconvBatch that has not been launched yet")
         if not self.built:
             check(_lib_().apr_pairlist_build(ptr(self.nbr), self.n_out, self.K, ptr(self.counters), ptr(self.blob),
                                              self.blob.numel(), stream()))
@@ -485,9 +488,10 @@ class OsPairs:
         nb = int(_lib_().apr_spconv_os_pairs_bytes(self.n_out, self.K, self.R))
         self.blob = torch.empty(nb, dtype=torch.uint8, device=nbr.device)
         self.built = False
+        self.queued = False      # its build rides in a SpconvBatch that has not been launched yet
 
     def build(self):
-        if not self.built:
+        if not self.built and not self.queued:
             check(_lib_().apr_spconv_os_pairs_build(ptr(self.nbr), self.n_out, self.n_in, self.K, self.R, ptr(self.blob),
                                                     self.blob.numel(), stream()))
             self.built = True
@@ -526,6 +530,8 @@ def spconv_os(x, os_pairs, cin, cout, w_bf3, scale=None, shift=None, residual=No
             raise _lib.AprHipError("spconv_os: residual shape mismatch")
     if w_bf3 is None:
         raise _lib.AprHipError("spconv_os: needs the bf16-split weights (pack_weights_bf3)")
+    if os_pairs.queued:
+        raise _lib.AprHipError("spconv_os: the tile pair lists are queued for building in a SpconvBatch that has not been launched")
     os_pairs.build()
     check(_lib_().apr_spconv_os_fwd(ptr(x), ldi, ptr(os_pairs.blob), n_out, K, os_pairs.R, cin, cout, ptr(w_bf3),
                                     ptr(scale), ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo, stream()))
@@ -661,6 +667,7 @@ class SpconvBatch:
         self.keep = []      # tensors referenced by raw pointers stay alive until the launch call returns
         self.prod = {}      # weight-stationary product buffers by size
         self.meta = []      # (P, cin, cout, mfma?, path) per launch while a SpconvProfile is active
+        self.pending = []   # pair lists whose build rides in this batch: marked built when the batch has been launched
 
     def add(self, x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu=False, out=None, n_out=None,
             plist=None, w_bf3=None, os_pairs=None, l2norm=False):
@@ -689,8 +696,9 @@ class SpconvBatch:
             if os_pairs.n_out != n_out or os_pairs.K != K:
                 raise _lib.AprHipError("spconv: tile pair lists do not belong to this kernel map")
             d.os_pairs, d.os_rows, d.os_n_in, d.w_bf3 = os_pairs.blob.data_ptr(), os_pairs.R, os_pairs.n_in, w_bf3.data_ptr()
-            if not os_pairs.built:
-                d.os_build_bytes, os_pairs.built = os_pairs.blob.numel(), True
+            if not os_pairs.built and not os_pairs.queued:      # built by this batch's launch; `built` is set there
+                d.os_build_bytes, os_pairs.queued = os_pairs.blob.numel(), True
+                self.pending.append(os_pairs)
             plist = None
         if plist is not None and nbr is not None and ws_supported(K, cin, cout):
             if plist.n_out != n_out or plist.K != K:
@@ -702,8 +710,9 @@ class SpconvBatch:
             d.counters, d.plist, d.prod_scratch = plist.counters.data_ptr(), plist.blob.data_ptr(), prod.data_ptr()
             if w_bf3 is not None:
                 d.w_bf3 = w_bf3.data_ptr()
-            if not plist.built:
-                d.plist_bytes, plist.built = plist.blob.numel(), True
+            if not plist.built and not plist.queued:
+                d.plist_bytes, plist.queued = plist.blob.numel(), True
+                self.pending.append(plist)
         self.descs.append(d)
         if PROFILE is not None:
             self.meta.append((PROFILE.pairs(nbr, n_out), cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0,
@@ -721,7 +730,9 @@ class SpconvBatch:
             PROFILE.records += [m[:4] + (float(t), None, m[4]) for m, t in zip(self.meta, ms)]
         else:
             check(_lib_().apr_spconv_fwd_batch(arr, len(self.descs), stream()))
-        self.descs, self.keep, self.prod, self.meta = [], [], {}, []
+        for pl in self.pending:
+            pl.built, pl.queued = True, False
+        self.descs, self.keep, self.prod, self.meta, self.pending = [], [], {}, [], []
 
 
 # ----------------------------------------------------------------------------
