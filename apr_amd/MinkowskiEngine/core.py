@@ -199,17 +199,18 @@ class CoordinateManager:
                 pos += sz
         return self._tpool.pop(ts_fine, None)      # handed out once: the table is written into
 
-    def pair_list(self, ts_in, ts_out, kernel_size, transpose=False):
-        """Per-offset pair lists of kernel_map(...) for the weight-stationary conv path (cached per map)."""
-        key = (ts_in, ts_out, kernel_size, transpose)
+    def pair_list(self, ts_in, ts_out, kernel_size, transpose=False, triples=False):
+        """Per-offset pair lists of kernel_map(...) for the weight-stationary conv path (cached per map); `triples`: the
+        x-triple entry lists of a 27-offset map instead (ops.PairList3: half the product rows)."""
+        key = ("ws3" if triples else "ws", ts_in, ts_out, kernel_size, transpose)
         pl = self._plists.get(key)
         if pl is None:
             nbr = self.kernel_map(ts_in, ts_out, kernel_size, transpose)
             if self._plist_counters is None:      # one fill clears the counters of every map of this manager
                 self._plist_counters = torch.zeros((16, ops.pair_counter_ints()), dtype=torch.int32, device=nbr.device)
-            slot = len(self._plists)
-            pl = ops.build_pairlist(nbr, lazy=True,
-                                    counters=self._plist_counters[slot] if slot < 16 else None)
+            slot = sum(1 for k in self._plists if k[0] in ("ws", "ws3"))
+            build = ops.build_pairlist3 if triples else ops.build_pairlist
+            pl = build(nbr, lazy=True, counters=self._plist_counters[slot] if slot < 16 else None)
             self._plists[key] = pl
         return pl
 

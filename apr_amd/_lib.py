@@ -36,7 +36,7 @@ class SpconvDesc(C.Structure):
                 ("counters", C.c_void_p), ("plist", C.c_void_p), ("prod_scratch", C.c_void_p),
                 ("plist_bytes", C.c_int64), ("w_bf3", C.c_void_p),
                 ("os_pairs", C.c_void_p), ("os_rows", C.c_int64), ("os_build_bytes", C.c_int64),
-                ("os_n_in", C.c_int64), ("l2norm", C.c_int32), ("reserved_", C.c_int32)]
+                ("os_n_in", C.c_int64), ("l2norm", C.c_int32), ("ws3", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
@@ -59,6 +59,10 @@ PROTOTYPES = {
     "apr_pairlist_counter_ints": (_i32, []),
     "apr_pairlist_bytes": (_sz, [_i64, _i32]),
     "apr_pairlist_build": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
+    "apr_pairlist3_bytes": (_sz, [_i64]),
+    "apr_pairlist3_build": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
+    "apr_spconv_ws3_supported": (C.c_int, [_i32, _i32, _i32]),
+    "apr_spconv_ws3_fwd_bf3": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "apr_spconv_packed_bf3_bytes": (_i64, [_i32, _i32, _i32]),
     "apr_spconv_pack_weights_bf3": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),

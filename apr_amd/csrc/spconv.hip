@@ -697,6 +697,15 @@ static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e
     int rco = apr_spconv_os_fwd(d.in, d.ldi, d.os_pairs, d.n_out, d.K, (int32_t)d.os_rows, d.cin, d.cout, d.w_bf3, d.scale,
                                 d.shift, d.residual, d.ldr, d.relu, d.out, d.ldo, stream);
     if (rco != APR_OK) return rco;
+  } else if (d.plist && d.ws3 && d.w_bf3) {   // triple pair lists: half the product rows (spconv_ws.hip)
+    if (d.plist_bytes > 0) {
+      int rcb = apr_pairlist3_build(d.nbr, d.n_out, d.K, d.counters, d.plist, (size_t)d.plist_bytes, stream);
+      if (rcb != APR_OK) return rcb;
+    }
+    if (e0) APR_HIP(hipEventRecord(e0, st));
+    int rcw = apr_spconv_ws3_fwd_bf3(d.in, d.ldi, d.counters, d.plist, d.n_out, d.cin, d.cout, d.w_bf3, d.scale, d.shift,
+                                     d.residual, d.ldr, d.relu, d.out, d.ldo, d.prod_scratch, stream);
+    if (rcw != APR_OK) return rcw;
   } else if (d.plist) {
     if (d.plist_bytes > 0) {   // the pair-list build is per map, not part of the timed conv layer
       int rcb = apr_pairlist_build(d.nbr, d.n_out, d.K, d.counters, d.plist, (size_t)d.plist_bytes, stream);

@@ -466,6 +466,271 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_ws_gemm_bf3(const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Triple pair lists + k_ws3_gemm_bf3: HALF the product rows for 3^3 maps.
+// The weight-stationary pair writes one product row per kernel-map pair and k_ws_reduce reads it back: 1.57x the layer's
+// algorithmic bytes through the fabric (PMC), which is what bounds the family.  Offsets are enumerated x fastest, so
+// k = 3t + j (j = 0, 1, 2) are the three x-neighbours of one (dy, dz): on surfaces they come together -- a row that has one
+// of them usually has two or three.  A TRIPLE entry is (output row, its up to three input rows of triple t); the gemm unit
+// is (triple t, 64 G consecutive entries, 64 output columns) with the three weight slices W[3t + j][:, 64] in LDS, a 16-entry
+// group runs its 3 x cin/64 chunks into the SAME 16 accumulator registers (an absent neighbour gathers a zero row), and ONE
+// product row leaves per entry: measured entries / pairs on the KITTI maps ~0.5.  The inner loop is the barrier-free step
+// pipeline of k_ws_gemm_bf3; MFMA work grows by the zero-padded share (~1.6x of a pipe that was 30 % busy), the product
+// traffic -- written by the gemm, read by the reduce -- halves.  The reduce is k_ws_reduce over 9 ids per row.
+// cin 64 (two 72 KB workgroups per CU) and 128 (one 144 KB workgroup of 8 waves); K = 27 only.
+constexpr int kRows3 = 256;
+struct Pair3Views {
+  PairHeader* hdr;   // counters of the 9 triples at cnt[t * kCntStride]
+  int* ent;          // [9][n_out][3] input rows (-1: absent) of the entries of triple t, at its region's head
+  int* pair_id;      // [n_out][9] position of the row's entry in triple t (t * n_out + rank) or -1
+};
+
+__host__ __device__ inline Pair3Views carve_pairs3(int32_t* counters, void* blob, int64_t n_out) {
+  Pair3Views v;
+  v.hdr = (PairHeader*)counters;
+  v.ent = (int*)blob;
+  v.pair_id = (int*)((char*)blob + align256((size_t)n_out * 9 * 12));
+  return v;
+}
+
+__device__ float g_zero_row[512];      // zero-initialised: the row an absent neighbour of a triple is gathered from
+
+__global__ __launch_bounds__(64 * kBuildWaves) void k_pairs3_build(const int* __restrict__ nbr, int n_out, Pair3Views v) {
+  __shared__ int s_nbr[kRows3 * 27 + 64];
+  __shared__ int s_id[kRows3 * 9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * kRows3;
+  const int rows = min(kRows3, n_out - row0);
+  const int total = rows * 27;
+  const int* src = nbr + (int64_t)row0 * 27;
+  for (int e0 = threadIdx.x; e0 < total; e0 += 9 * 64 * kBuildWaves) {
+    int t[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int e = e0 + u * 64 * kBuildWaves;
+      t[u] = (e < total) ? src[e] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int e = e0 + u * 64 * kBuildWaves;
+      if (e < total) s_nbr[e] = t[u];
+    }
+  }
+  __syncthreads();
+  auto any3 = [&](int r, int t) {
+    const int* p = &s_nbr[r * 27 + 3 * t];
+    return (p[0] & p[1] & p[2]) >= 0;      // some index non-negative <=> the AND of the three has its sign bit clear
+  };
+  int base[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int t = wave + kBuildWaves * s2;
+    base[s2] = 0;
+    if (t < 9) {
+      int cnt = 0;
+#pragma unroll
+      for (int c = 0; c < kRows3 / 64; ++c) {
+        const int r = c * 64 + lane;
+        cnt += __popcll(__ballot(r < rows && any3(r, t)));
+      }
+      if (lane == 0 && cnt) base[s2] = atomicAdd(&v.hdr->cnt[t * kCntStride], cnt);
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int t = wave + kBuildWaves * s2;
+    if (t < 9) {
+      int run = __shfl(base[s2], 0);
+#pragma unroll
+      for (int c = 0; c < kRows3 / 64; ++c) {
+        const int r = c * 64 + lane;
+        const bool ok = r < rows && any3(r, t);
+        const unsigned long long m = __ballot(ok);
+        if (r < rows) {
+          int pos = -1;
+          if (ok) {
+            const int rank = run + __popcll(m & ((1ull << lane) - 1ull));
+            if (rank < n_out) {      // counters not cleared by the caller would push past the region: never write there
+              pos = t * n_out + rank;
+              int* e = v.ent + (int64_t)pos * 3;
+              e[0] = s_nbr[r * 27 + 3 * t];
+              e[1] = s_nbr[r * 27 + 3 * t + 1];
+              e[2] = s_nbr[r * 27 + 3 * t + 2];
+            }
+          }
+          s_id[r * 9 + t] = pos;
+        }
+        run += __popcll(m);
+      }
+    }
+  }
+  __syncthreads();
+  int* dst = v.pair_id + (int64_t)row0 * 9;
+  for (int e = threadIdx.x; e < rows * 9; e += 64 * kBuildWaves) dst[e] = s_id[e];
+}
+
+template <int NCH, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_ws3_gemm_bf3(const float* __restrict__ in, int64_t ldi, Pair3Views v,
+                                                                          int cin, int cout, const __bf16* __restrict__ wp3,
+                                                                          float* __restrict__ prod, int n_out, int target_units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];   // [j 3][plane 3][step][col 64][quad 4][8 bf16]
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q = lane >> 4;
+  const int ncb = cout >> 6;
+  const int nbk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int lin = ncb > 1 ? xcd * (nbk >> 3) + min(xcd, nbk & 7) + loc : bid;      // column blocks of a unit behind one L2
+  const int bx = lin / ncb, by = lin - bx * ncb, gx = nbk / ncb;
+  const int col0 = by * 64;
+  constexpr int nstep = NCH * 2;
+  constexpr int plane_bytes = nstep * 64 * 64;
+  constexpr int slice_bytes = 3 * plane_bytes;
+  const int cnt_l = (lane < 9) ? v.hdr->cnt[lane * kCntStride] : 0;
+  int P = cnt_l;
+  for (int d = 16; d >= 1; d >>= 1) P += __shfl_xor(P, d);
+  P = __shfl(P, 0);
+  int G = (int)((((int64_t)(P + 63) >> 6) * ncb + target_units - 1) / target_units);
+  G = G < 1 ? 1 : (G > kMaxG ? kMaxG : G);
+  int span, units, incl;
+  for (;;) {
+    span = 64 * G;
+    units = (cnt_l + span - 1) / span;
+    incl = units;
+    for (int d = 1; d < 32; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (__shfl(incl, 31) <= gx || G >= kMaxG) break;
+    ++G;
+  }
+  const int total_units = __shfl(incl, 31);
+  const int frag_off = (r16 * 4 + ((r16 & 8) ? (q ^ 3) : q)) * 16;
+  const unsigned ldi32 = (unsigned)ldi;
+  auto row_ptr = [&](int idx) { return (idx >= 0 ? in + (uint64_t)(unsigned)idx * ldi32 : g_zero_row) + q * 8; };
+
+  for (int unit = bx; unit < total_units; unit += gx) {
+    const int t3 = __popcll(__ballot(lane < 9 && incl <= unit));
+    const int excl = __builtin_amdgcn_readfirstlane(__shfl(incl - units, t3));
+    const int region = t3 * n_out;
+    const int p_begin = region + (unit - excl) * span;
+    const int p_end = min(p_begin + span, region + __builtin_amdgcn_readfirstlane(__shfl(cnt_l, t3)));
+    const int ngroups = (p_end - p_begin + 15) >> 4;
+    int g = wave;
+    int my_p = p_begin + g * 16 + r16;
+    // the three input rows of this lane's entry (lanes past the unit's end: its first entry -- they recompute and re-store
+    // that entry's product row, the same bits), and those of the wave's next group
+    auto entry = [&](int p, int& a, int& b, int& c2) {
+      const int* e = v.ent + (int64_t)(p < p_end ? p : p_begin) * 3;
+      a = e[0]; b = e[1]; c2 = e[2];
+    };
+    int i0 = -1, i1 = -1, i2 = -1, n0 = -1, n1 = -1, n2 = -1;
+    if (g < ngroups) entry(my_p, i0, i1, i2);
+    if (g + NW < ngroups) entry(my_p + 16 * NW, n0, n1, n2);
+    {   // stage the three slices of the triple: straight copies (the global layout is the LDS image)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(wp3) +
+                                   ((int64_t)(3 * t3 + j) * (cout >> 6) + by) * slice_bytes;
+        unsigned char* dstl = s_raw + j * slice_bytes;
+        for (int o0 = tid * 16; o0 < slice_bytes; o0 += 8 * NT * 16) {
+          f32x4 tt[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (o0 + u * NT * 16 < slice_bytes) tt[u] = *reinterpret_cast<const f32x4*>(src + o0 + u * NT * 16);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (o0 + u * NT * 16 < slice_bytes) *reinterpret_cast<f32x4*>(dstl + o0 + u * NT * 16) = tt[u];
+        }
+      }
+    }
+    f32x4 bufA[4], bufB[4];
+    {
+      const float* a0 = row_ptr(i0);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) bufA[jj] = *reinterpret_cast<const f32x4*>(a0 + (jj >> 1) * 32 + (jj & 1) * 4);
+    }
+    __syncthreads();
+
+    const int nsteps = (g < ngroups) ? ((ngroups - g + NW - 1) / NW) * 3 * NCH : 0;
+    int j = 0, c = 0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define APR_WS33_STEP(cur, nxt)                                                                                   \
+    {                                                                                                             \
+      int c1 = c + 1, j1 = j;                                                                                     \
+      bool newg = false;                                                                                          \
+      if (c1 == NCH) {                                                                                            \
+        c1 = 0;                                                                                                   \
+        j1 = j + 1;                                                                                               \
+        if (j1 == 3) { j1 = 0; newg = true; }                                                                     \
+      }                                                                                                           \
+      const int nidx = newg ? n0 : (j1 == 0 ? i0 : (j1 == 1 ? i1 : i2));                                          \
+      const float* nb = row_ptr(nidx) + c1 * 64;                                                                  \
+      int m0 = n0, m1 = n1, m2 = n2;                                                                              \
+      if (newg) { /* the group after next: its entry is requested a whole group ahead */                          \
+        m0 = m1 = m2 = -1;                                                                                        \
+        if (g + 2 * NW < ngroups) entry(my_p + 32 * NW, m0, m1, m2);                                              \
+      }                                                                                                           \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                            \
+        nxt[jj] = *reinterpret_cast<const f32x4*>(nb + (jj >> 1) * 32 + (jj & 1) * 4);                            \
+      bf16x8 ah[2], am[2], al[2];                                                                                 \
+      apr_split3(cur[0], cur[1], ah[0], am[0], al[0]);                                                            \
+      apr_split3(cur[2], cur[3], ah[1], am[1], al[1]);                                                            \
+      const unsigned char* wb = s_raw + j * slice_bytes + (c * 2 * 64) * 64 + frag_off;                           \
+      bf16x8 wf[3][3];                                                                                            \
+      _Pragma("unroll") for (int i0_ = 0; i0_ < 2; ++i0_)                                                         \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                          \
+          wf[i0_][pl] = *reinterpret_cast<const bf16x8*>(wb + (i0_ * 16) * 64 + pl * plane_bytes);                \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
+        const int s = i >> 2, cb = i & 3;                                                                         \
+        if (i < 6) {                                                                                              \
+          const int s2 = (i + 2) >> 2, cb2 = (i + 2) & 3;                                                         \
+          _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                        \
+            wf[(i + 2) % 3][pl] =                                                                                 \
+                *reinterpret_cast<const bf16x8*>(wb + (s2 * 64 + cb2 * 16) * 64 + pl * plane_bytes);             \
+          __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                         \
+        const bf16x8 wh = wf[i % 3][0], wm = wf[i % 3][1], wl = wf[i % 3][2];                                     \
+        f32x4 t = acc[cb];                                                                                        \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[s], t, 0, 0, 0);                                       \
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[s], t, 0, 0, 0);                                       \
+        acc[cb] = t;                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+      }                                                                                                           \
+      if (newg) {                                                                                                 \
+        float* dst = prod + (int64_t)(my_p < p_end ? my_p : p_begin) * cout + col0 + q * 4;                       \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                          \
+          __builtin_nontemporal_store(acc[cb], reinterpret_cast<f32x4*>(dst + cb * 16));                         \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};                   \
+        g += NW;                                                                                                  \
+        my_p += 16 * NW;                                                                                          \
+        i0 = n0; i1 = n1; i2 = n2;                                                                                \
+        n0 = m0; n1 = m1; n2 = m2;                                                                                \
+      }                                                                                                           \
+      j = j1;                                                                                                     \
+      c = c1;                                                                                                     \
+    }
+
+    int s_ = 0;
+    for (; s_ + 2 <= nsteps; s_ += 2) {
+      APR_WS33_STEP(bufA, bufB)
+      APR_WS33_STEP(bufB, bufA)
+    }
+    if (s_ < nsteps) APR_WS33_STEP(bufA, bufB)
+#undef APR_WS33_STEP
+    __syncthreads();   // the slices are re-staged by the next unit
+  }
+}
+
 // All pair ids of the row first, then all product loads in flight at once (exec-masked), summed in offset order:
 // the naive "load id -> branch -> load -> add" loop is a chain of K dependent L2 round trips (~25 us floor).
 template <int KT>
@@ -615,6 +880,80 @@ static int ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const v
   else
     hipLaunchKernelGGL(k_ws_reduce<32>, rgrid, dim3(256), 0, st, prod_scratch, v, n_out, K, cout, scale, shift,
                        residual, ldr, relu, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// ---- triple pair lists (3^3 maps): half the product rows; see k_ws3_gemm_bf3 ----
+APR_API size_t apr_pairlist3_bytes(int64_t n_out) {
+  const size_t n = (size_t)(n_out > 0 ? n_out : 1);
+  return align256(n * 9 * 12) + align256(n * 9 * 4) + 256;
+}
+
+APR_API int apr_pairlist3_build(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* counters, void* plist3,
+                                size_t plist3_bytes, void* stream) {
+  APR_CHECK_ARG(n_out > 0 && n_out < (1ll << 31) / 32 && K == 27, "apr_pairlist3_build: needs 0 < n_out < 2^26 and K = 27");
+  APR_CHECK_ARG(plist3_bytes >= apr_pairlist3_bytes(n_out), "apr_pairlist3_build: blob too small");
+  APR_CHECK_ARG(nbr != nullptr && counters != nullptr && plist3 != nullptr, "apr_pairlist3_build: null argument");
+  Pair3Views v = carve_pairs3(counters, plist3, n_out);
+  hipLaunchKernelGGL(k_pairs3_build, dim3((unsigned)cdiv64(n_out, kRows3)), dim3(64 * kBuildWaves), 0, (hipStream_t)stream, nbr,
+                     (int)n_out, v);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// 1 if apr_spconv_ws3_fwd_bf3 takes the layer: a 27-offset map, 64 or 128 input channels, cout % 64 == 0
+APR_API int apr_spconv_ws3_supported(int32_t K, int32_t cin, int32_t cout) {
+  return K == 27 && (cin == 64 || cin == 128) && cout >= 64 && cout % 64 == 0;
+}
+
+// out = act((sum_k in[nbr[., k]] @ W[k]) * scale + shift + residual) over the TRIPLE pair lists of apr_pairlist3_build;
+// w_bf3 from apr_spconv_pack_weights_bf3(w, 27, cin, cout); prod_scratch: f32 [9 * n_out, cout].
+APR_API int apr_spconv_ws3_fwd_bf3(const float* in, int64_t ldi, const int32_t* counters, const void* plist3, int64_t n_out,
+                                   int32_t cin, int32_t cout, const void* w_bf3, const float* scale, const float* shift,
+                                   const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo,
+                                   float* prod_scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(in && counters && plist3 && w_bf3 && out && prod_scratch && n_out > 0 && n_out < (1ll << 31) / 32,
+                "apr_spconv_ws3_fwd_bf3: bad n_out / null argument");
+  APR_CHECK_ARG(apr_spconv_ws3_supported(27, cin, cout), "apr_spconv_ws3_fwd_bf3: needs cin 64 or 128 and cout %% 64 == 0");
+  APR_CHECK_ARG(ldi > 0 && ldi < (1ll << 31) && ldi % 4 == 0 && ldo % 4 == 0 &&
+                    ((((uintptr_t)in) | ((uintptr_t)out) | ((uintptr_t)prod_scratch)) & 15) == 0,
+                "apr_spconv_ws3_fwd_bf3: 16-byte aligned rows required");
+  APR_CHECK_ARG(!residual || (ldr % 4 == 0 && (((uintptr_t)residual) & 15) == 0), "apr_spconv_ws3_fwd_bf3: residual alignment");
+  Pair3Views v = carve_pairs3(const_cast<int32_t*>(counters), const_cast<void*>(plist3), n_out);
+  {
+    static std::mutex s_mu;
+    static bool s_attr[64] = {};
+    int dev = 0;
+    APR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(s_mu);
+    if (dev >= 0 && dev < 64 && !s_attr[dev]) {
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws3_gemm_bf3<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws3_gemm_bf3<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      s_attr[dev] = true;
+    }
+  }
+  const size_t lds = (size_t)3 * cin * 64 * 6;
+  const int64_t per_cu = cin == 64 ? 2 : 1;
+  static const int s_target = env_int("APR_WS_TARGET", 768);
+  int64_t target = 256 * per_cu;
+  if (target > s_target) target = s_target;
+  int64_t gx = cdiv64(target, cout / 64);
+  const int64_t need = cdiv64(n_out * 9, 64) + 9;
+  if (gx > need) gx = need;
+  if (cin == 64)
+    hipLaunchKernelGGL((k_ws3_gemm_bf3<1, 4>), dim3((unsigned)(gx * (cout / 64))), dim3(256), lds, st, in, ldi, v, cin, cout,
+                       (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target);
+  else
+    hipLaunchKernelGGL((k_ws3_gemm_bf3<2, 8>), dim3((unsigned)(gx * (cout / 64))), dim3(512), lds, st, in, ldi, v, cin, cout,
+                       (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target);
+  PairViews rv;
+  rv.hdr = v.hdr;
+  rv.pair_in = nullptr;
+  rv.pair_id = v.pair_id;
+  hipLaunchKernelGGL(k_ws_reduce<9>, dim3((unsigned)cdiv64(n_out * (cout / 4), 256)), dim3(256), 0, st, prod_scratch, rv, n_out,
+                     9, cout, scale, shift, residual, ldr, relu, out, ldo);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

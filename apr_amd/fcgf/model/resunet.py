@@ -46,6 +46,10 @@ WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", 
 OS_STAGES = ("block2", "block3_tr", "block2_tr")
 
 
+WS3_MAX_ROWS_128 = int(os.environ.get("APR_WS3_MAX_ROWS_128", "100000"))
+WS3_CIN128 = os.environ.get("APR_WS3_CIN128", "1") != "0"      # A/B switch: 0 = triple lists for 64 input channels only
+
+
 def _os_stages():
     env = os.environ.get("APR_OS_STAGES")
     if env is None:
@@ -175,6 +179,20 @@ class ResUNet2(ME.MinkowskiNetwork):
         # for the ~0.6 ms Python needs to plan all 23 launches before the first one left (APR_FUSED_EAGER=0: one call)
         eager = os.environ.get("APR_FUSED_EAGER", "1") != "0"
 
+        ws3 = os.environ.get("APR_WS3", "1") != "0"      # A/B switch: 0 = one product row per pair for every ws layer
+
+        def ws_list(layer, m):
+            """The weight-stationary pair lists of map m for `layer`: x-triple entry lists (half the product rows) where
+            the gemm takes the shape (27 offsets, 64 / 128 input channels), per-offset lists elsewhere."""
+            tri = ws3 and layer.packed_weight_bf3() is not None and ops.ws3_supported(layer.kernel_volume, layer.in_channels,
+                                                                                      layer.out_channels)
+            # 128 input channels: the three slices take 144 KB of LDS (one 8-wave workgroup per CU instead of three 4-wave
+            # ones) and the zero-padded MFMA share grows with the pairs per row; on the largest same-level maps that costs
+            # more than the halved product rows save (FatBN's block2_tr, 189 k rows: 470 vs 413 us; 71 k rows: 161 vs 166)
+            if tri and layer.in_channels == 128 and ((m[0] == m[1] and cm.size(m[1]) > WS3_MAX_ROWS_128) or not WS3_CIN128):
+                tri = False
+            return cm.pair_list(*m, triples=tri)
+
         def stage(name, feats, cmap, n_out, bmap, out):
             """conv -> folded BN -> residual block; cmap / bmap = (ts_in, ts_out, kernel, transpose)."""
             conv, norm, blk = getattr(self, "conv" + name), getattr(self, "norm" + name), getattr(self, "block" + name)
@@ -184,14 +202,14 @@ class ResUNet2(ME.MinkowskiNetwork):
                 a = conv.run_occ(cm, n_out, scale=sc, shift=sh)
             else:
                 a = conv.run(feats, cm.kernel_map(*cmap), n_out, scale=sc, shift=sh, batch=batch,
-                             plist=cm.pair_list(*cmap) if "conv" + name in ws else None)
+                             plist=ws_list(conv, cmap) if "conv" + name in ws else None)
             bl = None
             # 64 input channels only: at 128 the kernel exists and is tested but loses to the weight-stationary pair
             # on every level (12 frames per call: 494 vs 444 us at 189 k rows, 79 vs 69 us at 26 k)
             if "block" + name in osn and blk.conv1.in_channels == 64 and blk.conv1.packed_weight_bf3() is not None:
                 bl = cm.os_pair_list(*bmap, blk.conv1.in_channels, blk.conv1.out_channels)
             if bl is None and "block" + name in ws:
-                bl = cm.pair_list(*bmap)
+                bl = ws_list(blk.conv1, bmap)
             r = blk.fused_eval(a, cm.kernel_map(*bmap), out, batch=batch, plist=bl)
             if eager:
                 batch.launch()      # the stage's three convolutions leave now: the GPU works while Python plans the next stage

@@ -455,6 +455,44 @@ class PairList:
         return self.build().counters[::pair_counter_stride()][:self.K].cpu().numpy()
 
 
+class PairList3(PairList):
+    """Triple pair lists of a 27-offset kernel map (apr_pairlist3_build): an entry = an output row with its up to three
+    x-neighbours of one (dy, dz); the weight-stationary gemm writes ONE product row per entry -- about half as many as
+    pairs (apr_spconv_ws3_fwd_bf3).  Same life cycle as PairList (lazy build inside a SpconvBatch)."""
+
+    def prod_scratch(self, cout):
+        """Product rows [9 * n_out, cout]; triple t uses the head of its own n_out-row region."""
+        return torch.empty(self.n_out * 9 * cout, dtype=torch.float32, device=self.blob.device)
+
+    def build(self):
+        if self.queued:
+            raise _lib.AprHipError("PairList3: its build is queued in a SpconvBatch that has not been launched yet")
+        if not self.built:
+            check(_lib_().apr_pairlist3_build(ptr(self.nbr), self.n_out, self.K, ptr(self.counters), ptr(self.blob),
+                                              self.blob.numel(), stream()))
+            self.built = True
+        return self
+
+    def counts(self):
+        """Entries per triple (host sync; tests / diagnostics)."""
+        return self.build().counters[::pair_counter_stride()][:9].cpu().numpy()
+
+
+def ws3_supported(K, cin, cout):
+    return bool(_lib_().apr_spconv_ws3_supported(int(K), int(cin), int(cout)))
+
+
+def build_pairlist3(nbr, lazy=False, counters=None):
+    """nbr int32 [n_out, 27] -> PairList3 (see build_pairlist for `counters`)."""
+    if nbr.dtype != torch.int32 or not nbr.is_contiguous() or nbr.dim() != 2 or nbr.shape[1] != 27:
+        raise _lib.AprHipError("build_pairlist3: nbr must be a contiguous int32 [n_out, 27] tensor")
+    nb = int(_lib_().apr_pairlist3_bytes(nbr.shape[0]))
+    if counters is None:
+        counters = torch.zeros(pair_counter_ints(), dtype=torch.int32, device=nbr.device)
+    pl = PairList3(counters, torch.empty(nb, dtype=torch.uint8, device=nbr.device), nbr, False)
+    return pl if lazy else pl.build()
+
+
 def pair_counter_ints() -> int:
     """Length of the int32 counter block of one pair list (32 counters, one per 256 B: apr_pairlist_counter_ints)."""
     return int(_lib_().apr_pairlist_counter_ints())
@@ -572,6 +610,9 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         if residual.shape[0] != n_out or residual.shape[1] != cout:
             raise _lib.AprHipError("spconv: residual shape mismatch")
     use_ws = plist is not None and nbr is not None and ws_supported(K, cin, cout)
+    use_ws3 = use_ws and isinstance(plist, PairList3)
+    if use_ws3 and (w_bf3 is None or not ws3_supported(K, cin, cout)):
+        raise _lib.AprHipError("spconv: triple pair lists need the bf16-split weights and cin 64 / 128, K = 27")
     if use_ws:
         if plist.n_out != n_out or plist.K != K:
             raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
@@ -581,7 +622,11 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         P = prof.pairs(nbr, n_out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if use_ws:
+    if use_ws3:
+        check(_lib_().apr_spconv_ws3_fwd_bf3(ptr(x), ldi, ptr(plist.counters), ptr(plist.blob), n_out, cin, cout, ptr(w_bf3),
+                                             ptr(scale), ptr(shift), ptr(residual), ldr, int(bool(relu)), ptr(out), ldo,
+                                             ptr(prod), stream()))
+    elif use_ws:
         check(_lib_().apr_spconv_ws_fwd_bf3(ptr(x), ldi, ptr(plist.counters), ptr(plist.blob), n_out, K, cin, cout, ptr(wp),
                                             ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr, int(bool(relu)),
                                             ptr(out), ldo, ptr(prod), stream()))
@@ -703,11 +748,15 @@ class SpconvBatch:
         if plist is not None and nbr is not None and ws_supported(K, cin, cout):
             if plist.n_out != n_out or plist.K != K:
                 raise _lib.AprHipError("spconv: pair list does not belong to this kernel map")
-            need = plist.n_out * plist.K * cout      # launches run in order on one stream: share the scratch
+            is3 = isinstance(plist, PairList3)
+            if is3 and (w_bf3 is None or not ws3_supported(K, cin, cout)):
+                raise _lib.AprHipError("spconv: triple pair lists need the bf16-split weights and cin 64 / 128, K = 27")
+            need = plist.n_out * (9 if is3 else plist.K) * cout      # launches run in order on one stream: share the scratch
             prod = self.prod.get(need)
             if prod is None:
                 prod = self.prod[need] = plist.prod_scratch(cout)
             d.counters, d.plist, d.prod_scratch = plist.counters.data_ptr(), plist.blob.data_ptr(), prod.data_ptr()
+            d.ws3 = int(is3)
             if w_bf3 is not None:
                 d.w_bf3 = w_bf3.data_ptr()
             if not plist.built and not plist.queued:

@@ -250,6 +250,21 @@ int apr_spconv_wgrad(const float* in, int64_t ldi, const float* dout, int64_t ld
                      int32_t K, int32_t cin, int32_t cout, float* dw, void* scratch, size_t scratch_bytes,
                      void* stream);
 
+/* Triple pair lists for 27-offset maps (spconv_ws.hip): offsets are x fastest, so k = 3t + j are the three x-neighbours of
+ * one (dy, dz); an ENTRY of triple t is an output row with its up to three input rows, and the gemm writes ONE product
+ * row per entry (about half as many as pairs on LiDAR surfaces), accumulating the three offsets in registers -- the
+ * product round trip that bounds the weight-stationary pair halves.  Same operator and epilogue as apr_spconv_ws_fwd_bf3
+ * (FCGF_APR/model/resunet.py:31-140); counters: a zeroed apr_pairlist_counter_ints() block; prod_scratch f32
+ * [9 * n_out, cout]; cin 64 / 128, cout % 64 == 0 (apr_spconv_ws3_supported). */
+size_t apr_pairlist3_bytes(int64_t n_out);
+int apr_pairlist3_build(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* counters, void* plist3, size_t plist3_bytes,
+                        void* stream);
+int apr_spconv_ws3_supported(int32_t K, int32_t cin, int32_t cout);
+int apr_spconv_ws3_fwd_bf3(const float* in, int64_t ldi, const int32_t* counters, const void* plist3, int64_t n_out,
+                           int32_t cin, int32_t cout, const void* w_bf3, const float* scale, const float* shift,
+                           const float* residual, int64_t ldr, int32_t relu, float* out, int64_t ldo, float* prod_scratch,
+                           void* stream);
+
 /* One launch description of apr_spconv_fwd; apr_spconv_fwd_batch enqueues n of them back to back
  * from a single call (the 23 fused conv launches of one ResUNet encode), so a host binding pays
  * one FFI transition instead of 23 and can overlap several encodes from different host threads. */
@@ -271,7 +286,8 @@ typedef struct apr_spconv_desc {
   int32_t l2norm;         /* != 0: out[j, :] /= |out[j, :]|_2 behind the epilogue (the encoder's normalize_feature,
                            * FCGF_APR/model/resunet.py:139-142): in the tile kernel's epilogue when it runs the layer
                            * with cout 32 or 64 (same bits as apr_l2_normalize), else as a second launch */
-  int32_t reserved_;
+  int32_t ws3;            /* != 0 (with plist and w_bf3): plist is a TRIPLE pair list (apr_pairlist3_build / _bytes), the launch
+                           * runs through apr_spconv_ws3_fwd_bf3 and prod_scratch holds 9 * n_out rows */
 } apr_spconv_desc;
 int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* stream);
 /* Same, with one HIP event pair per launch recorded on `stream` (around the conv kernels only, not a pair-list

@@ -70,6 +70,15 @@ for name, ti, to, cin, cout, tr in layers:
             us3 = batched(pl, out3, w3)
             err3 = float((out3 - out).norm() / out.norm())
             line += f" | ws-bf3 {us3:7.1f} us {2.0*P*cin*cout/us3/1e6:6.1f} TF  (rel diff {err3:.1e})"
+        if w3 is not None and ops.ws3_supported(27, cin, cout):      # x-triple entry lists: one product row per entry
+            t_b3 = timeit(lambda: ops.build_pairlist3(nbr))
+            pl3 = ops.build_pairlist3(nbr)
+            out5 = torch.empty_like(out)
+            ops.spconv(x, nbr, 27, cin, cout, wp, out=out5, plist=pl3, w_bf3=w3); batched(pl3, out5, w3)
+            us5 = batched(pl3, out5, w3)
+            err5 = float((out5 - out).norm() / out.norm())
+            ent = int(pl3.counts().sum())
+            line += f" | ws3 {us5:7.1f} us (entries/pairs {ent / P:.2f}, build {t_b3:5.1f} us, rel diff {err5:.1e})"
         R = ops.os_tile_rows(cm.size(to), cin, cout) if w3 is not None else 0
         if R:
             t_ob = timeit(lambda: ops.build_os_pairs(nbr, cm.size(ti), R))

@@ -61,7 +61,7 @@ def test_spconv_matches_oracle(dev, cin, cout, K, n_in, n_out):
     (64, 64, 27, 31, 31, 0.3), (256, 256, 27, 1246, 1246, 0.29), (64, 64, 27, 40000, 40000, 0.27),
     (64, 64, 27, 500, 500, 0.0), (128, 64, 27, 100, 1000, 1.0), (512, 64, 27, 400, 700, 0.3),
 ])
-@pytest.mark.parametrize("gemm", ["fp32", "bf3"])
+@pytest.mark.parametrize("gemm", ["fp32", "bf3", "ws3"])
 def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, density, gemm):
     """apr_pairlist_build + apr_spconv_ws_fwd[_bf3] (strided / transposed / deep layers) against the same oracle,
     with the fused epilogue and strided in / out / residual rows; also bit-stable run to run.  `gemm`: the fp32-MFMA
@@ -73,6 +73,10 @@ def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
         if cin not in (64, 128, 256):
             pytest.skip("k_ws_gemm_bf3 covers cin 64 / 128 / 256")
         xw = xw * torch.from_numpy(np.exp(rng.uniform(-9.2, 9.2, (n_in, 1))).astype(np.float32))
+    if gemm == "ws3":      # the x-triple entry lists (k_ws3_gemm_bf3: one product row per entry, three offsets per accumulator)
+        if cin not in (64, 128) or K != 27:
+            pytest.skip("k_ws3_gemm_bf3 covers 27-offset maps with cin 64 / 128")
+        xw = xw * torch.from_numpy(np.exp(rng.uniform(-9.2, 9.2, (n_in, 1))).astype(np.float32))
     x = xw[:, 32:]
     W = torch.from_numpy((rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 8)).astype(np.float32))
     nbr = _random_map(rng, n_in, n_out, K, density)
@@ -81,10 +85,11 @@ def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
     resw = torch.from_numpy(rng.standard_normal((n_out, cout + 64)).astype(np.float32))
     res = resw[:, :cout]
     wp = ops.pack_weights(W.to(dev))
-    w3 = ops.pack_weights_bf3(W.to(dev)) if gemm == "bf3" else None
-    assert (w3 is not None) == (gemm == "bf3")
+    w3 = ops.pack_weights_bf3(W.to(dev)) if gemm in ("bf3", "ws3") else None
+    assert (w3 is not None) == (gemm in ("bf3", "ws3"))
     nbr_d = torch.from_numpy(nbr).to(dev)
-    pl = ops.build_pairlist(nbr_d)
+    mk = ops.build_pairlist3 if gemm == "ws3" else ops.build_pairlist
+    pl = mk(nbr_d)
     outw = torch.zeros(n_out, cout + 32, device=dev)
     xd, resd = xw.to(dev)[:, 32:], resw.to(dev)[:, :cout]
     out = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd, relu=True,
@@ -100,10 +105,13 @@ def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
     assert float(((bare - ref0).norm(dim=1) / mag).max()) < 5e-6
     assert rel_l2(bare, ref0) < 2e-6
     assert float(outw[:, :32].abs().max()) == 0.0          # neighbouring columns untouched
-    # pair lists: one region per offset, counts consistent with the map
-    assert np.array_equal(pl.counts(), (nbr >= 0).sum(axis=0))
+    # pair lists: one region per offset (per x-triple: rows with any of its three offsets), counts consistent with the map
+    if gemm == "ws3":
+        assert np.array_equal(pl.counts(), (nbr.reshape(n_out, 9, 3) >= 0).any(axis=2).sum(axis=0))
+    else:
+        assert np.array_equal(pl.counts(), (nbr >= 0).sum(axis=0))
     again = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd,
-                       relu=True, plist=ops.build_pairlist(nbr_d), w_bf3=w3)
+                       relu=True, plist=mk(nbr_d), w_bf3=w3)
     assert torch.equal(again, out)
     # and agrees with the tile kernel to fp32 summation-order noise
     tile = ops.spconv(xd, nbr_d, K, cin, cout, wp, scale=scale.to(dev), shift=shift.to(dev), residual=resd, relu=True)
