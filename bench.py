@@ -114,6 +114,9 @@ def pmc_traffic(path):
             return ks["k_spconv_pairs"]["hbm_bytes_per_launch"], src
         if path == "os":
             return ks["k_os_conv"]["hbm_bytes_per_launch"], src
+        fam = json.load(open(files[-1])).get("ws_family")
+        if fam:       # gemm (per-offset pairs or x-triple entries) + reduce, bytes of the family per layer
+            return fam["hbm_bytes_per_layer"], src
         return ks["k_ws_gemm"]["hbm_bytes_per_launch"] + ks["k_ws_reduce"]["hbm_bytes_per_launch"], src
     except KeyError:
         return None, src
@@ -768,10 +771,11 @@ def main():
                     "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
                     "mfma_tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12}
 
-        names = {"tile": "k_spconv_pairs", "ws": "k_ws_gemm_bf3+k_ws_reduce", "os": "k_os_conv"}
+        names = {"tile": "k_spconv_pairs", "ws": "k_ws_gemm_bf3|k_ws3_gemm_bf3+k_ws_reduce", "os": "k_os_conv"}
         what = {"tile": "pair-compacted gather -> fp32 MFMA -> fused epilogue, one kernel",
-                "ws": "weight-stationary gather -> bf16 MFMA in an exact 3-way split (k_ws_gemm_bf3), product rows through "
-                      "HBM, then per-row sum + fused epilogue (k_ws_reduce)",
+                "ws": "weight-stationary gather -> bf16 MFMA in an exact 3-way split (k_ws3_gemm_bf3 over x-triple entries: "
+                      "one product row per entry; k_ws_gemm_bf3 over per-offset pairs for 256 input channels), product rows "
+                      "through HBM, then per-row sum + fused epilogue (k_ws_reduce)",
                 "os": "output-stationary: tile accumulators in LDS, gather -> bf16 MFMA in an exact 3-way split -> fused "
                       "epilogue, no product rows"}
         # the instructions a family issues decide which roof prices it: the tile kernel runs exact-fp32 MFMA (157.3 TFLOP/s

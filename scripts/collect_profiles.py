@@ -3,7 +3,7 @@ usage: python scripts/collect_profiles.py <tag> [prefix=r01]"""
 import csv, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-prefix = sys.argv[2] if len(sys.argv) > 2 else "r03"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = os.path.join(root, "gpurun_out", f"profile_{tag}")
 dst = os.path.join(root, "profiles")
 pairs = [("bench.json", f"{prefix}_bench.json"), ("bench_s1.json", f"{prefix}_bench_streams1.json"),
@@ -14,6 +14,12 @@ pairs = [("bench.json", f"{prefix}_bench.json"), ("bench_s1.json", f"{prefix}_be
          ("predator_profile.log", f"{prefix}_predator_host_profile.log")]
 pairs += [("bench_s1_plain.json", f"{prefix}_bench_streams1_plain.json"),
           ("bench_s1_d3_l3.json", f"{prefix}_bench_streams1_depth3_lanes3.json")]
+pairs += [("selflaunch_gloo2.json", f"{prefix}_selflaunch_gloo2.json"),
+          ("selflaunch_gloo2_config4.json", f"{prefix}_selflaunch_gloo2_config4.json"),
+          ("host_cpu_split_poll.log", f"{prefix}_host_cpu_split_poll.log"),
+          ("host_cpu_split_sync.log", f"{prefix}_host_cpu_split_sync.log"),
+          ("match_stats/m_kernel_stats.csv", f"{prefix}_matching_0_30pct_kernel_stats.csv"),
+          ("match_load.log", f"{prefix}_matching_0_30pct.log")]
 pairs += [(f"driver_cmd_{i}.json", f"{prefix}_driver_cmd_{i}.json") for i in (1, 2, 3)]
 pairs += [(f"driver_cmd_{i}.log", f"{prefix}_driver_cmd_{i}.log") for i in (1, 2, 3)]
 for a, b in pairs:

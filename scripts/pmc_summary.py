@@ -7,8 +7,8 @@ bench primes its streams with the timed workload itself, not with a small pair, 
 full-size launch (round 1's figure was diluted 2.8x by 180 small priming launches)."""
 import csv, glob, json, os, sys
 out = sys.argv[1]
-KERNELS = ("k_spconv_pairs", "k_ws_gemm", "k_ws_reduce", "k_os_conv", "k_os_build", "k_pairs_build", "k_dense_gemm",
-           "k_spconv_smallcin")
+KERNELS = ("k_spconv_pairs", "k_ws_gemm", "k_ws3_gemm", "k_ws_reduce", "k_os_conv", "k_os_build", "k_pairs_build",
+           "k_pairs3_build", "k_dense_gemm", "k_spconv_smallcin")
 
 
 def per_kernel(counter, sub, names):
@@ -44,9 +44,13 @@ res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separ
                      "exact; units KB",
        "kernels": table("pmc_{}", KERNELS)}
 ks = res["kernels"]
-if "k_ws_gemm" in ks and "k_ws_reduce" in ks:
-    res["kernel"] = "k_ws_gemm+k_ws_reduce (one weight-stationary conv layer = one launch of each)"
-    res["hbm_bytes_per_launch"] = ks["k_ws_gemm"]["hbm_bytes_per_launch"] + ks["k_ws_reduce"]["hbm_bytes_per_launch"]
+if "k_ws_reduce" in ks and ("k_ws_gemm" in ks or "k_ws3_gemm" in ks):
+    # one weight-stationary conv layer = one gemm launch (k_ws_gemm_bf3 over per-offset pairs, or k_ws3_gemm_bf3 over x-triple
+    # entries) + one k_ws_reduce launch: bytes of the family / layers (= reduce launches)
+    tot = sum(ks[k]["hbm_bytes_per_launch"] * ks[k]["launches"] for k in ("k_ws_gemm", "k_ws3_gemm", "k_ws_reduce") if k in ks)
+    res["kernel"] = "k_ws_gemm_bf3 | k_ws3_gemm_bf3 + k_ws_reduce (one weight-stationary conv layer = one gemm + one reduce launch)"
+    res["ws_family"] = {"layers": ks["k_ws_reduce"]["launches"], "hbm_bytes_per_layer": tot / ks["k_ws_reduce"]["launches"]}
+    res["hbm_bytes_per_launch"] = res["ws_family"]["hbm_bytes_per_layer"]
 pk = table("pred_pmc_{}", ("k_kpconv_weighted_mfma", "k_kpconv_weighted_generic"))
 if pk:
     res["predator_kpconv"] = {"command": "same counters -- python3 scripts/kpconv_bench.py (KPConv step 1 per pyramid "

@@ -5,7 +5,7 @@
 #   gpurun -- scripts/profile_round.sh r02        -> gpurun_out/profile_r02/*  (scripts/collect_profiles.py copies
 #   what is judged into profiles/)
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
@@ -19,6 +19,14 @@ python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err </dev/null || { echo "be
 echo "[profile] one stream: plain, and with the host three steps ahead + the matching batch on three lanes"
 python3 $R/bench.py --streams 1 --depth 1 --match-lanes 1 --steps 120 --no-cpu-baseline --no-roofline --no-workloads > $OUT/bench_s1_plain.json 2> $OUT/bench_s1_plain.err </dev/null || { echo "s1 plain failed"; exit 1; }
 python3 $R/bench.py --streams 1 --depth 3 --match-lanes 3 --steps 120 --no-cpu-baseline --no-roofline --no-workloads > $OUT/bench_s1_d3_l3.json 2> $OUT/bench_s1_d3_l3.err </dev/null || { echo "s1 depth 3 lanes 3 failed"; exit 1; }
+echo "[profile] bench.py --gpus 2 with no launcher around it (gloo, both ranks on this GPU): weak line and config-4 mode"
+APR_BENCH_BACKEND=gloo APR_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 2 --steps 20 --warmup 5 --no-workloads --no-cpu-baseline --no-roofline > $OUT/selflaunch_gloo2.json 2> $OUT/selflaunch_gloo2.err </dev/null || { echo "self-launch failed"; tail -5 $OUT/selflaunch_gloo2.err; exit 1; }
+APR_BENCH_BACKEND=gloo APR_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 2 --pairs-total 30 --warmup 5 --no-workloads --no-cpu-baseline --no-roofline > $OUT/selflaunch_gloo2_config4.json 2> $OUT/selflaunch_gloo2_config4.err </dev/null || { echo "self-launch config 4 failed"; exit 1; }
+echo "[profile] host CPU of a rank: where the three worker threads spend their time"
+python3 $R/scripts/host_cpu_split.py 150 > $OUT/host_cpu_split_poll.log 2>&1 </dev/null || { echo "host split failed"; exit 1; }
+APR_FETCH_WAIT=sync python3 $R/scripts/host_cpu_split.py 150 > $OUT/host_cpu_split_sync.log 2>&1 </dev/null || { echo "host split (sync) failed"; exit 1; }
+echo "[profile] matching at 0 / 30 % true matches under rocprof (the regime a trained checkpoint puts the matcher in)"
+SHARES=0.0,0.3 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/match_stats -o m -- python3 $R/scripts/match_load_bench.py > $OUT/match_load.log 2>&1 </dev/null || { echo "match stats failed"; exit 1; }
 echo "[profile] rocprof stats, default run"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $R/bench.py --no-cpu-baseline --no-workloads > $OUT/bench_prof.json 2> $OUT/bench_prof.err </dev/null || { echo "rocprof default failed"; exit 1; }
 echo "[profile] rocprof stats, single stream"
