@@ -36,6 +36,10 @@ class PairRegistration:
         # encoder still runs)
         self.feature_hook = None
         self._ones_cache = {}
+        # how `register_batch` waits for its two fetches (ops.wait_event): None = the process default (sleeping poll: one CPU
+        # per rank with three steps in flight); "sync" = hipEventSynchronize (a spinning core, lowest wake-up latency: for a
+        # caller that has ONE step in flight, like the reference's own loop)
+        self.fetch_wait = None
 
     @torch.no_grad()
     def voxelize_pair(self, xyz0, xyz1):
@@ -154,7 +158,7 @@ class PairRegistration:
 
         Larger launches amortise the ~10-20 us latency floor of every sparse-conv / index kernel and the host cost
         of an encoder call over B pairs.  -> list of (T [4,4] float64, info)."""
-        return ops.drive(self.register_batch_phases(pairs, seeds))     # one code path: the pipelined step, waited for
+        return ops.drive(self.register_batch_phases(pairs, seeds), wait=self.fetch_wait)     # one code path: the pipelined step, waited for
 
     @torch.no_grad()
     def __call__(self, xyz0, xyz1, seed=0):

@@ -231,9 +231,12 @@ def finalize_maps(maps, extras=()):
 BLOCKING_EVENTS = os.environ.get("APR_BLOCKING_EVENTS", "1") != "0"
 # ... which turned out not to be enough on this stack: measured per worker thread (scripts/host_cpu_split.py), a thread inside
 # hipEventSynchronize burns CPU for the whole wall time of the wait with the blocking flag set or not (0.254 s of CPU over
-# 0.254 s of waiting; 3.06 CPUs busy per rank for 0.3 CPUs' worth of enqueue work).  The fetch wait therefore POLLS:
-# event.query() + time.sleep(APR_FETCH_POLL_US, default 50 us; the sleep releases the GIL).  APR_FETCH_WAIT=sync restores
-# hipEventSynchronize.
+# 0.254 s of waiting; 3.06 CPUs busy per rank for 0.3 CPUs' worth of enqueue work).  The fetch wait therefore POLLS, inside
+# the library (apr_event_wait: hipEventQuery + nanosleep(APR_FETCH_POLL_US, default 25 us), the thread's timer slack at
+# 1 us), i.e. with the interpreter lock released for the whole wait.  A first version polled from Python (event.query() +
+# time.sleep): every waiting thread then took the GIL 25 000 times a second, and on a box with a slow host the enqueueing
+# threads lost 14 % of the throughput to it (2259 against 2616 pairs/s).  APR_FETCH_WAIT=sync restores hipEventSynchronize,
+# APR_FETCH_WAIT=pypoll the Python loop.
 FETCH_WAIT = os.environ.get("APR_FETCH_WAIT", "poll")
 FETCH_POLL_S = float(os.environ.get("APR_FETCH_POLL_US", "25")) * 1e-6
 _SLACK = __import__("threading").local()
@@ -256,15 +259,24 @@ def fetch_event():
     return torch.cuda.Event(blocking=BLOCKING_EVENTS)
 
 
-def wait_event(ev):
-    """Host wait for a fetch event without spinning on a CPU (see FETCH_WAIT above)."""
-    if FETCH_WAIT == "sync":
+def wait_event(ev, mode=None):
+    """Host wait for a fetch event without spinning on a CPU and without holding the GIL (see FETCH_WAIT above).  `mode`
+    overrides the process default for this wait: "sync" = hipEventSynchronize, i.e. a spinning core and the lowest wake-up
+    latency -- what a caller with ONE step in flight wants (a sleeping core of an otherwise idle host takes 50-100 us to come
+    back: 775 -> 679 pairs/s one pair at a time), and what a rank sharing a node with seven others does not."""
+    mode = mode or FETCH_WAIT
+    if mode == "sync":
         ev.synchronize()
         return
-    import time
-    fine_sleep_slack()
-    while not ev.query():
-        time.sleep(FETCH_POLL_S)
+    if mode == "pypoll":
+        import time
+        fine_sleep_slack()
+        while not ev.query():
+            time.sleep(FETCH_POLL_S)
+        return
+    if ev.query():      # landed already (or never recorded): nothing to wait for
+        return
+    check(_lib_().apr_event_wait(C.c_void_p(ev.cuda_event), int(FETCH_POLL_S * 1e6)))
 
 
 class PendingFetch:
@@ -281,21 +293,22 @@ class PendingFetch:
         self.event.record()
         self._then, self._keep = then, keep
 
-    def wait(self):
-        wait_event(self.event)
+    def wait(self, mode=None):
+        wait_event(self.event, mode)
 
     def finish(self):
         wait_event(self.event)
         return self._then(self._host.numpy())
 
 
-def drive(gen):
+def drive(gen, wait=None):
     """Run a generator that yields PendingFetch objects (register_batch_phases, collate_phases) to completion on the
-    calling thread, waiting at every fetch: the blocking form of a pipelined step.  -> the generator's return value."""
+    calling thread, waiting at every fetch: the blocking form of a pipelined step.  -> the generator's return value.
+    `wait`: how to wait (wait_event's `mode`; None = the process default)."""
     try:
         pending = next(gen)
         while True:
-            pending.wait()
+            pending.wait(wait)
             pending = gen.send(None)
     except StopIteration as stop:
         return stop.value

@@ -42,7 +42,7 @@ class HostPending:
     def synchronize(self):
         self._future.result()
 
-    def wait(self):
+    def wait(self, mode=None):
         self._future.result()
 
     def finish(self):

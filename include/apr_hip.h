@@ -38,6 +38,10 @@ const char* apr_last_error(void);
 int apr_version(void);
 /* Number of HIP devices visible; does not initialise a context. */
 int apr_device_count(void);
+/* Host wait for a HIP event (hipEvent_t) by hipEventQuery + nanosleep(poll_us): no spinning CPU (hipEventSynchronize spins on
+ * this stack even for hipEventBlockingSync events) and, called through ctypes, no interpreter lock held while waiting.  The
+ * reference's loop blocks in `.cpu()` / `.item()` at the same places (FCGF_APR/scripts/test_apr.py:137-146). */
+int apr_event_wait(void* event, int32_t poll_us);
 
 /* ------------------------------------------------------------------------
  * Voxel hashing / coordinate maps
