@@ -406,11 +406,11 @@ class _ConvBase(nn.Module):
         """3-way bf16 split of the kernel for the weight-stationary path (None if the shape is not covered or the
         split path is switched off with APR_WS_BF3=0)."""
         import os
-        if os.environ.get("APR_WS_BF3", "1") == "0" or self.kernel.dim() != 3:
+        if os.environ.get("APR_WS_BF3", "1") == "0":
             return None
         k = (self.kernel.data_ptr(), self.kernel._version, self.kernel.device)
-        if getattr(self, "_bf3_key", None) != k:
-            self._bf3 = ops.pack_weights_bf3(self.kernel)
+        if getattr(self, "_bf3_key", None) != k:      # a kernel-size-1 layer stores [Cin, Cout]: the dense K = 1 image
+            self._bf3 = ops.pack_weights_bf3(self.kernel if self.kernel.dim() == 3 else self.kernel.unsqueeze(0))
             self._bf3_key = k
         return self._bf3
 
@@ -444,7 +444,8 @@ class _ConvBase(nn.Module):
         return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
                   self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
                   relu=relu, out=out, n_out=n_out, plist=None if os_pairs is not None else plist,
-                  w_bf3=self.packed_weight_bf3() if plist is not None else None, os_pairs=os_pairs, **kw)
+                  w_bf3=self.packed_weight_bf3() if (plist is not None or (nbr is None and batch is not None)) else None,
+                  os_pairs=os_pairs, **kw)
 
     def occ_ready(self, x: SparseTensor):
         """True if this layer on this input is the occupancy special case (ops.occ_conv): constant-1 features, one input

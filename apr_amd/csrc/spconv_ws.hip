@@ -844,10 +844,14 @@ static int ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const v
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+      APR_HIP(hipFuncSetAttribute((const void*)k_ws_gemm_bf3<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       s_attr[dev] = true;
     }
   }
-  if (w_bf3 && (cin == 64 || cin == 128 || cin == 256)) {
+  // 192 / 384 input channels: the transposed convolutions behind a skip concatenation in the wide variants (ResUNetFatBN:
+  // conv2_tr 192 -> 128, conv3_tr 384 -> 128, FCGF_APR/model/resunet.py:224-227) -- same kernel, 3 / 6 chunks per group
+  if (w_bf3 && (cin == 64 || cin == 128 || cin == 192 || cin == 256 || cin == 384)) {
     // bf16 3-way split path: slice = cin * 64 * 6 B
     const size_t lds3 = (size_t)cin * 64 * 6;
     int64_t per_cu3 = (160 * 1024) / (int64_t)lds3;
@@ -860,8 +864,11 @@ static int ws_fwd(const float* in, int64_t ldi, const int32_t* counters, const v
     if (cin == 256 && s_nw8)
       hipLaunchKernelGGL((k_ws_gemm_bf3<4, 8>), dim3((unsigned)(gx3 * (cout / 64))), dim3(512), lds3, st, in, ldi, v, K, cin, cout,
                          (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
+    else if (cin == 384)      // 144 KB slice: one 8-wave workgroup per CU
+      hipLaunchKernelGGL((k_ws_gemm_bf3<6, 8>), dim3((unsigned)(gx3 * (cout / 64))), dim3(512), lds3, st, in, ldi, v, K, cin, cout,
+                         (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
     else {
-      auto k3 = cin == 64 ? k_ws_gemm_bf3<1> : cin == 128 ? k_ws_gemm_bf3<2> : k_ws_gemm_bf3<4>;
+      auto k3 = cin == 64 ? k_ws_gemm_bf3<1> : cin == 128 ? k_ws_gemm_bf3<2> : cin == 192 ? k_ws_gemm_bf3<3> : k_ws_gemm_bf3<4>;
       hipLaunchKernelGGL(k3, dim3((unsigned)(gx3 * (cout / 64))), dim3(256), lds3, st, in, ldi, v, K, cin, cout,
                          (const __bf16*)w_bf3, prod_scratch, (int)n_out, (int)target3);
     }

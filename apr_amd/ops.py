@@ -388,13 +388,13 @@ def pack_weights(w: torch.Tensor) -> torch.Tensor:
 
 def pack_weights_bf3(w: torch.Tensor):
     """[K,cin,cout] fp32 kernel -> the 3-way bf16 split image of apr_spconv_ws_fwd_bf3 (uint8 blob), or None when the
-    shape is not covered (sparse kernels: cin not in 64/128/256; the dense K = 1 form takes any cin % 64 == 0;
+    shape is not covered (sparse kernels: cin not in 64/128/192/256/384; the dense K = 1 form takes any cin % 64 == 0;
     cout % 64 != 0)."""
     w = _f32(w.detach(), "pack_weights_bf3.w")
     if w.dim() != 3:
         return None
     K, cin, cout = w.shape
-    if (cin not in (64, 128, 256) and not (K == 1 and cin % 64 == 0 and cin >= 64)) or cout % 64 != 0 or cout < 64:
+    if (cin not in (64, 128, 192, 256, 384) and not (K == 1 and cin % 64 == 0 and cin >= 64)) or cout % 64 != 0 or cout < 64:
         return None
     lib = _lib_()
     blob = torch.empty(int(lib.apr_spconv_packed_bf3_bytes(K, cin, cout)), dtype=torch.uint8, device=w.device)
@@ -775,6 +775,11 @@ class SpconvBatch:
             if not plist.built and not plist.queued:
                 d.plist_bytes, plist.queued = plist.blob.numel(), True
                 self.pending.append(plist)
+        elif nbr is None and K == 1 and w_bf3 is not None and cin % 64 == 0 and cout % 64 == 0 and ldi % 4 == 0 \
+                and ldo % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 \
+                and (residual is None or (ldr % 4 == 0 and residual.data_ptr() % 16 == 0)) \
+                and (scale is None or scale.data_ptr() % 16 == 0) and (shift is None or shift.data_ptr() % 16 == 0):
+            d.w_bf3 = w_bf3.data_ptr()          # identity map, 64-multiple widths: the dense GEMM on the bf16 split
         self.descs.append(d)
         if PROFILE is not None:
             self.meta.append((PROFILE.pairs(nbr, n_out), cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0,

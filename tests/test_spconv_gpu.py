@@ -70,8 +70,8 @@ def test_weight_stationary_path_matches_oracle(dev, cin, cout, K, n_in, n_out, d
     rng = np.random.default_rng(cin * 977 + cout + K + n_out)
     xw = torch.from_numpy(rng.standard_normal((n_in, cin + 32)).astype(np.float32))
     if gemm == "bf3":
-        if cin not in (64, 128, 256):
-            pytest.skip("k_ws_gemm_bf3 covers cin 64 / 128 / 256")
+        if cin not in (64, 128, 192, 256, 384):
+            pytest.skip("k_ws_gemm_bf3 covers cin 64 / 128 / 192 / 256 / 384")
         xw = xw * torch.from_numpy(np.exp(rng.uniform(-9.2, 9.2, (n_in, 1))).astype(np.float32))
     if gemm == "ws3":      # the x-triple entry lists (k_ws3_gemm_bf3: one product row per entry, three offsets per accumulator)
         if cin not in (64, 128) or K != 27:
