@@ -128,6 +128,8 @@ PROTOTYPES = {
     "apr_reverse_gather": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _i64, _p]),
     "apr_reverse_gather_range": (C.c_int, [_p, _i32, _p, _p, _i64, _i64, _i64, _i32, _p, _i64, _p]),
     "apr_gather_pool": (C.c_int, [_p, _i64, _i64, _i32, _p, _i32, _i64, _i32, _p, _i64, _p]),
+    "apr_gather_pool_argmax": (C.c_int, [_p, _i64, _i64, _i32, _p, _i32, _i64, _p, _i64, _p, _p]),
+    "apr_gather_pool_backward": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p]),
     "apr_edge_features": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p]),
     "apr_group_max": (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _f32, _p, _i64, _p]),
     "apr_coords_bbox": (C.c_int, [_p, _i64, _p, _p]),

@@ -277,6 +277,58 @@ __global__ void k_gather_pool(const float* __restrict__ x, int64_t ldx, int ns, 
   }
 }
 
+// max_pool with the position of the maximum: amax[q, c] = the FIRST h whose x_pad[inds[q,h], c] equals the maximum (what
+// the backward routes the gradient to, as torch.max(dim) does); thread = (query, channel)
+__global__ void k_gather_pool_argmax(const float* __restrict__ x, int64_t ldx, int ns, int c, const int* __restrict__ inds,
+                                     int H, int64_t nq, float* __restrict__ out, int64_t ldo,
+                                     unsigned char* __restrict__ amax) {
+  const int64_t total = nq * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t qi = t / c;
+    const int col = (int)(t - qi * c);
+    float m = -__builtin_inff();
+    int best = 0;
+    for (int h0 = 0; h0 < H; h0 += 8) {
+      int idx[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) idx[u] = (h0 + u < H) ? inds[qi * H + h0 + u] : -2;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = (idx[u] >= 0 && idx[u] < ns) ? x[(int64_t)idx[u] * ldx + col] : (idx[u] == -2 ? -__builtin_inff() : 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] > m) {
+          m = v[u];
+          best = h0 + u;
+        }
+    }
+    out[qi * ldo + col] = m;
+    amax[qi * c + col] = (unsigned char)best;
+  }
+}
+
+// Backward of max_pool / closest_pool as a GATHER over the reverse neighbour table (revtable.hip): dx[s, c] = sum of
+// dout[q, c] over the entries (q, h) of row s's run with h == amax[q, c] (mode 0) or h == 0 (mode 1), in run order:
+// deterministic, no float atomics, no contribution buffer.  thread = (support row, channel)
+__global__ void k_gather_pool_bwd(const float* __restrict__ dout, int64_t lddo, int c, const int* __restrict__ rev_t,
+                                  const int* __restrict__ start, int64_t ns, int H, const unsigned char* __restrict__ amax,
+                                  int mode, float* __restrict__ dx, int64_t lddx) {
+  const int64_t total = ns * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = t / c;
+    const int col = (int)(t - s * c);
+    float acc = 0.f;
+    for (int e = start[s]; e < start[s + 1]; ++e) {
+      const int pos = rev_t[e];
+      const int q = pos / H, h = pos - q * H;
+      const bool mine = mode == 1 ? h == 0 : (int)amax[(int64_t)q * c + col] == h;
+      if (mine) acc += dout[(int64_t)q * lddo + col];
+    }
+    dx[s * lddx + col] = acc;
+  }
+}
+
 // edge features of the DGCNN-style self attention: row (i,j) = [f_i, f_nbr(i,j) - f_i]   (gcn.py:9-35)
 __global__ void k_edge_features(const float* __restrict__ f, int64_t ldf, int n, int c, const int* __restrict__ knn,
                                 int k, float* __restrict__ out) {
@@ -849,6 +901,36 @@ APR_API int apr_gather_pool(const float* x, int64_t ldx, int64_t ns, int32_t c, 
   else
     hipLaunchKernelGGL(k_gather_pool, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)ns, c, inds, H,
                        nq, mode, out, ldo);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// max_pool (blocks.py:86-102) with the arg-max kept for the backward: amax u8 [nq, c] (H <= 255).
+APR_API int apr_gather_pool_argmax(const float* x, int64_t ldx, int64_t ns, int32_t c, const int32_t* inds, int32_t H,
+                                   int64_t nq, float* out, int64_t ldo, uint8_t* amax, void* stream) {
+  APR_CHECK_ARG(nq >= 0 && ns >= 0 && c > 0 && H > 0 && H <= 255 && ldx >= c && ldo >= c && x && inds && out && amax,
+                "apr_gather_pool_argmax: bad arguments (H <= 255)");
+  if (nq == 0) return APR_OK;
+  int64_t nblk = cdiv64(nq * c, 256);
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(k_gather_pool_argmax, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)ns, c, inds, H,
+                     nq, out, ldo, amax);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// Input gradient of max_pool (mode 0, amax from apr_gather_pool_argmax) / closest_pool (mode 1, amax unused) over the
+// reverse table of the SAME index tensor (apr_reverse_table_build(inds, nq, H, ns)): dx f32 [ns, c], every row written.
+APR_API int apr_gather_pool_backward(const float* dout, int64_t lddo, int32_t c, const int32_t* rev_t, const int32_t* start,
+                                     int64_t ns, int32_t H, const uint8_t* amax, int32_t mode, float* dx, int64_t lddx,
+                                     void* stream) {
+  APR_CHECK_ARG(dout && rev_t && start && dx && ns > 0 && c > 0 && H > 0 && lddo >= c && lddx >= c && (mode == 1 || amax) &&
+                    (mode == 0 || mode == 1),
+                "apr_gather_pool_backward: bad arguments");
+  int64_t nblk = cdiv64(ns * c, 256);
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(k_gather_pool_bwd, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dout, lddo, c, rev_t, start, ns,
+                     H, amax, mode, dx, lddx);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

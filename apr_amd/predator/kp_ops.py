@@ -257,6 +257,55 @@ def gather_pool(x, inds, mode, out=None):
     return out
 
 
+class PoolFunction(torch.autograd.Function):
+    """max_pool / closest_pool (blocks.py:71-102) with forward and backward on the HIP kernels: the forward records which
+    neighbour gave each maximum (apr_gather_pool_argmax), the backward gathers dout over the reverse table of the index tensor
+    (apr_gather_pool_backward: deterministic, the same bits every run).  Training path; inference keeps gather_pool."""
+
+    @staticmethod
+    def forward(ctx, x, inds, mode):
+        inds = _i32(inds, "pool.inds")
+        x = x.contiguous()
+        ns, c = x.shape
+        nq, H = inds.shape
+        lib = _lib.load()
+        amax = None
+        if mode == "max":
+            out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+            amax = torch.empty((nq, c), dtype=torch.uint8, device=x.device)
+            check(lib.apr_gather_pool_argmax(ptr(x), c, ns, c, ptr(inds), H, nq, ptr(out), c, ptr(amax), stream()))
+        else:
+            out = gather_pool(x, inds, "closest")
+        ctx.save_for_backward(inds, amax if amax is not None else inds)
+        ctx.cfg = (mode, int(ns), int(c))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inds, amax = ctx.saved_tensors
+        mode, ns, c = ctx.cfg
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        dout = dout.contiguous()
+        rev_t, start = reverse_table(inds, ns)
+        dx = torch.empty((ns, c), dtype=torch.float32, device=dout.device)
+        check(_lib.load().apr_gather_pool_backward(ptr(dout), c, c, ptr(rev_t), ptr(start), ns, inds.shape[1],
+                                                   ptr(amax) if mode == "max" else None, 0 if mode == "max" else 1, ptr(dx), c,
+                                                   stream()))
+        return dx, None, None
+
+
+HIP_TRAIN_POOL = os.environ.get("APR_HIP_TRAIN_POOL", "1") != "0"     # A/B switch: 0 = torch indexing for the pools in training
+
+
+def pool_train(x, inds, mode):
+    """The tracked (training) form of max_pool / closest_pool: HIP kernels when the table is narrow enough for the u8 arg-max."""
+    if HIP_TRAIN_POOL and x.dim() == 2 and x.shape[0] > 0 and inds.shape[0] > 0 and inds.shape[1] <= 255:
+        return PoolFunction.apply(x, inds, mode)
+    g = gather_pad(x, inds if mode == "max" else inds[:, 0])
+    return g.max(1)[0] if mode == "max" else g
+
+
 def edge_features(f, knn):
     knn = _i32(knn, "edge_features.knn")
     f, ldf = ops._rows(f, "edge_features.f")

@@ -43,13 +43,13 @@ def _param_key(*ts):
 
 def max_pool(x, inds):
     if kp_ops.tracking(x):
-        return kp_ops.gather_pad(x, inds).max(1)[0]
+        return kp_ops.pool_train(x, inds, "max")
     return kp_ops.gather_pool(x, inds, "max")
 
 
 def closest_pool(x, inds, out=None):
     if kp_ops.tracking(x):
-        return kp_ops.gather_pad(x, inds[:, 0])
+        return kp_ops.pool_train(x, inds, "closest")
     return kp_ops.gather_pool(x, inds, "closest", out=out)
 
 

@@ -613,6 +613,16 @@ int apr_reverse_gather_range(const float* src, int32_t c, const int32_t* rev_t, 
 int apr_gather_pool(const float* x, int64_t ldx, int64_t ns, int32_t c, const int32_t* inds, int32_t H,
                     int64_t nq, int32_t mode, float* out, int64_t ldo, void* stream);
 
+/* Training path of the pooling gathers (Predator_APR/models/blocks.py:71-102 under lib/trainer.py:142-280): the forward of
+ * max_pool that also records which neighbour gave each maximum (amax u8 [nq, c]: the first h at the maximum, H <= 255), and
+ * the input gradient of max_pool (mode 0) / closest_pool (mode 1) as a gather over the reverse table of the same index
+ * tensor (apr_reverse_table_build): dx[s, c] = sum of dout[q, c] over the entries (q, h) that point at s and were the
+ * maximum (mode 0) / the first neighbour (mode 1), in table order -- deterministic, no float atomics. */
+int apr_gather_pool_argmax(const float* x, int64_t ldx, int64_t ns, int32_t c, const int32_t* inds, int32_t H, int64_t nq,
+                           float* out, int64_t ldo, uint8_t* amax, void* stream);
+int apr_gather_pool_backward(const float* dout, int64_t lddo, int32_t c, const int32_t* rev_t, const int32_t* start,
+                             int64_t ns, int32_t H, const uint8_t* amax, int32_t mode, float* dx, int64_t lddx, void* stream);
+
 /* get_graph_feature (gcn.py:9-35) as rows: out[(i*k + j), :] = [f_i, f_knn(i,j) - f_i], f32 [n*k, 2c]. */
 int apr_edge_features(const float* f, int64_t ldf, int32_t n, int32_t c, const int32_t* knn, int32_t k,
                       float* out, void* stream);

@@ -440,3 +440,32 @@ def test_linear_training_function_any_width(dev, n, cin, cout):
     (y * proj.to(dev)).sum().backward()
     assert rel_l2(y.detach().cpu(), torch.nn.functional.linear(x.double(), W.double())) < 2e-6
     assert rel_l2(xg.grad.cpu(), xd.grad) < 2e-6 and rel_l2(Wg.grad.cpu(), Wd.grad) < 2e-6
+
+
+@pytest.mark.parametrize("mode,ns,nq,H,c", [("max", 3000, 1100, 37, 64), ("max", 500, 2000, 58, 129), ("closest", 900, 4000, 12, 258),
+                                            ("closest", 50, 70, 1, 34), ("max", 64, 64, 255, 8)])
+def test_pool_training_function_gradients(dev, mode, ns, nq, H, c):
+    """kp_ops.PoolFunction (max_pool / closest_pool of blocks.py:71-102 in training): forward == the inference kernel, the input
+    gradient == torch autograd through the reference's gather-and-max formulation, the same bits on a second backward; shadow
+    neighbours (index ns) and rows nobody points at included."""
+    rng = np.random.default_rng(ns + nq + H)
+    x = torch.from_numpy(rng.standard_normal((ns, c)).astype(np.float32))
+    inds = torch.from_numpy(rng.integers(0, ns + 1, (nq, H)).astype(np.int32))      # ns = the shadow row
+    inds[rng.random(nq) < 0.1] = ns                                                    # queries with shadow neighbours only
+    proj = torch.from_numpy(rng.standard_normal((nq, c)).astype(np.float32))
+    xr = x.double().requires_grad_(True)
+    g = kp_ops.gather_pad(xr, inds.long() if mode == "max" else inds[:, 0].long())
+    ref = g.max(1)[0] if mode == "max" else g
+    (ref * proj.double()).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    assert kp_ops.HIP_TRAIN_POOL
+    out = kp_ops.pool_train(xg, inds.to(dev), mode)
+    assert "PoolFunction" in type(out.grad_fn).__name__
+    assert torch.equal(out.detach(), kp_ops.gather_pool(x.to(dev), inds.to(dev), mode))
+    assert torch.equal(out.detach().cpu().double(), ref.detach())
+    (out * proj.to(dev)).sum().backward()
+    assert rel_l2(xg.grad.cpu(), xr.grad) < 1e-6
+    g1 = xg.grad.clone()
+    xg.grad = None
+    (kp_ops.pool_train(xg, inds.to(dev), mode) * proj.to(dev)).sum().backward()
+    assert torch.equal(xg.grad, g1)
