@@ -11,8 +11,13 @@ import math
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import ops
 from .._lib import AprHipError
+
+# kernel maps over the stride-1 map probe conv1's occupancy bitmap before the hash table (ops.kernel_map_occ); 0: table only
+OCC_KERNEL_MAP = os.environ.get("APR_OCC_KERNEL_MAP", "1") != "0"
 
 
 class CoordinateMapKey:
@@ -67,6 +72,7 @@ class CoordinateManager:
         self._plist_counters = None
         self._tpool = None
         self._bbox = None
+        self._occ = []           # [(scratch, bbox, kernel size)]: the occupancy bitmap conv1 left over the stride-1 map
         self.device = self.maps[1].keys.device
 
     # -- coordinate maps -----------------------------------------------------
@@ -177,7 +183,11 @@ class CoordinateManager:
             else:
                 # regular: c_in = c_out + o*ts_in ; transposed (coarse->fine): c_coarse = c_fine - o*ts_fine
                 scale = -ts_out if transpose else ts_in
-                nbr = ops.kernel_map(out_map, in_map, kernel_size, scale)
+                if self._occ and ts_in == 1 and not transpose and kernel_size == 3 and OCC_KERNEL_MAP:
+                    # the bitmap conv1 built over this map answers most probes (empty cells) without the hash table
+                    nbr = ops.kernel_map_occ(out_map, in_map, kernel_size, scale, self._occ[0])
+                else:
+                    nbr = ops.kernel_map(out_map, in_map, kernel_size, scale)
             self._kmaps[key] = nbr
         return nbr
 
@@ -465,7 +475,7 @@ class _ConvBase(nn.Module):
             shift = self.bias.view(-1)
         w = self.kernel.detach().reshape(self.kernel_volume, self.out_channels)
         return ops.occ_conv(cm.get_map(1).coords, n_out, cm.get_bbox(), self.kernel_size, w, scale=scale, shift=shift,
-                            relu=relu, out=out)
+                            relu=relu, out=out, keep=cm._occ if not cm._occ else None)
 
     def _reverse_map(self, x: SparseTensor, nbr_fwd, ts_out):
         """Map of the input gradient: (table, mirrored offsets?)  (backward)."""

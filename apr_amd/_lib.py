@@ -143,6 +143,7 @@ PROTOTYPES = {
     "apr_occ_conv_scratch_bytes": (_sz, [_p, _i32]),
     "apr_occ_conv_pays": (C.c_int, [_p, _i32, _i64]),
     "apr_occ_conv": (C.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _p, _i64, _p, _sz, _p]),
+    "apr_kernel_map_occ": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _p, _p, _p]),
     "apr_mha": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_mha_headmajor": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_softmax_matvec": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _p, _p]),

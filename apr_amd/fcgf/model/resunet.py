@@ -44,6 +44,10 @@ WS_STAGES = ("block2", "block3", "block4", "conv4_tr", "block4_tr", "conv3_tr", 
 # block3_tr 2 x 79 -> 2 x 57 us at 12 frames per call.  Only taken where the layer has 64 input channels
 # (apr_spconv_os_tile_rows); elsewhere the stage keeps its entry in WS_STAGES.  APR_OS_STAGES overrides ("none": off).
 OS_STAGES = ("block2", "block3_tr", "block2_tr")
+# ... and only on maps large enough: the tile kernel's per-offset barrier and its streamed weight slices are a fixed cost per
+# tile, the triple-list gemm's units are not.  scripts/layer_bench.py, 64 -> 64, os vs ws3 (us): 189 k rows 126 / 141,
+# 71 k rows 55 / 54.5, 27.7 k rows (ONE pair per call) 38.4 / 29.1, 10.2 k rows 31.1 / 16.2.
+OS_MIN_ROWS = int(os.environ.get("APR_OS_MIN_ROWS", "50000"))
 
 
 WS3_MAX_ROWS_128 = int(os.environ.get("APR_WS3_MAX_ROWS_128", "100000"))
@@ -206,7 +210,8 @@ class ResUNet2(ME.MinkowskiNetwork):
             bl = None
             # 64 input channels only: at 128 the kernel exists and is tested but loses to the weight-stationary pair
             # on every level (12 frames per call: 494 vs 444 us at 189 k rows, 79 vs 69 us at 26 k)
-            if "block" + name in osn and blk.conv1.in_channels == 64 and blk.conv1.packed_weight_bf3() is not None:
+            if ("block" + name in osn and blk.conv1.in_channels == 64 and blk.conv1.packed_weight_bf3() is not None
+                    and n_out >= OS_MIN_ROWS):
                 bl = cm.os_pair_list(*bmap, blk.conv1.in_channels, blk.conv1.out_channels)
             if bl is None and "block" + name in ws:
                 bl = ws_list(blk.conv1, bmap)

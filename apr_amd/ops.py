@@ -1026,10 +1026,11 @@ def occ_conv_supported(bbox, kernel_size, cout, n=None):
     return int(_lib_().apr_occ_conv_scratch_bytes(box, int(kernel_size))) > 0
 
 
-def occ_conv(coords, n, bbox, kernel_size, w, scale=None, shift=None, relu=False, residual=None, out=None):
+def occ_conv(coords, n, bbox, kernel_size, w, scale=None, shift=None, relu=False, residual=None, out=None, keep=None):
     """Stride-1 ks^3 convolution of the constant-1 feature over the voxels coords[:n] (apr_occ_conv): w f32 [ks^3, cout];
     bbox: the 8 host ints of `coords_bbox` for these rows (or a superset; voxel units).  Same bits as `spconv` over the
-    kernel map on all-ones features; a row outside the box comes out as NaN."""
+    kernel map on all-ones features; a row outside the box comes out as NaN.  keep: a list that receives
+    (scratch, bbox tuple, kernel_size) -- the occupancy bitmap, for `kernel_map_occ`."""
     lib = _lib_()
     w = _f32(w, "occ_conv.w").contiguous()
     K, cout = w.shape
@@ -1048,7 +1049,20 @@ def occ_conv(coords, n, bbox, kernel_size, w, scale=None, shift=None, relu=False
     scratch = torch.empty(sb, dtype=torch.uint8, device=coords.device)
     check(lib.apr_occ_conv(ptr(coords), int(n), box, int(kernel_size), ptr(w), cout, ptr(scale), ptr(shift), ptr(residual),
                            ldr, int(bool(relu)), ptr(out), ldo, ptr(scratch), sb, stream()))
+    if keep is not None:
+        keep.append((scratch, tuple(int(v) for v in bbox), int(kernel_size)))
     return out
+
+
+def kernel_map_occ(out_map: CoordMap, in_map: CoordMap, kernel_size: int, scale: int, occ) -> torch.Tensor:
+    """`kernel_map` with the occupancy bitmap `occ` = (scratch, bbox, bitmap kernel size) that `occ_conv(keep=...)` left
+    for `in_map` as a pre-filter of the probes (apr_kernel_map_occ): same table."""
+    scratch, bbox, bks = occ
+    nbr = torch.empty((out_map.n, kernel_size ** 3), dtype=torch.int32, device=out_map.coords.device)
+    box = (C.c_int32 * 8)(*bbox)
+    check(_lib_().apr_kernel_map_occ(ptr(out_map.coords), out_map.n, None, ptr(in_map.keys), ptr(in_map.vals), in_map.cap,
+                                     int(kernel_size), int(scale), box, int(bks), ptr(scratch), ptr(nbr), stream()))
+    return nbr
 
 
 def set_match_lanes(lanes):

@@ -166,6 +166,15 @@ int apr_occ_conv_pays(const int32_t* bbox_host, int32_t kernel_size, int64_t n);
 int apr_occ_conv(const int32_t* coords, int64_t n, const int32_t* bbox_host, int32_t kernel_size, const float* w,
                  int32_t cout, const float* scale, const float* shift, const float* residual, int64_t ldr,
                  int32_t relu, float* out, int64_t ldo, void* scratch, size_t scratch_bytes, void* stream);
+/* apr_kernel_map with the bitmap apr_occ_conv left in `occ_scratch` as a pre-filter of the probes (72 % of a LiDAR
+ * map's probes hit an empty cell, the table's most expensive case): same table out, bit for bit.  bbox_host and
+ * bitmap_kernel_size: those of the apr_occ_conv call that wrote occ_scratch (same stream, or ordered behind it);
+ * in_keys / in_vals: the map the bitmap was built from; out_coords: that map's rows or a coarser map's.  Cells outside
+ * the bitmap's box fall back to the table.  Replaces the same MinkowskiEngine kernel-map build as apr_kernel_map. */
+int apr_kernel_map_occ(const int32_t* out_coords, int64_t n_out, const int32_t* n_out_dev, const uint64_t* in_keys,
+                       const int32_t* in_vals, int64_t cap, int32_t kernel_size, int32_t scale,
+                       const int32_t* bbox_host, int32_t bitmap_kernel_size, const void* occ_scratch, int32_t* nbr,
+                       void* stream);
 
 /* ------------------------------------------------------------------------
  * Sparse convolution forward (gather -> MFMA -> fused epilogue), fp32.

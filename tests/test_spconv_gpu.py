@@ -366,6 +366,34 @@ def _clustered_coords(rng, n, nbatch, lo, hi, spread):
     return coords[rng.permutation(len(coords))].astype(np.int32)
 
 
+@pytest.mark.parametrize("bks,n,nbatch,lo,hi,spread", [
+    (5, 4000, 3, -40, 55, 6), (3, 3000, 2, -21, 20, 4), (7, 1500, 2, -25, 30, 5), (5, 60000, 2, -160, 161, 30), (5, 1, 1, 7, 7, 0),
+])
+def test_kernel_map_with_occupancy_prefilter(dev, bks, n, nbatch, lo, hi, spread):
+    """apr_kernel_map_occ (probe conv1's occupancy bitmap first, the hash table only for occupied cells) == apr_kernel_map,
+    on the same-level 3^3 map and on the strided 1 -> 2 map (output voxels floor below the box's minimum: cells outside the
+    bitmap go to the table), with the exact box, a superset box and a box that MISSES voxels."""
+    rng = np.random.default_rng(bks * 1000 + n)
+    coords = np.array([[0, 7, 7, 7]], dtype=np.int32) if n == 1 else _clustered_coords(rng, n, nbatch, lo, hi, spread)
+    cd = torch.from_numpy(coords).to(dev)
+    N = len(coords)
+    m = ops.build_map(cd)
+    m2 = ops.build_map(cd, floor_to=2)
+    ops.finalize_maps([m, m2])
+    bbox = ops.coords_bbox(cd).tolist()
+    w = torch.zeros((bks ** 3, 8), dtype=torch.float32, device=dev)
+    ref_same, ref_down = ops.kernel_map(m, m, 3, 1), ops.kernel_map(m2, m, 3, 1)
+    assert int((ref_same >= 0).sum()) >= N and int((ref_down >= 0).sum()) >= N
+    boxes = [bbox, [bbox[0] - 3, bbox[1] - 40, bbox[2], bbox[3] + 37, bbox[4], bbox[5] + 2, bbox[6] + 1, 0]]
+    if n > 1:
+        boxes.append([bbox[0] + 2, bbox[1], bbox[2] + 1, bbox[3] - 3, bbox[4], bbox[5], max(bbox[6] - 1, 0), 0])
+    for box in boxes:
+        keep = []
+        ops.occ_conv(m.coords, N, box, bks, w, keep=keep)
+        assert torch.equal(ops.kernel_map_occ(m, m, 3, 1, keep[0]), ref_same)
+        assert torch.equal(ops.kernel_map_occ(m2, m, 3, 1, keep[0]), ref_down)
+
+
 @pytest.mark.parametrize("ks,cout,n,nbatch,lo,hi,spread", [
     (5, 32, 4000, 3, -40, 55, 6), (3, 32, 3000, 2, -20, 20, 4), (7, 32, 1500, 2, -25, 30, 5), (5, 8, 500, 1, 0, 31, 3),
     (5, 40, 2500, 4, -100, -36, 5), (5, 32, 60000, 2, -160, 160, 30), (5, 64, 1, 1, 7, 7, 0),
