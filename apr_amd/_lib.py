@@ -39,8 +39,30 @@ class SpconvDesc(C.Structure):
                 ("os_n_in", C.c_int64), ("l2norm", C.c_int32), ("ws3", C.c_int32)]
 
 
+class ResunetLayer(C.Structure):
+    """struct apr_resunet_layer (include/apr_hip.h)."""
+    _fields_ = [("K", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32),
+                ("w_packed", C.c_void_p), ("w_bf3", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
+class ResunetPlan(C.Structure):
+    """struct apr_resunet_plan (include/apr_hip.h)."""
+    _fields_ = [("layer", ResunetLayer * 23), ("conv1_w", C.c_void_p), ("conv1_ks", C.c_int32), ("normalize", C.c_int32),
+                ("ws_conv", C.c_uint32), ("ws_block", C.c_uint32), ("os_block", C.c_uint32),
+                ("ws3", C.c_int32), ("ws3_cin128", C.c_int32), ("os_min_rows", C.c_int32), ("occ_kernel_map", C.c_int32),
+                ("ws3_max_rows_128", C.c_int64)]
+
+
+class LevelMap(C.Structure):
+    """struct apr_level_map (include/apr_hip.h)."""
+    _fields_ = [("coords", C.c_void_p), ("keys", C.c_void_p), ("vals", C.c_void_p), ("cap", C.c_int64), ("n", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
 PROTOTYPES = {
+    "apr_resunet_encode_supported": (C.c_int, [_p, _p, _p]),
+    "apr_resunet_encode_scratch_bytes": (_sz, [_p, _p, _p]),
+    "apr_resunet_encode": (C.c_int, [_p, _p, _p, _p, _i32, _p, _sz, _p, _i64, _p]),
     "apr_last_error": (C.c_char_p, []),
     "apr_version": (C.c_int, []),
     "apr_device_count": (C.c_int, []),

@@ -48,6 +48,8 @@ OS_STAGES = ("block2", "block3_tr", "block2_tr")
 # tile, the triple-list gemm's units are not.  scripts/layer_bench.py, 64 -> 64, os vs ws3 (us): 189 k rows 126 / 141,
 # 71 k rows 55 / 54.5, 27.7 k rows (ONE pair per call) 38.4 / 29.1, 10.2 k rows 31.1 / 16.2.
 OS_MIN_ROWS = int(os.environ.get("APR_OS_MIN_ROWS", "50000"))
+# the fused plan issued by ONE library call (apr_resunet_encode) instead of stage by stage from Python; 0: A/B switch
+ENCODE_PLAN = os.environ.get("APR_ENCODE_PLAN", "1") != "0"
 
 
 WS3_MAX_ROWS_128 = int(os.environ.get("APR_WS3_MAX_ROWS_128", "100000"))
@@ -159,11 +161,93 @@ class ResUNet2(ME.MinkowskiNetwork):
         return (self.use_fused and not self.training and not torch.is_grad_enabled() and self.NORM_TYPE == 'BN'
                 and self.BLOCK_NORM_TYPE == 'BN')
 
+    # ---- the fused plan as ONE library call (apr_resunet_encode, csrc/encoder.hip): same launches, issued from C
+    _STAGES = ("1", "2", "3", "4", "4_tr", "3_tr", "2_tr")
+
+    def _encode_plan(self):
+        """The model as an apr_resunet_plan (packed weights, folded BatchNorm, routing), rebuilt when a parameter, a buffer
+        or a routing switch changes."""
+        import ctypes as C
+        from ... import _lib
+        tensors = getattr(self, "_plan_tensors", None)
+        if tensors is None:
+            tensors = self._plan_tensors = list(self.parameters()) + list(self.buffers())
+        ws, osn = _ws_stages(), _os_stages()
+        env = (tuple(sorted(ws)), tuple(sorted(osn)), os.environ.get("APR_WS3", "1"), os.environ.get("APR_WS_BF3", "1"),
+               WS3_CIN128, WS3_MAX_ROWS_128, OS_MIN_ROWS, ME.core.OCC_KERNEL_MAP, bool(self.normalize_feature))
+        key = (tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors), env)
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan
+        plan, keep = _lib.ResunetPlan(), []
+
+        def fill(i, conv, norm, relu):
+            L = plan.layer[i]
+            L.K, L.cin, L.cout, L.relu = conv.kernel_volume if conv.kernel.dim() == 3 else 1, conv.in_channels, conv.out_channels, int(relu)
+            wp, w3 = conv.packed_weight(), conv.packed_weight_bf3()
+            sc, sh = norm.folded() if norm is not None else (None, None)
+            if sh is None and conv.bias is not None:
+                sh = conv.bias.detach().view(-1)
+            keep.extend([wp, w3, sc, sh])
+            L.w_packed, L.w_bf3 = wp.data_ptr(), (w3.data_ptr() if w3 is not None else None)
+            L.scale, L.shift = (sc.data_ptr() if sc is not None else None), (sh.data_ptr() if sh is not None else None)
+
+        for s, name in enumerate(self._STAGES):
+            blk = getattr(self, "block" + name)
+            fill(3 * s, getattr(self, "conv" + name), getattr(self, "norm" + name), False)
+            fill(3 * s + 1, blk.conv1, blk.norm1, True)
+            fill(3 * s + 2, blk.conv2, blk.norm2, True)
+            if "conv" + name in ws:
+                plan.ws_conv |= 1 << s
+            if "block" + name in ws:
+                plan.ws_block |= 1 << s
+            if "block" + name in osn:
+                plan.os_block |= 1 << s
+        fill(21, self.conv1_tr, None, True)
+        fill(22, self.final, None, False)
+        w1 = self.conv1.kernel.detach().reshape(self.conv1.kernel_volume, self.conv1.out_channels).float().contiguous()
+        keep.append(w1)
+        plan.conv1_w, plan.conv1_ks, plan.normalize = w1.data_ptr(), int(self.conv1.kernel_size), int(bool(self.normalize_feature))
+        plan.ws3, plan.ws3_cin128 = int(os.environ.get("APR_WS3", "1") != "0"), int(WS3_CIN128)
+        plan.os_min_rows, plan.occ_kernel_map, plan.ws3_max_rows_128 = OS_MIN_ROWS, int(ME.core.OCC_KERNEL_MAP), WS3_MAX_ROWS_128
+        self._plan, self._plan_keep, self._plan_key = plan, keep, key
+        return plan
+
+    def _forward_plan(self, x, cm):
+        """The encode through apr_resunet_encode, or None when the case is not covered (conv1 not on occupancy, a profile
+        being recorded, APR_ENCODE_PLAN=0): the caller then walks the stages itself."""
+        import ctypes as C
+        from ... import _lib
+        if not ENCODE_PLAN or ops.PROFILE is not None or self.conv1.bias is not None or not self.conv1.occ_ready(x):
+            return None
+        lib = _lib.load()
+        plan = self._encode_plan()
+        lv = (_lib.LevelMap * 4)()
+        for l, ts in enumerate((1, 2, 4, 8)):
+            m = cm.get_map(ts)
+            lv[l].coords, lv[l].keys, lv[l].vals, lv[l].cap, lv[l].n = m.coords.data_ptr(), m.keys.data_ptr(), m.vals.data_ptr(), m.cap, m.n
+        box = (C.c_int32 * 8)(*[int(v) for v in cm.get_bbox()])
+        pp = C.byref(plan)
+        sb = int(lib.apr_resunet_encode_scratch_bytes(pp, lv, box))
+        if sb == 0:
+            return None
+        dev = x.F.device
+        scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+        out = torch.empty((cm.size(1), self.final.out_channels), dtype=torch.float32, device=dev)
+        counters, slots = None, 0
+        if cm._plist_counters is not None and not cm._plists:      # zeroed with the map sizes' fetch and not yet used: hand them over
+            counters, slots, cm._plist_counters = cm._plist_counters, cm._plist_counters.shape[0], None
+        ops.check(lib.apr_resunet_encode(pp, lv, box, ops.ptr(counters), slots, ops.ptr(scratch), sb, ops.ptr(out), out.shape[1],
+                                         ops.stream()))
+        return out
+
     def forward_fused(self, x):
         cm = x.coordinate_manager
         if x.coordinate_map_key.stride != 1:
             raise ValueError("encoder input must be at tensor stride 1")
         cm.build_pyramid([2, 4, 8])
+        planned = self._forward_plan(x, cm)
+        if planned is not None:
+            return ME.SparseTensor(planned, coordinate_map_key=CoordinateMapKey(1), coordinate_manager=cm)
         N1, N2, N3, N4 = (cm.size(s) for s in (1, 2, 4, 8))
         CH, TR = self.CHANNELS, self.TR_CHANNELS
         dev = x.F.device

@@ -309,6 +309,43 @@ int apr_spconv_fwd_batch(const apr_spconv_desc* descs_host, int32_t n, void* str
 int apr_spconv_fwd_batch_timed(const apr_spconv_desc* descs, int32_t n, float* layer_ms, void* stream);
 
 /* ------------------------------------------------------------------------
+ * One ResUNet encode as ONE call (round 4): ResUNet2.forward in eval mode, FCGF_APR/model/resunet.py:142-191, over the
+ * four coordinate maps of a batch -- conv1 on the occupancy bitmap, the 7 + 3 kernel maps, the pair lists of every routed
+ * layer and the 23 conv launches are enqueued from C over one scratch arena.  The kernels, their arguments and their order
+ * are those of the module-by-module plan (apr_amd/fcgf/model/resunet.py forward_fused): same bits.  Python needed ~0.8 ms
+ * per encode to issue the same ~60 launches; with one pair per call (the reference loop's shape, test_apr.py:111-163) the
+ * host, not the GPU, set the pace.
+ *   layer[3 s + 0 / 1 / 2]: stage s = "1", "2", "3", "4", "4_tr", "3_tr", "2_tr": its (strided / transposed) conv with
+ *   the folded BN, then the two convs of its residual block; layer[21] = conv1_tr, layer[22] = final.
+ *   ws_conv / ws_block / os_block: bit s = stage s takes the weight-stationary / output-stationary kernels where the
+ *   shape allows (else the tile kernel).  lv[l]: the map of tensor stride 2^l (coords int32[n, 4], the hash table, n).
+ *   counters: apr_pairlist_counter_ints() x n_counter_slots int32, ZERO on entry (one block per pair list; NULL: a
+ *   block of the arena is cleared with one fill).  bbox_host: apr_coords_bbox of lv[0] (or a superset).
+ *   apr_resunet_encode_supported: 1 if the occupancy form of conv1 applies (apr_occ_conv_pays) and every map is
+ *   non-empty; otherwise the caller runs the module-by-module plan. */
+typedef struct apr_resunet_layer {
+  int32_t K, cin, cout, relu;
+  const float* w_packed;          /* apr_spconv_pack_weights image */
+  const void* w_bf3;              /* apr_spconv_pack_weights_bf3 image, or NULL */
+  const float* scale; const float* shift;     /* folded BatchNorm / bias, nullable */
+} apr_resunet_layer;
+typedef struct apr_resunet_plan {
+  apr_resunet_layer layer[23];
+  const float* conv1_w;           /* conv1's raw kernel f32 [ks^3, cout] (occupancy form) */
+  int32_t conv1_ks, normalize;
+  uint32_t ws_conv, ws_block, os_block;
+  int32_t ws3, ws3_cin128, os_min_rows, occ_kernel_map;
+  int64_t ws3_max_rows_128;
+} apr_resunet_plan;
+typedef struct apr_level_map {
+  const int32_t* coords; const uint64_t* keys; const int32_t* vals; int64_t cap; int64_t n;
+} apr_level_map;
+int apr_resunet_encode_supported(const apr_resunet_plan* plan, const apr_level_map* lv, const int32_t* bbox_host);
+size_t apr_resunet_encode_scratch_bytes(const apr_resunet_plan* plan, const apr_level_map* lv, const int32_t* bbox_host);
+int apr_resunet_encode(const apr_resunet_plan* plan, const apr_level_map* lv, const int32_t* bbox_host, int32_t* counters,
+                       int32_t n_counter_slots, void* scratch, size_t scratch_bytes, float* out, int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------
  * Normalisation / elementwise on feature rows [n, c]
  * ---------------------------------------------------------------------- */
 

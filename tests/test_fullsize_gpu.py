@@ -259,6 +259,16 @@ def test_bn2c_headline_batch_matches_oracle_and_single_frames(dev):
         o += counts[b]
     again = pipe.encode_batch(cm)
     assert torch.equal(again, F)                                   # bitwise reproducible, run to run
+    # ... and the same bits whether the plan leaves through ONE library call (apr_resunet_encode, the default) or stage by
+    # stage from Python
+    from apr_amd.fcgf.model import resunet as R
+    assert R.ENCODE_PLAN
+    R.ENCODE_PLAN = False
+    try:
+        staged = pipe.encode_batch(pipe.voxelize_batch(clouds)[0])
+    finally:
+        R.ENCODE_PLAN = True
+    assert torch.equal(staged, F)
     os.environ["APR_WS_STAGES"], os.environ["APR_OS_STAGES"] = "none", "none"
     try:
         tile = pipe.encode_batch(pipe.voxelize_batch(clouds)[0])

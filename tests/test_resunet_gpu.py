@@ -183,3 +183,41 @@ def test_full_size_properties_translation_and_batch_order(dev):
     swapped = encode(torch.cat([f1, f0]))                                 # (3)
     n0, n1 = len(frames[0]), len(frames[1])
     assert rel_l2(swapped[:n1].cpu(), base[n0:].cpu()) < 1e-6 and rel_l2(swapped[n1:].cpu(), base[:n0].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("name,n_out,seeds", [("ResUNetBN2C", 32, [0]), ("ResUNetBN2C", 32, [1, 2, 3]), ("ResUNetFatBN", 128, [4, 5]),
+                                               ("ResUNetBN2E", 32, [6]), ("ResUNetBN2", 32, [7, 8])])
+def test_one_call_encode_plan_equals_the_stage_by_stage_plan(dev, name, n_out, seeds, monkeypatch):
+    """apr_resunet_encode (the whole fused plan enqueued from C over one arena) == forward_fused walking its stages from
+    Python, bit for bit: the same kernels with the same arguments in the same order.  Also with other routing switches,
+    and twice on one coordinate manager (the second call clears counter blocks of its own)."""
+    from apr_amd.fcgf.model import resunet as R
+    om, hm = model_pair(name, n_out)
+    hm.eval()
+    C, F = batched_input(seeds)
+    Cd, Fd = torch.from_numpy(C).to(dev), torch.from_numpy(F).to(dev)
+
+    def run(plan, x=None):
+        monkeypatch.setattr(R, "ENCODE_PLAN", plan)
+        if x is None:
+            x = ME.SparseTensor(Fd, coordinates=Cd, unit_features=True)
+        with torch.no_grad():
+            return hm(x), x
+
+    ref, xr = run(False)
+    assert xr.coordinate_manager._kmaps                       # the stage walk filled the manager's caches ...
+    got, xg = run(True)
+    assert not xg.coordinate_manager._kmaps                   # ... the one-call plan never touched them
+    assert torch.equal(got.F, ref.F)
+    again, _ = run(True, xg)
+    assert torch.equal(again.F, ref.F)
+    for env in ({"APR_WS3": "0"}, {"APR_OS_STAGES": "none"}, {"APR_WS_STAGES": "none", "APR_OS_STAGES": "none"},
+                {"APR_OS_MIN_ROWS": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setattr(R, "OS_MIN_ROWS", int(env.get("APR_OS_MIN_ROWS", R.OS_MIN_ROWS)))
+        a, _ = run(False)
+        b, _ = run(True)
+        assert torch.equal(a.F, b.F), env
+        for k in env:
+            monkeypatch.delenv(k)
