@@ -75,6 +75,19 @@ class CoordinateManager:
         self._occ = []           # [(scratch, bbox, kernel size)]: the occupancy bitmap conv1 left over the stride-1 map
         self.device = self.maps[1].keys.device
 
+    @classmethod
+    def from_maps(cls, maps, counters=None):
+        """A manager over FINALISED maps {tensor stride: ops.CoordMap} that something else built (ops.VoxelPyramid: the
+        whole pyramid by one library call); `counters`: zeroed pair-list counter blocks [16, ops.pair_counter_ints()]."""
+        self = cls.__new__(cls)
+        self._adopted, self._dedup = True, None
+        self.maps = dict(maps)
+        self._kmaps, self._plists = {}, {}
+        self._plist_counters = counters
+        self._tpool, self._bbox, self._occ = None, None, []
+        self.device = self.maps[1].keys.device
+        return self
+
     # -- coordinate maps -----------------------------------------------------
     def _finalize(self, extras=()):
         pend = [m for m in self.maps.values() if m.n is None]

@@ -58,8 +58,17 @@ class LevelMap(C.Structure):
     _fields_ = [("coords", C.c_void_p), ("keys", C.c_void_p), ("vals", C.c_void_p), ("cap", C.c_int64), ("n", C.c_int64)]
 
 
+class Pyramid(C.Structure):
+    """struct apr_pyramid (include/apr_hip.h)."""
+    _fields_ = [("lv", LevelMap * 4), ("first", C.c_void_p), ("pts", C.c_void_p), ("header", C.c_void_p),
+                ("header_ints", C.c_int32), ("compact", C.c_int32), ("compact_rows", C.c_int64),
+                ("counters", C.c_void_p), ("n_counter_slots", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
 PROTOTYPES = {
+    "apr_voxel_pyramid_scratch_bytes": (_sz, [_i64, _i32]),
+    "apr_voxel_pyramid": (C.c_int, [_p, _p, _i32, _f32, _p, _sz, _p, _p]),
     "apr_resunet_encode_supported": (C.c_int, [_p, _p, _p]),
     "apr_resunet_encode_scratch_bytes": (_sz, [_p, _p, _p]),
     "apr_resunet_encode": (C.c_int, [_p, _p, _p, _p, _i32, _p, _sz, _p, _i64, _p]),

@@ -343,3 +343,123 @@ APR_API int apr_resunet_encode(const apr_resunet_plan* plan, const apr_level_map
   e.walk(out, ldo);
   return e.rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The front end of a step as one call (see include/apr_hip.h): the same kernels in the same order as
+// PairRegistration.voxelize_batch issued them tensor by tensor (apr_amd/fcgf/pipeline.py).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Front {
+  bool dry;
+  char* base;
+  size_t off = 0;
+  Front(void* arena) : dry(arena == nullptr), base((char*)(((uintptr_t)arena + 255) & ~(uintptr_t)255)) {}
+  void* take(size_t bytes) {
+    void* q = dry ? nullptr : (void*)(base + off);
+    off += al256(bytes);
+    return q;
+  }
+};
+
+struct MapBufs {
+  uint64_t* keys; int32_t* vals; int64_t cap; int32_t* coords; int64_t* first; int32_t *n_dev, *status; void* scratch;
+  size_t scratch_bytes; int64_t rows;
+};
+
+// the builds run one behind the other on one stream: they share ONE scratch (sized for the largest, the first)
+MapBufs take_map(Front& f, int64_t rows, bool want_first, int32_t* hdr_slot, void* shared_scratch, size_t shared_bytes) {
+  MapBufs m;
+  m.rows = rows;
+  m.cap = apr_hash_capacity(rows);
+  m.keys = (uint64_t*)f.take((size_t)m.cap * 8);
+  m.vals = (int32_t*)f.take((size_t)m.cap * 4);
+  m.coords = (int32_t*)f.take((size_t)rows * 16);
+  m.first = want_first ? (int64_t*)f.take((size_t)rows * 8) : nullptr;
+  m.scratch_bytes = shared_bytes;
+  m.scratch = shared_scratch;
+  m.n_dev = hdr_slot;                   // the map writes its row count and status straight into the header
+  m.status = hdr_slot ? hdr_slot + 1 : nullptr;
+  return m;
+}
+
+// compact table: a scan puts >= ~8 points into a voxel, so the de-duplicating table (sized for the RAW points) is ~10x
+// larger than the voxels it ends up holding and every kernel-map probe into it would miss L2 (CoordinateManager.__init__)
+inline int64_t compact_rows_for(int64_t n_points) { return n_points > 4 * 65536 ? (n_points / 4 > 65536 ? n_points / 4 : 65536) : 0; }
+
+int front_walk(Front& f, const float* const* frames, const int64_t* offs, int32_t nseg, float vs, apr_pyramid* out,
+               hipStream_t st) {
+  const int64_t N = offs ? offs[nseg] : 0;
+  const int64_t R = compact_rows_for(N);
+  const int hints = 10 + nseg + 8;
+  int32_t* hdr = (int32_t*)f.take((size_t)hints * 4);
+  int32_t* counters = (int32_t*)f.take((size_t)16 * apr_pairlist_counter_ints() * 4);
+  int32_t* raw = (int32_t*)f.take((size_t)N * 16);
+  int64_t* offs_dev = (int64_t*)f.take((size_t)(nseg + 1) * 8);
+  float* pts = (float*)f.take((size_t)N * 12);
+  // level 0 = the compact table if there is one, else the de-duplicating table itself
+  const size_t sbytes = apr_map_scratch_bytes(N);
+  void* const sc = f.take(sbytes);
+  MapBufs dedup = take_map(f, N, true, f.dry ? nullptr : hdr + (R ? 8 : 0), sc, sbytes);
+  MapBufs lvl[4];
+  if (R) lvl[0] = take_map(f, R, false, f.dry ? nullptr : hdr, sc, sbytes);
+  else lvl[0] = dedup;
+  const int64_t rows = R ? R : N;
+  for (int l = 1; l < 4; ++l) lvl[l] = take_map(f, rows, false, f.dry ? nullptr : hdr + 2 * l, sc, sbytes);
+  if (f.dry) return APR_OK;
+
+  int rc;
+  // the header and the pair-list counters behind it (adjacent in the arena) cleared by one small launch (k_pack_i32's
+  // zero leg; a hipMemsetAsync here cost the three-steps-in-flight loop 1.7 %)
+  const size_t clear = (size_t)((char*)counters - (char*)hdr) + (size_t)16 * apr_pairlist_counter_ints() * 4;
+  if ((rc = apr_pack_i32(nullptr, nullptr, 0, nullptr, hdr, (int64_t)(clear / 4), st)) != APR_OK) return rc;
+  if ((rc = apr_voxelize_frames(frames, offs, nseg, vs, raw, offs_dev, st)) != APR_OK) return rc;
+  if ((rc = apr_map_build(raw, N, nullptr, 0, dedup.keys, dedup.vals, dedup.cap, dedup.coords, dedup.first, dedup.n_dev,
+                          dedup.status, dedup.scratch, dedup.scratch_bytes, st)) != APR_OK)
+    return rc;
+  if ((rc = apr_segment_counts(dedup.first, dedup.n_dev, offs_dev, nseg, hdr + 10, st)) != APR_OK) return rc;
+  if ((rc = apr_coords_bbox(raw, N, hdr + 10 + nseg, st)) != APR_OK) return rc;
+  if ((rc = apr_gather_frame_points(frames, offs, nseg, dedup.first, dedup.n_dev, N, pts, st)) != APR_OK) return rc;
+  if (R &&
+      (rc = apr_map_build(dedup.coords, R, dedup.n_dev, 0, lvl[0].keys, lvl[0].vals, lvl[0].cap, lvl[0].coords, nullptr,
+                          lvl[0].n_dev, lvl[0].status, lvl[0].scratch, lvl[0].scratch_bytes, st)) != APR_OK)
+    return rc;
+  for (int l = 1; l < 4; ++l)
+    if ((rc = apr_map_build(lvl[l - 1].coords, rows, lvl[l - 1].n_dev, 1 << l, lvl[l].keys, lvl[l].vals, lvl[l].cap, lvl[l].coords,
+                            nullptr, lvl[l].n_dev, lvl[l].status, lvl[l].scratch, lvl[l].scratch_bytes, st)) != APR_OK)
+      return rc;
+  for (int l = 0; l < 4; ++l) {
+    out->lv[l].coords = lvl[l].coords; out->lv[l].keys = lvl[l].keys; out->lv[l].vals = lvl[l].vals;
+    out->lv[l].cap = lvl[l].cap; out->lv[l].n = lvl[l].rows;
+  }
+  out->first = dedup.first;
+  out->pts = pts;
+  out->header = hdr;
+  out->header_ints = hints;
+  out->compact = R ? 1 : 0;
+  out->compact_rows = R;
+  out->counters = counters;
+  out->n_counter_slots = 16;
+  return APR_OK;
+}
+
+}  // namespace
+
+APR_API size_t apr_voxel_pyramid_scratch_bytes(int64_t n_points, int32_t nseg) {
+  if (n_points <= 0 || nseg <= 0 || nseg > APR_MAX_FRAMES) return 0;
+  Front f(nullptr);
+  int64_t offs[APR_MAX_FRAMES + 1] = {};
+  offs[nseg] = n_points;
+  (void)front_walk(f, nullptr, offs, nseg, 1.f, nullptr, nullptr);
+  return f.off + 512;
+}
+
+APR_API int apr_voxel_pyramid(const float* const* frames_host, const int64_t* offsets_host, int32_t nseg, float voxel_size,
+                              void* arena, size_t arena_bytes, apr_pyramid* out, void* stream) {
+  APR_CHECK_ARG(frames_host && offsets_host && nseg >= 1 && nseg <= APR_MAX_FRAMES && arena && out && voxel_size > 0.f,
+                "apr_voxel_pyramid: bad arguments (1 .. %d frames)", APR_MAX_FRAMES);
+  APR_CHECK_ARG(offsets_host[0] == 0 && offsets_host[nseg] > 0, "apr_voxel_pyramid: offsets must run 0 .. total points > 0");
+  APR_CHECK_ARG(arena_bytes >= apr_voxel_pyramid_scratch_bytes(offsets_host[nseg], nseg), "apr_voxel_pyramid: arena too small");
+  Front f(arena);
+  return front_walk(f, frames_host, offsets_host, nseg, voxel_size, out, (hipStream_t)stream);
+}

@@ -17,10 +17,16 @@ one for the RANSAC result.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import MinkowskiEngine as ME
 from .. import _host, ops
+
+# the front end of a step (voxelise -> de-duplicated map -> compact table -> coarser maps) through ONE library call
+# (apr_voxel_pyramid); 0: tensor by tensor from Python (A/B switch)
+FRONT_END_CALL = os.environ.get("APR_FRONT_END_CALL", "1") != "0"
 
 
 class PairRegistration:
@@ -67,16 +73,34 @@ class PairRegistration:
         host sync fetches every size (12 + 4 builds and 2 syncs per step become 4 builds and 1 sync)."""
         if len(clouds) > 1023:
             raise ValueError("at most 1023 frames per batch (10-bit batch index in the voxel key; 1023 is reserved for the empty-slot key)")
+        cm, counts, pts_all, first, offs = ops.drive(self._front_end_phases(clouds), wait=self.fetch_wait)
+        return cm, counts, first, offs, pts_all
+
+    def _front_end_phases(self, clouds):
+        """The front end of a step as a generator (yields its ops.PendingFetch): -> (coordinate manager with the 4-level
+        pyramid, rows per frame, representative point of every row, first input point of every row, frame offsets).  Up to
+        ops.MAX_FRAMES frames leave through ONE library call over one arena (ops.VoxelPyramid); more frames, or a batch whose
+        voxels outnumber a quarter of its points, go tensor by tensor (same kernels, same bits)."""
+        if len(clouds) <= ops.MAX_FRAMES and FRONT_END_CALL:
+            vp = ops.VoxelPyramid(clouds, self.voxel_size)
+            yield vp.pending
+            res = vp.finish()
+            if res is not None:
+                maps, counts, bbox, pts_all, first, counters = res
+                cm = ME.CoordinateManager.from_maps(maps, counters)
+                cm.set_bbox(bbox)
+                return cm, counts, pts_all, first, vp.offsets
         coords_all, offs_dev, offs, gather = self._voxelize_frames(clouds)
         m = ops.build_map(coords_all, want_first=True)
         counts_dev = ops.segment_counts(m, offs_dev)
         bbox_dev = ops.coords_bbox(coords_all)         # for conv1 on occupancy (ops.occ_conv); fetched with the sizes
-        pts_all = gather(m)                            # representative point of every voxel row (frame b = rows
-        cm = ME.CoordinateManager(base_map=m)          # sum(counts[:b]) .. + counts[b], contiguous)
-        counts, bbox = cm.build_pyramid([2, 4, 8], extras=[counts_dev, bbox_dev])
+        pts_all = gather(m)                            # enqueued before the fetch: the host does not wait for it
+        cm = ME.CoordinateManager(base_map=m)
+        pending = cm.build_pyramid_async([2, 4, 8], extras=[counts_dev, bbox_dev])
+        yield pending
+        counts, bbox = pending.finish()
         cm.set_bbox(bbox)
-        pts_all = pts_all[:m.n]
-        return cm, [int(c) for c in counts], m.first, offs, pts_all
+        return cm, [int(c) for c in counts], pts_all[:m.n], m.first, offs
 
     def _voxelize_frames(self, clouds):
         """-> (coords int32 [sum n, 4] with the frame index as batch id, offsets on the device, offsets as a list, gather):
@@ -105,18 +129,7 @@ class PairRegistration:
         if len(clouds) > 1023:
             raise ValueError("at most 1023 frames per batch (10-bit batch index in the voxel key; 1023 is reserved "
                              "for the empty-slot key)")
-        coords_all, offs_dev, offs, gather = self._voxelize_frames(clouds)
-        m = ops.build_map(coords_all, want_first=True)
-        counts_dev = ops.segment_counts(m, offs_dev)
-        bbox_dev = ops.coords_bbox(coords_all)         # for conv1 on occupancy (ops.occ_conv); fetched with the sizes
-        pts_all = gather(m)                            # enqueued before the fetch: the host does not wait for it
-        cm = ME.CoordinateManager(base_map=m)
-        pending = cm.build_pyramid_async([2, 4, 8], extras=[counts_dev, bbox_dev])
-        yield pending
-        counts, bbox = pending.finish()
-        cm.set_bbox(bbox)
-        counts = [int(c) for c in counts]
-        pts_all = pts_all[:m.n]
+        cm, counts, pts_all, _, _ = yield from self._front_end_phases(clouds)
         F = self.encode_batch(cm)
         if self.feature_hook is not None:
             F = self.feature_hook(F, counts, pairs)

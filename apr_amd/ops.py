@@ -122,6 +122,59 @@ def gather_frame_points(clouds, m):
     return pts
 
 
+class VoxelPyramid:
+    """The front end of a step in flight (apr_voxel_pyramid: frames -> voxel coordinates -> de-duplicated stride-1 map ->
+    compact table -> three coarser maps, ONE library call over ONE arena) and the fetch of its header.  `pending`: the
+    PendingFetch to wait for; `finish()` -> (maps {1, 2, 4, 8: CoordMap}, rows per frame, bounding box, representative points
+    f32 [rows, 3], first-point indices int64 [rows], zeroed pair-list counters) as views of the arena, or None when the
+    compact table turned out too small (more distinct voxels than a quarter of the points: the caller goes through the
+    tensor-by-tensor path)."""
+
+    def __init__(self, clouds, voxel_size):
+        lib = _lib_()
+        ptrs, offs, keep = _frame_table(clouds)
+        self.nseg, self.n_points = len(clouds), int(offs[len(clouds)])
+        sb = int(lib.apr_voxel_pyramid_scratch_bytes(self.n_points, self.nseg))
+        if sb == 0:
+            raise _lib.AprHipError(f"voxel_pyramid: 1 .. {MAX_FRAMES} non-empty frames")
+        self.arena = torch.empty(sb, dtype=torch.uint8, device=keep[0].device)
+        self.py = _lib.Pyramid()
+        check(lib.apr_voxel_pyramid(ptrs, offs, self.nseg, float(voxel_size), ptr(self.arena), sb, C.byref(self.py), stream()))
+        self.offsets = [int(o) for o in offs]
+        self.pending = PendingFetch(self._view(self.py.header, self.py.header_ints, torch.int32), self._then, keep=keep)
+
+    def _view(self, p, count, dtype, cols=None):
+        off = p - self.arena.data_ptr()
+        t = self.arena[off:off + count * dtype.itemsize].view(dtype)
+        return t if cols is None else t.view(-1, cols)
+
+    def _then(self, host):
+        py, nseg = self.py, self.nseg
+        if any(int(host[2 * i + 1]) != 0 for i in range(5)):
+            raise _lib.AprHipError("coordinate outside the packed voxel-key range (|xyz| < 2^17 voxels, batch < 1023)")
+        n0 = int(host[0])
+        if py.compact and int(host[8]) > py.compact_rows:
+            return None
+        maps = {}
+        for l in range(4):
+            lv, m = py.lv[l], CoordMap()
+            m.n, m.cap, m.n_in = int(host[2 * l]), int(lv.cap), int(lv.n)
+            m.coords = self._view(lv.coords, m.n * 4, torch.int32, 4)
+            m.keys, m.vals = self._view(lv.keys, m.cap, torch.int64), self._view(lv.vals, m.cap, torch.int32)
+            m.n_dev = m.status = None
+            m.first = None
+            maps[1 << l] = m
+        maps[1].first = first = self._view(py.first, n0, torch.int64)
+        counts = [int(c) for c in host[10:10 + nseg]]
+        bbox = [int(v) for v in host[10 + nseg:18 + nseg]]
+        pts = self._view(py.pts, n0 * 3, torch.float32, 3)
+        counters = self._view(py.counters, py.n_counter_slots * pair_counter_ints(), torch.int32, pair_counter_ints())
+        return maps, counts, bbox, pts, first, counters
+
+    def finish(self):
+        return self.pending.finish()
+
+
 def pack_i32(parts, zero=None):
     """Small int32 GPU tensors -> one int32 GPU vector (their concatenation), by ONE launch (apr_pack_i32); `zero`: an int32
     GPU tensor cleared by the same launch."""

@@ -345,6 +345,35 @@ size_t apr_resunet_encode_scratch_bytes(const apr_resunet_plan* plan, const apr_
 int apr_resunet_encode(const apr_resunet_plan* plan, const apr_level_map* lv, const int32_t* bbox_host, int32_t* counters,
                        int32_t n_counter_slots, void* scratch, size_t scratch_bytes, float* out, int64_t ldo, void* stream);
 
+/* The front end of a step as ONE call: frames -> voxel coordinates -> the de-duplicated stride-1 map (its rows in first-
+ * occurrence order = frame order, the representative input point of every row, rows per frame, bounding box) -> that map
+ * re-inserted into a table of its own size -> the three coarser maps, chained on device-side row counts -> ONE int32
+ * header with everything the host needs, ready for a single device -> host copy.  Replaces ME.utils.sparse_quantize +
+ * batched_coordinates + the coordinate manager's strided maps (FCGF_APR/lib/complement_data_loader.py:776-812,
+ * FCGF_APR/scripts/test_apr.py:120-131) for a batch of frames; the kernels and their order are those of the tensor-by-
+ * tensor front end (apr_voxelize_frames, apr_map_build x 5, apr_segment_counts, apr_coords_bbox, apr_gather_frame_points,
+ * apr_pack_i32): same bits.  Python needed ~45 allocations and a dozen calls for it, and with one pair per call the GPU
+ * idled between its kernels.
+ *   arena: apr_voxel_pyramid_scratch_bytes(total points, nseg) bytes; every pointer of *out points into it.
+ *   out->lv[l]: level l's map; lv[l].n = rows ALLOCATED (the true count is in the header).  out->header (device):
+ *   int32 {n, status} x 5 maps (levels 0..3, then the de-duplicating table when compact != 0, else zeros), rows per frame
+ *   [nseg], bounding box [8]; header_ints of them.  status != 0: a coordinate outside the packed key range.
+ *   compact != 0: level 0 is the compact table over the first compact_rows rows of the de-duplicated map; if the header
+ *   says the de-duplicated map has MORE rows than that (more than a quarter of the points are distinct voxels: never on
+ *   LiDAR input) the caller must rebuild through the tensor-by-tensor path.
+ *   out->counters: apr_pairlist_counter_ints() x 16 int32, zeroed (for apr_resunet_encode). */
+typedef struct apr_pyramid {
+  apr_level_map lv[4];
+  const int64_t* first;           /* [rows allocated] index of the first input point of every level-0 row */
+  const float* pts;               /* [rows allocated, 3] that point */
+  int32_t* header; int32_t header_ints;
+  int32_t compact; int64_t compact_rows;
+  int32_t* counters; int32_t n_counter_slots;
+} apr_pyramid;
+size_t apr_voxel_pyramid_scratch_bytes(int64_t n_points, int32_t nseg);
+int apr_voxel_pyramid(const float* const* frames_host, const int64_t* offsets_host, int32_t nseg, float voxel_size,
+                      void* arena, size_t arena_bytes, apr_pyramid* out, void* stream);
+
 /* ------------------------------------------------------------------------
  * Normalisation / elementwise on feature rows [n, c]
  * ---------------------------------------------------------------------- */

@@ -111,7 +111,7 @@ def test_negative_coordinates_floor(dev):
         assert np.array_equal(cm.get_map(ts).coords.cpu().numpy(), ocm.get_coords(ts))
 
 
-def test_batched_dedup_map_compaction_and_fallback(dev):
+def test_batched_dedup_map_compaction_and_fallback(dev, monkeypatch):
     """PairRegistration.voxelize_batch builds ONE hash over all raw points and re-inserts the unique voxels into a
     table sized by a guess (rows / 4).  Dense scans take that compact table; a sparse cloud (every point its own voxel)
     exceeds the guess and must fall back to the big table — either way coordinates, sizes and kernel maps equal the
@@ -123,11 +123,16 @@ def test_batched_dedup_map_compaction_and_fallback(dev):
     sparse = [rng.uniform(-200, 200, (160000, 3)).astype(np.float32) for _ in range(2)]      # ~1 point per voxel
     dense = [np.repeat(rng.uniform(-40, 40, (20000, 3)), 9, axis=0).astype(np.float32) +      # 9 points per voxel
              rng.uniform(0, 0.01, (180000, 3)).astype(np.float32) for _ in range(2)]
-    for clouds, expect_fallback in ((sparse, True), (dense, False)):
+    from apr_amd.fcgf import pipeline as P
+    for clouds, expect_fallback, one_call in ((sparse, True, False), (dense, False, False), (sparse, True, True), (dense, False, True)):
         pipe = PairRegistration(torch.nn.Identity(), 0.3)
         tc = [torch.from_numpy(c).to(dev) for c in clouds]
+        monkeypatch.setattr(P, "FRONT_END_CALL", one_call)     # the front end through ONE library call / tensor by tensor
         cm, counts, first, poffs, _ = pipe.voxelize_batch(tc)
-        assert (cm._dedup is None) == expect_fallback
+        if one_call:
+            assert (ops.VoxelPyramid(tc, 0.3).finish() is None) == expect_fallback
+        else:
+            assert (cm._dedup is None) == expect_fallback
         # reference: per-frame quantisation, then a plain coordinate manager
         rows = []
         for b, c in enumerate(tc):
@@ -188,3 +193,42 @@ def test_transposed_tables_from_one_prefilled_pool(dev):
         probe = ops.kernel_map(cm.get_map(ts), cm.get_map(2 * ts), 3, -ts)
         assert torch.equal(got, probe)
     assert cm._tpool == {}                      # every table handed out exactly once
+
+
+def test_one_call_front_end_equals_the_tensor_by_tensor_front_end(dev, monkeypatch):
+    """apr_voxel_pyramid (frames -> de-duplicated map -> compact table -> coarser maps, one call over one arena) against
+    PairRegistration's tensor-by-tensor front end: the same rows in the same order on every level, the same kernel maps,
+    rows per frame, bounding box, representative points; small frames (no compact table), full frames (compact table),
+    ragged / one frame, and a batch with more distinct voxels than a quarter of its points (the compact table is too small:
+    the call reports it and the pipeline falls back)."""
+    from apr_amd.fcgf import pipeline as P
+    from apr_amd.fcgf.pipeline import PairRegistration
+    pipe = PairRegistration(torch.nn.Identity(), voxel_size=0.3)
+    rng = np.random.default_rng(11)
+    cases = [[torch.from_numpy(synth.make_small_frame(s)).to(dev) for s in (0, 1)],
+             [torch.from_numpy(synth.make_frame(s)).to(dev) for s in (0, 1, 2)],
+             [torch.from_numpy((rng.standard_normal((n, 3)) * 20).astype(np.float32)).to(dev) for n in (5000, 1, 7321, 256)],
+             [torch.from_numpy(synth.make_frame(3)).to(dev)]]
+    for clouds in cases:
+        monkeypatch.setattr(P, "FRONT_END_CALL", False)
+        cm0, counts0, first0, offs0, pts0 = pipe.voxelize_batch(clouds)
+        monkeypatch.setattr(P, "FRONT_END_CALL", True)
+        vp = ops.VoxelPyramid(clouds, 0.3)
+        assert vp.finish() is not None                                  # the one-call path was taken
+        cm1, counts1, first1, offs1, pts1 = pipe.voxelize_batch(clouds)
+        assert counts0 == counts1 and offs0 == offs1 and cm0.get_bbox() == cm1.get_bbox()
+        assert torch.equal(first0, first1) and torch.equal(pts0, pts1)
+        for ts in (1, 2, 4, 8):
+            assert cm0.size(ts) == cm1.size(ts) and torch.equal(cm0.get_map(ts).coords, cm1.get_map(ts).coords)
+        for key in ((1, 1, 3, False), (1, 2, 3, False), (2, 2, 3, False), (4, 8, 3, False), (8, 4, 3, True)):
+            assert torch.equal(cm0.kernel_map(*key), cm1.kernel_map(*key)), key
+        assert int(cm1._plist_counters.abs().sum()) == 0
+    # scattered points: (almost) every point its own voxel -> the quarter-size compact table cannot hold them
+    sparse = [torch.from_numpy((rng.uniform(-400, 400, (150000, 3))).astype(np.float32)).to(dev) for _ in range(2)]
+    assert ops.VoxelPyramid(sparse, 0.3).finish() is None
+    cm1, counts1, first1, offs1, pts1 = pipe.voxelize_batch(sparse)
+    monkeypatch.setattr(P, "FRONT_END_CALL", False)
+    cm0, counts0, first0, offs0, pts0 = pipe.voxelize_batch(sparse)
+    assert counts0 == counts1 and sum(counts1) > 290000 and torch.equal(pts0, pts1)
+    for ts in (1, 2, 4, 8):
+        assert torch.equal(cm0.get_map(ts).coords, cm1.get_map(ts).coords)
