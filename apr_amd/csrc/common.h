@@ -43,6 +43,9 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int apr_internal_nn_brute(const float* f0, int64_t n0, const float* f1, int64_t n1, int32_t c, uint64_t* best,
                           const unsigned* run_if, void* stream);
 
+// hash.hip: memset as a kernel of the library's own (APR_FILL_KERNEL=0: hipMemsetAsync)
+int apr_internal_fill(void* ptr, int32_t byte_value, size_t bytes, hipStream_t st);
+
 // dense.hip: [M, cin] x [cin, cout] with the sparse conv's epilogue (identity kernel map); _ok = shape is supported
 bool apr_internal_dense_ok(int64_t M, int32_t cin, int32_t cout);
 int apr_internal_dense_gemm(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const float* wp,

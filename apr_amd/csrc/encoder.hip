@@ -410,7 +410,8 @@ int front_walk(Front& f, const float* const* frames, const int64_t* offs, int32_
 
   int rc;
   // the header and the pair-list counters behind it (adjacent in the arena) cleared by one small launch (k_pack_i32's
-  // zero leg; a hipMemsetAsync here cost the three-steps-in-flight loop 1.7 %)
+  // zero leg).  A first version -- hipMemsetAsync here and a scratch of its own for each of the five builds -- cost the
+  // three-steps-in-flight loop 1.7 %; the fill alone turned out neutral later, so it was the larger footprint
   const size_t clear = (size_t)((char*)counters - (char*)hdr) + (size_t)16 * apr_pairlist_counter_ints() * 4;
   if ((rc = apr_pack_i32(nullptr, nullptr, 0, nullptr, hdr, (int64_t)(clear / 4), st)) != APR_OK) return rc;
   if ((rc = apr_voxelize_frames(frames, offs, nseg, vs, raw, offs_dev, st)) != APR_OK) return rc;

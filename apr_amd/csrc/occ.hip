@@ -296,7 +296,7 @@ APR_API int apr_occ_conv(const int32_t* coords, int64_t n, const int32_t* bbox_h
   APR_CHECK_ARG(scratch_bytes >= (size_t)L.words * 4 + 256, "apr_occ_conv: scratch too small");
   hipStream_t st = (hipStream_t)stream;
   unsigned* bm = (unsigned*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-  APR_HIP(hipMemsetAsync(bm, 0, (size_t)L.words * 4, st));
+  if (int rcf = apr_internal_fill(bm, 0, (size_t)L.words * 4, st)) return rcf;
   hipLaunchKernelGGL(k_occ_set, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (const int4*)coords, (int)n, L.g,
                      kernel_size / 2, bm);
   const dim3 grid((unsigned)cdiv64(n, 64));
