@@ -65,8 +65,24 @@ class Pyramid(C.Structure):
                 ("counters", C.c_void_p), ("n_counter_slots", C.c_int32)]
 
 
+class GcnLayer(C.Structure):
+    """struct apr_gcn_layer (include/apr_hip.h)."""
+    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("heads", C.c_int32),
+                ("eps1", C.c_float), ("eps2", C.c_float), ("eps3", C.c_float),
+                ("w1", C.c_void_p), ("w2", C.c_void_p), ("w3", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p),
+                ("wq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p), ("wm", C.c_void_p),
+                ("bq", C.c_void_p), ("bk", C.c_void_p), ("bv", C.c_void_p), ("bm", C.c_void_p)]
+
+
+class GcnDesc(C.Structure):
+    """struct apr_gcn_desc (include/apr_hip.h)."""
+    _fields_ = [("n_layers", C.c_int32), ("c", C.c_int32), ("layer", GcnLayer * 8)]
+
+
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
 PROTOTYPES = {
+    "apr_gcn_scratch_bytes": (_sz, [_p, _i32, _i32]),
+    "apr_gcn_forward": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _sz, _p]),
     "apr_voxel_pyramid_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_voxel_pyramid": (C.c_int, [_p, _p, _i32, _f32, _p, _sz, _p, _p]),
     "apr_resunet_encode_supported": (C.c_int, [_p, _p, _p]),

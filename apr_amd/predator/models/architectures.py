@@ -201,24 +201,26 @@ class KPFCNN(nn.Module):
         npairs = len(lens_c) // 2
         side = _side_streams(pcd_c.device, npairs) if (npairs > 1 and not grad) else None
         main = torch.cuda.current_stream() if side else None
+        # inference: every pair's two results land in their rows of ONE buffer (allocated on the caller's stream, which joins
+        # the side streams below before anything reads it): no concatenation
+        gnn_out = None if grad else torch.empty_like(unconditioned_feats)
         for pi, p in enumerate(range(0, len(lens_c), 2)):
             a, b = row0 + lens_c[p], row0 + lens_c[p] + lens_c[p + 1]
+            outs = {} if grad else {"out0": gnn_out[row0:a], "out1": gnn_out[a:b]}
             if side:
                 side[pi].wait_stream(main)
                 with torch.cuda.stream(side[pi]):
                     src_feats_c, tgt_feats_c = self.gnn(pcd_c[row0:a].contiguous(), pcd_c[a:b].contiguous(),
-                                                        unconditioned_feats[row0:a], unconditioned_feats[a:b])
-                src_feats_c.record_stream(main)
-                tgt_feats_c.record_stream(main)
+                                                        unconditioned_feats[row0:a], unconditioned_feats[a:b], **outs)
             else:
                 src_feats_c, tgt_feats_c = self.gnn(pcd_c[row0:a].contiguous(), pcd_c[a:b].contiguous(),
-                                                    unconditioned_feats[row0:a], unconditioned_feats[a:b])
+                                                    unconditioned_feats[row0:a], unconditioned_feats[a:b], **outs)
             gnn_rows += [src_feats_c, tgt_feats_c]
             row0 = b
         if side:
             for st in side[:npairs]:
                 main.wait_stream(st)
-        feats_c = conv1x1(torch.cat(gnn_rows, dim=0), self.proj_gnn, self._c[1])
+        feats_c = conv1x1(torch.cat(gnn_rows, dim=0) if grad else gnn_out, self.proj_gnn, self._c[1])
         scores_c_raw = conv1x1(feats_c, self.proj_score, self._c[2])          # [N_c, 1]
         feats_gnn_norm = (torch.nn.functional.normalize(feats_c, p=2, dim=1) if grad else ops.l2_normalize(feats_c))
         feats_gnn_raw = feats_c

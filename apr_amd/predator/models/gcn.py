@@ -11,8 +11,13 @@ from copy import deepcopy
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import kp_ops, point_ops
 from .blocks import _param_key
+
+# the overlap-attention module of a pair through ONE library call (apr_gcn_forward); 0: layer by layer (A/B switch)
+GCN_CALL = os.environ.get("APR_GCN_CALL", "1") != "0"
 
 
 class _Packed:
@@ -164,8 +169,87 @@ class GCN(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.names = layer_names
 
-    def forward(self, coords0, coords1, desc0, desc1):
-        """coords [N,3], desc [N,C] (row-major) -> updated descriptors."""
+    def _desc(self):
+        """The module as an apr_gcn_desc (packed weights, biases, eps), or None when a layer is outside the one-call form
+        (channels not a multiple of 64, heads of another width than 64, split weights switched off); rebuilt when a
+        parameter changes."""
+        from ... import _lib
+        params = getattr(self, "_desc_params", None)
+        if params is None:
+            params = self._desc_params = list(self.parameters())
+        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params), kp_ops.DENSE_BF3, kp_ops.MHA_MFMA)
+        if getattr(self, "_desc_key", None) == key:
+            return self._desc_val
+        d, keep, ok = _lib.GcnDesc(), [], kp_ops.DENSE_BF3 and kp_ops.MHA_MFMA and len(self.layers) <= 8
+        d.n_layers = len(self.layers)
+
+        def w3(conv, cache, heads=None):
+            wp = cache.get(conv) if heads is None else cache.get(conv, heads)
+            info, bias = (wp, None if conv.bias is None else conv.bias.detach()) if heads is None else wp
+            keep.extend([info, bias])
+            split = info[5]
+            return (split.data_ptr() if split is not None else None), (bias.data_ptr() if bias is not None else None)
+
+        for i, (layer, name) in enumerate(zip(self.layers, self.names)):
+            if not ok:
+                break
+            L = d.layer[i]
+            if name == 'self':
+                c = layer.conv1.weight.shape[0]
+                L.kind, L.k = 0, int(layer.k)
+                L.eps1, L.eps2, L.eps3 = layer.in1.eps, layer.in2.eps, layer.in3.eps
+                (L.w1, _), (L.w2, _), (L.w3, _) = (w3(cv, ch) for cv, ch in zip((layer.conv1, layer.conv2, layer.conv3), layer._c))
+                ok = ok and None not in (L.w1, L.w2, L.w3) and layer.k + 1 <= 16
+            else:
+                at = layer.attn
+                c = at.merge.weight.shape[0]
+                L.kind, L.heads, L.eps1 = 1, int(at.num_heads), layer.mlp[1].eps
+                (L.wq, L.bq), (L.wk, L.bk), (L.wv, L.bv) = (w3(cv, ch, at.num_heads) for cv, ch in zip(at.proj, at._hm))
+                L.wm, L.bm = w3(at.merge, at._c[3])
+                (L.w1, L.b1), (L.w2, L.b2) = w3(layer.mlp[0], layer._c[0]), w3(layer.mlp[3], layer._c[1])
+                ok = ok and None not in (L.wq, L.wk, L.wv, L.wm, L.w1, L.w2) and at.dim == 64
+            d.c = c
+            ok = ok and c % 64 == 0
+        self._desc_val, self._desc_keep, self._desc_key = (d if ok else None), keep, key
+        return self._desc_val
+
+    def _forward_call(self, coords0, coords1, desc0, desc1, out0, out1):
+        """The module through apr_gcn_forward (one library call per pair), or None when not covered."""
+        import ctypes as C
+        from ... import _lib
+        d = self._desc()
+        n0, n1 = desc0.shape[0], desc1.shape[0]
+        if d is None or any(t.stride(0) % 4 or t.data_ptr() % 16 or t.stride(1) != 1 for t in (desc0, desc1)):
+            return None
+        lib = _lib.load()
+        sb = int(lib.apr_gcn_scratch_bytes(C.byref(d), n0, n1))
+        if sb == 0:
+            return None
+        dev = desc0.device
+        if out0 is None:
+            out0 = torch.empty((n0, d.c), dtype=torch.float32, device=dev)
+        if out1 is None:
+            out1 = torch.empty((n1, d.c), dtype=torch.float32, device=dev)
+        scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+        p0, p1 = (point_ops._pts(p, "gcn.coords") for p in (coords0, coords1))
+        kp_ops.check(lib.apr_gcn_forward(C.byref(d), kp_ops.ptr(p0), n0, kp_ops.ptr(p1), n1, kp_ops.ptr(desc0), desc0.stride(0),
+                                         kp_ops.ptr(desc1), desc1.stride(0), kp_ops.ptr(out0), out0.stride(0), kp_ops.ptr(out1),
+                                         out1.stride(0), kp_ops.ptr(scratch), sb, kp_ops.stream()))
+        return out0, out1
+
+    def forward(self, coords0, coords1, desc0, desc1, out0=None, out1=None):
+        """coords [N,3], desc [N,C] (row-major) -> updated descriptors (written into out0 / out1 when given)."""
+        if GCN_CALL and not kp_ops.tracking(desc0, desc1, *self.parameters()):
+            done = self._forward_call(coords0, coords1, desc0, desc1, out0, out1)
+            if done is not None:
+                return done
+        res = self._forward_layers(coords0, coords1, desc0, desc1)
+        if out0 is not None:
+            out0.copy_(res[0]); out1.copy_(res[1])
+            return out0, out1
+        return res
+
+    def _forward_layers(self, coords0, coords1, desc0, desc1):
         for layer, name in zip(self.layers, self.names):
             if name == 'cross':
                 if kp_ops.tracking(desc0, desc1, *layer.parameters()):

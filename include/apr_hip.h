@@ -716,6 +716,34 @@ int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m
 int apr_mha_headmajor(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim,
                       int32_t heads, float* out, void* stream);
 
+/* The overlap-attention module of one scan pair (GCN.forward, Predator_APR/models/gcn.py:171-205: 'self' = SelfAttention
+ * :38-77 on each cloud, 'cross' = AttentionalPropagation :119-128 in both directions with the residual add) as ONE call.
+ * The module issued 62 library calls and 6 concatenations per pair on ~1.4 k points -- the largest share of the 110 calls
+ * per pair that kept KPFCNN's scheduler thread, not the GPU, at its limit.  Same kernels, arguments and order as the
+ * modules' own (apr_knn, apr_edge_features, apr_dense_gemm_bf3, apr_norm_params, apr_group_max, apr_instance_norm_act,
+ * apr_mha_headmajor, apr_affine_act): same bits; the concatenations become column slices of one buffer.
+ *   c % 64 == 0, c / heads == 64, k + 1 <= 16; weights: apr_spconv_pack_weights_bf3(K = 1) images ([cin, cout] as the
+ *   layers' own Linear / Conv1d weights transposed; wq / wk / wv with their output channels head-major, as
+ *   apr_mha_headmajor reads them); biases f32, 16-byte aligned, nullable.  x0 [n0, c] / x1 [n1, c] in, out0 / out1 out. */
+#define APR_GCN_MAX_LAYERS 8
+typedef struct apr_gcn_layer {
+  int32_t kind;                   /* 0: self attention, 1: cross attention */
+  int32_t k, heads;               /* self: neighbours of the kNN graph; cross: attention heads */
+  float eps1, eps2, eps3;         /* self: InstanceNorm eps of in1 / in2 / in3; cross: eps1 = mlp[1].eps */
+  const void *w1, *w2, *w3;       /* self: conv1 [2c, c], conv2 [2c, 2c], conv3 [4c, c]; cross: w1 = mlp[0] [2c, 2c], w2 = mlp[3] [2c, c] */
+  const float *b1, *b2;           /* cross: biases of mlp[0], mlp[3] */
+  const void *wq, *wk, *wv, *wm;  /* cross: the three projections (head-major) and merge, [c, c] */
+  const float *bq, *bk, *bv, *bm;
+} apr_gcn_layer;
+typedef struct apr_gcn_desc {
+  int32_t n_layers, c;
+  apr_gcn_layer layer[APR_GCN_MAX_LAYERS];
+} apr_gcn_desc;
+size_t apr_gcn_scratch_bytes(const apr_gcn_desc* d, int32_t n0, int32_t n1);
+int apr_gcn_forward(const apr_gcn_desc* d, const float* pts0, int32_t n0, const float* pts1, int32_t n1, const float* x0,
+                    int64_t ldx0, const float* x1, int64_t ldx1, float* out0, int64_t ldo0, float* out1, int64_t ldo1,
+                    void* scratch, size_t scratch_bytes, void* stream);
+
 /* out[i] = sum_j softmax_j(<a_i, b_j> / temperature) * w[j]  (cross saliency, architectures.py:176-181). */
 int apr_softmax_matvec(const float* a, const float* b, const float* w, int32_t n, int32_t m, int32_t c,
                        float temperature, float* out, void* stream);

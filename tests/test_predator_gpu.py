@@ -469,3 +469,42 @@ def test_pool_training_function_gradients(dev, mode, ns, nq, H, c):
     xg.grad = None
     (kp_ops.pool_train(xg, inds.to(dev), mode) * proj.to(dev)).sum().backward()
     assert torch.equal(xg.grad, g1)
+
+
+@pytest.mark.parametrize("n0,n1,c,heads,k,names", [(300, 417, 256, 4, 10, ['self', 'cross', 'self']), (1400, 1311, 256, 4, 10, ['self', 'cross', 'self']),
+                                                    (90, 77, 128, 2, 6, ['cross', 'self']), (515, 64, 64, 1, 15, ['self'])])
+def test_gcn_one_call_equals_the_layer_by_layer_module(dev, n0, n1, c, heads, k, names, monkeypatch):
+    """apr_gcn_forward (the overlap-attention module of a pair as one library call over one arena, concatenations as column
+    slices) == the Python modules issuing the same kernels one by one: bit for bit; results into caller-provided row slices;
+    a width outside the one-call form (c = 96) falls back to the modules."""
+    from apr_amd.predator.models import gcn as G
+    torch.manual_seed(n0 + c)
+    net = G.GCN(heads, c, k, names).to(dev).eval()
+    with torch.no_grad():
+        for m in net.modules():                      # the biases start at zero in the reference's init: make them count
+            if getattr(m, "bias", None) is not None:
+                m.bias.uniform_(-0.3, 0.3)
+    p0, p1 = torch.randn(n0, 3, device=dev) * 5, torch.randn(n1, 3, device=dev) * 5
+    wide = torch.randn(n0 + n1, c, device=dev)
+    x0, x1 = wide[:n0], wide[n0:]
+    with torch.no_grad():
+        monkeypatch.setattr(G, "GCN_CALL", False)
+        r0, r1 = net(p0, p1, x0, x1)
+        monkeypatch.setattr(G, "GCN_CALL", True)
+        assert net._desc() is not None
+        g0, g1 = net(p0, p1, x0, x1)
+        assert torch.equal(g0, r0) and torch.equal(g1, r1)
+        buf = torch.full((n0 + n1 + 2, c), 7.0, device=dev)
+        o0, o1 = net(p0, p1, x0, x1, out0=buf[1:1 + n0], out1=buf[1 + n0:1 + n0 + n1])
+        assert torch.equal(buf[1:1 + n0], r0) and torch.equal(buf[1 + n0:1 + n0 + n1], r1)
+        assert bool((buf[0] == 7.0).all()) and bool((buf[-1] == 7.0).all())
+        net.layers[0].conv1.weight.mul_(1.5) if names[0] == 'self' else net.layers[0].mlp[0].weight.mul_(1.5)   # the packed images follow the parameters
+        monkeypatch.setattr(G, "GCN_CALL", False)
+        r0, r1 = net(p0, p1, x0, x1)
+        monkeypatch.setattr(G, "GCN_CALL", True)
+        g0, g1 = net(p0, p1, x0, x1)
+        assert torch.equal(g0, r0) and torch.equal(g1, r1)
+        odd = G.GCN(3, 96, 8, ['self', 'cross']).to(dev).eval()
+        assert odd._desc() is None
+        y0, y1 = odd(p0, p1, torch.randn(n0, 96, device=dev), torch.randn(n1, 96, device=dev))
+        assert y0.shape == (n0, 96) and bool(torch.isfinite(y1).all())
