@@ -20,6 +20,8 @@ pairs += [("selflaunch_gloo2.json", f"{prefix}_selflaunch_gloo2.json"),
           ("host_cpu_split_sync.log", f"{prefix}_host_cpu_split_sync.log"),
           ("match_stats/m_kernel_stats.csv", f"{prefix}_matching_0_30pct_kernel_stats.csv"),
           ("match_load.log", f"{prefix}_matching_0_30pct.log")]
+pairs += [("one_pair_split.log", f"{prefix}_one_pair_split.log"),
+          ("one_pair_split_python_plan.log", f"{prefix}_one_pair_split_python_plan.log")]
 pairs += [(f"driver_cmd_{i}.json", f"{prefix}_driver_cmd_{i}.json") for i in (1, 2, 3)]
 pairs += [(f"driver_cmd_{i}.log", f"{prefix}_driver_cmd_{i}.log") for i in (1, 2, 3)]
 for a, b in pairs:

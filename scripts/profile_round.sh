@@ -25,6 +25,9 @@ APR_BENCH_BACKEND=gloo APR_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 2 --
 echo "[profile] host CPU of a rank: where the three worker threads spend their time"
 python3 $R/scripts/host_cpu_split.py 150 > $OUT/host_cpu_split_poll.log 2>&1 </dev/null || { echo "host split failed"; exit 1; }
 APR_FETCH_WAIT=sync python3 $R/scripts/host_cpu_split.py 150 > $OUT/host_cpu_split_sync.log 2>&1 </dev/null || { echo "host split (sync) failed"; exit 1; }
+echo "[profile] one pair per call: host time between the fetches against time blocked on the GPU"
+python3 $R/scripts/one_pair_split.py > $OUT/one_pair_split.log 2>&1 </dev/null || { echo "one pair split failed"; exit 1; }
+APR_ENCODE_PLAN=0 APR_FRONT_END_CALL=0 python3 $R/scripts/one_pair_split.py > $OUT/one_pair_split_python_plan.log 2>&1 </dev/null || { echo "one pair split (python plan) failed"; exit 1; }
 echo "[profile] matching at 0 / 30 % true matches under rocprof (the regime a trained checkpoint puts the matcher in)"
 SHARES=0.0,0.3 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/match_stats -o m -- python3 $R/scripts/match_load_bench.py > $OUT/match_load.log 2>&1 </dev/null || { echo "match stats failed"; exit 1; }
 echo "[profile] rocprof stats, default run"
