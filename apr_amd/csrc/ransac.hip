@@ -583,27 +583,170 @@ __global__ void k_score_finish(Hyp* __restrict__ hyps, const int* __restrict__ s
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ inline int count_parts(int nblk, int nwords) {
+// ---------------------------------------------------------------------------------------------------------------
+// Pruning the correspondences of the count (round 4).  With trained descriptors the survivors are 4-inlier samples: tens
+// of thousands of transforms within a few metres of each other, each counted over ALL correspondences -- of which the
+// outliers (70 % at a 30 % match share) are tens of metres away under every one of them.  Take a reference T_ref (the
+// first survivor) and the residual r_c = |T_ref s_c - t_c| of every correspondence.  For a hypothesis h,
+//     | |T_h s - t| - |T_ref s - t| | <= |T_h s - T_ref s| <= ||R_h - R_ref||_F |s| + |t_h - t_ref| <= delta_h
+// with delta_h := ||R_h - R_ref||_F * max|s| + |t_h - t_ref|.  So if delta_h <= D, a correspondence with r_c >= m + D is
+// at distance >= m from its target under T_h: not an inlier (inliers need < m).  k_live keeps the correspondences with
+// r_c < m + D (in order) as a second record set; k_near sorts the survivors into NEAR (delta_h <= D: counted over the kept
+// records only) and FAR (counted over all, as before -- also everything when T_ref is a poor draw: only speed is lost).
+// fp64 throughout, D compared with 1e-6 m to spare; counts, picks and errors are those of the full evaluation, bit for bit
+// (tests/test_match_pose_gpu.py).  APR_RANSAC_PRUNE=0: every survivor is FAR.
+// ---------------------------------------------------------------------------------------------------------------
+enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveInts = 8 };
+constexpr double kPruneReach = 10.0;      // D, metres
+
+__global__ __launch_bounds__(1024) void k_live(const float4* __restrict__ rec, int64_t n0, double m_up,
+                                               const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int few,
+                                               float4* __restrict__ rec_live, float* __restrict__ rec2_live,
+                                               int* __restrict__ live) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int nv = min(*n_valid, cap);
+  if (nv <= few) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Hyp* hp = hyps;      // T_ref: the first survivor
+  const double T0 = hp->T[0], T1 = hp->T[1], T2 = hp->T[2], T3 = hp->T[3], T4 = hp->T[4], T5 = hp->T[5];
+  const double T6 = hp->T[6], T7 = hp->T[7], T8 = hp->T[8], T9 = hp->T[9], T10 = hp->T[10], T11 = hp->T[11];
+  const double reach = m_up + kPruneReach, reach2 = reach * reach;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < n0; c0 += 1024) {
+    const int64_t i = c0 + threadIdx.x;
+    bool keep = false;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (i < n0) {
+      a = rec[2 * i];
+      b = rec[2 * i + 1];
+      const double sx = a.x, sy = a.y, sz = a.z;
+      const double dx = T0 * sx + T1 * sy + T2 * sz + T3 - (double)b.x;
+      const double dy = T4 * sx + T5 * sy + T6 * sz + T7 - (double)b.y;
+      const double dz = T8 * sx + T9 * sy + T10 * sz + T11 - (double)b.z;
+      keep = !(dx * dx + dy * dy + dz * dz >= reach2);      // NaN stays (it is nobody's inlier either way; never dropped on a maybe)
+    }
+    const unsigned long long mk = __ballot(keep);
+    if (lane == 0) s_wave[wave] = __popcll(mk);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    int all = 0;
+    for (int w = 0; w < 16; ++w) all += s_wave[w];
+    if (keep) {
+      const int pos = before + __popcll(mk & ((1ull << lane) - 1ull));
+      rec_live[2 * (int64_t)pos] = a;
+      rec_live[2 * (int64_t)pos + 1] = b;
+      float* row = rec2_live + (int64_t)(pos >> 1) * 12 + (pos & 1);
+      row[0] = a.x; row[2] = a.y; row[4] = a.z; row[6] = b.x; row[8] = b.y; row[10] = b.z;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += all;
+    __syncthreads();
+  }
+  const int n_live = s_base;
+  const int64_t slots = 2 * rec2_rows(n_live);      // pad the last mini-chunk with a correspondence nothing reaches
+  for (int64_t pos = n_live + threadIdx.x; pos < slots; pos += 1024) {
+    float* row = rec2_live + (pos >> 1) * 12 + (pos & 1);
+    row[0] = 0.f; row[2] = 0.f; row[4] = 0.f; row[6] = 3e18f; row[8] = 3e18f; row[10] = 3e18f;
+  }
+  if (threadIdx.x == 0) {
+    const int nmini = (int)(rec2_rows(n_live) / kMini);
+    live[kLiveCount] = n_live;
+    live[kLiveMini] = nmini;
+    live[kLiveWords] = (nmini + 31) / 32;
+    live[kLiveNear] = 0;
+    live[kLiveFar] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_near(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int few,
+                                              const unsigned* __restrict__ maxn2, int prune, int* __restrict__ order_near,
+                                              int* __restrict__ order_far, unsigned char* __restrict__ near_flag,
+                                              int* __restrict__ live, unsigned* __restrict__ band, int nwords) {
+  const int nv = min(*n_valid, cap);
+  if (nv <= few) return;
+  const int lane = threadIdx.x & 63;
+  const double Mn = sqrt((double)__uint_as_float(*maxn2)) * (1.0 + 1e-6);
+  const Hyp* r = hyps;
+  const int nround = (nv + 255) & ~255;
+  for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nround; h += gridDim.x * blockDim.x) {
+    bool nr = false;
+    if (h < nv && prune) {
+      const Hyp* p = hyps + h;
+      double f2 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const double d = p->T[4 * a + b] - r->T[4 * a + b];
+          f2 += d * d;
+        }
+        const double dt = p->T[4 * a + 3] - r->T[4 * a + 3];
+        t2 += dt * dt;
+      }
+      const double delta = (sqrt(f2) * Mn + sqrt(t2)) * (1.0 + 1e-9) + 1e-6;
+      nr = delta <= kPruneReach;      // NaN: far
+    }
+    const bool fr = h < nv && !nr;
+    if (h < nv) {
+      near_flag[h] = nr ? 1 : 0;
+      for (int w = 0; w < nwords; ++w) band[(int64_t)h * nwords + w] = 0u;
+    }
+    const unsigned long long mn = __ballot(nr), mf = __ballot(fr);
+    int bn = 0, bf = 0;
+    if (lane == 0) {
+      if (mn) bn = atomicAdd(live + kLiveNear, __popcll(mn));
+      if (mf) bf = atomicAdd(live + kLiveFar, __popcll(mf));
+    }
+    bn = __shfl(bn, 0);
+    bf = __shfl(bf, 0);
+    if (nr) order_near[bn + __popcll(mn & ((1ull << lane) - 1ull))] = h;
+    if (fr) order_far[bf + __popcll(mf & ((1ull << lane) - 1ull))] = h;
+  }
+}
+
+__device__ inline int count_parts(int nblk, int nunits) {      // ranges per 256-hypothesis block: ~4096 items in all
   int S = (4096 + nblk - 1) / nblk;
-  if (S > nwords) S = nwords;
+  if (S > nunits) S = nunits;
   return S < 1 ? 1 : S;
 }
 
+// `order` / `live` (both or neither): the hypotheses order[0 .. live[kLiveNear or kLiveFar]) over the correspondence list
+// whose mini-chunk count is live[kLiveMini] (the pruned list of k_live); band rows keep the FULL stride `nwords` and were
+// cleared by k_near.
 __global__ __launch_bounds__(256) void k_count(const float* __restrict__ rec2, int nwords, int nmini, double thr_lt,
                                                const unsigned* __restrict__ maxn2, Hyp* __restrict__ hyps,
                                                const int* __restrict__ n_valid, int cap, unsigned* __restrict__ band,
-                                               int few) {
-  const int nv = min(*n_valid, cap);
-  if (nv <= few) return;
+                                               int few, const int* __restrict__ order, const int* __restrict__ live,
+                                               int which, int pruned) {
+  const int nv_all = min(*n_valid, cap);
+  if (nv_all <= few) return;
+  const int nv = order ? live[which] : nv_all;
+  if (nv <= 0) return;
+  const int nwords_full = nwords;
+  if (pruned) {
+    nmini = live[kLiveMini];
+    nwords = live[kLiveWords];
+  }
+  // Work items = (256 hypotheses, a contiguous range of MINI-CHUNKS).  A thread walks its range row by row behind scalar
+  // loads: ~115 us per 32 mini-chunks whatever else runs, so the ranges must be short enough that the grid is many waves
+  // per SIMD deep (ranges of whole 32-mini-chunk words left 248 items of 115 us each for the pruned list of a 30 % pair:
+  // no faster than the full list).  The band words were cleared by k_near; a range ORs its bits in.
   const int nblk = (nv + 255) >> 8;
-  const int S = count_parts(nblk, nwords);
+  const int S = count_parts(nblk, nmini > 0 ? nmini : 1);
   const float Mn = sqrtf(__uint_as_float(*maxn2)) * 1.000001f;
   const float thr = (float)thr_lt;
+  (void)nwords;
   for (int item = blockIdx.x; item < nblk * S; item += gridDim.x) {
     const int hb = item / S, part = item - hb * S;
-    const int w_begin = (int)((int64_t)nwords * part / S), w_end = (int)((int64_t)nwords * (part + 1) / S);
-    const int h = hb * 256 + threadIdx.x;
-    const Hyp* hp = hyps + (h < nv ? h : nv - 1);
+    const int m_begin = (int)((int64_t)nmini * part / S), m_stop = (int)((int64_t)nmini * (part + 1) / S);
+    const int w_begin = m_begin >> 5, w_end = (m_stop + 31) >> 5;
+    const int slot = hb * 256 + threadIdx.x;
+    const bool act = slot < nv;
+    const int h = order ? order[act ? slot : nv - 1] : (act ? slot : nv - 1);
+    const Hyp* hp = hyps + h;
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = (float)hp->T[k];
@@ -617,8 +760,8 @@ __global__ __launch_bounds__(256) void k_count(const float* __restrict__ rec2, i
     int total = 0;
     for (int w = w_begin; w < w_end; ++w) {
       unsigned mask = 0;
-      const int m_end = min(32, nmini - w * 32);
-      for (int mc = 0; mc < m_end; ++mc) {
+      const int m_first = max(0, m_begin - w * 32), m_end = min(32, m_stop - w * 32);
+      for (int mc = m_first; mc < m_end; ++mc) {
         const float* __restrict__ row = rec2 + (int64_t)(w * 32 + mc) * (kMini * 12);   // wave-uniform: scalar loads
         int c_lo = 0, c_hi = 0;
 #pragma unroll 4
@@ -642,18 +785,21 @@ __global__ __launch_bounds__(256) void k_count(const float* __restrict__ rec2, i
         if (c_lo == c_hi) total += c_lo;
         else mask |= 1u << mc;
       }
-      if (h < nv) band[(int64_t)h * nwords + w] = mask;
+      if (act && mask) atomicOr(&band[(int64_t)h * nwords_full + w], mask);
     }
-    if (h < nv && total) atomicAdd(&hyps[h].inliers, total);
+    if (act && total) atomicAdd(&hyps[h].inliers, total);
   }
 }
 
 // The flagged cells, exactly: a wave per (hypothesis, mini-chunk), lane = correspondence, the fp64 expression of k_score.
 __global__ __launch_bounds__(256) void k_count_fix(const float4* __restrict__ rec, int64_t n0, double thr_lt,
                                                    Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
-                                                   const unsigned* __restrict__ band, int nwords, int few) {
+                                                   const unsigned* __restrict__ band, int nwords, int few,
+                                                   const float4* __restrict__ rec_live, const int* __restrict__ live,
+                                                   const unsigned char* __restrict__ near_flag) {
   const int nv = min(*n_valid, cap);
   if (nv <= few) return;
+  const int64_t n_live = live ? live[kLiveCount] : 0;
   const int lane = threadIdx.x & 63;
   const int64_t total = (int64_t)nv * nwords;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -668,6 +814,9 @@ __global__ __launch_bounds__(256) void k_count_fix(const float4* __restrict__ re
       const int h = (int)(cell / nwords), w = (int)(cell - (int64_t)h * nwords);
       unsigned bits = __shfl(mask, L);
       const Hyp* hp = hyps + h;
+      const bool nr = near_flag && near_flag[h];      // a pruned-list hypothesis: its cells index the pruned records
+      const float4* __restrict__ R = nr ? rec_live : rec;
+      const int64_t nR = nr ? n_live : n0;
       const double T0 = hp->T[0], T1 = hp->T[1], T2 = hp->T[2], T3 = hp->T[3], T4 = hp->T[4], T5 = hp->T[5];
       const double T6 = hp->T[6], T7 = hp->T[7], T8 = hp->T[8], T9 = hp->T[9], T10 = hp->T[10], T11 = hp->T[11];
       int cnt = 0;
@@ -676,8 +825,8 @@ __global__ __launch_bounds__(256) void k_count_fix(const float4* __restrict__ re
         bits &= bits - 1u;
         const int64_t i = ((int64_t)w * 32 + mc) * 64 + lane;
         bool in = false;
-        if (i < n0) {
-          const float4 a = rec[2 * i], bq = rec[2 * i + 1];
+        if (i < nR) {
+          const float4 a = R[2 * i], bq = R[2 * i + 1];
           const double sx = a.x, sy = a.y, sz = a.z;
           const double dx = T0 * sx + T1 * sy + T2 * sz + T3 - (double)bq.x;
           const double dy = T4 * sx + T5 * sy + T6 * sz + T7 - (double)bq.y;
@@ -1137,6 +1286,11 @@ struct RansacScratch {
   unsigned* band;  // [cap][band_words(n0)] flagged mini-chunks
   SelPart* selp;   // [kSelParts]
   unsigned long long* rec8;   // [n0] quantised correspondences for k_sample_screen
+  float4* rec_live;           // [2 n0] the correspondences k_live kept, both layouts, ...
+  float* rec2_live;
+  int* live;                  // ... their counts and the NEAR / FAR list lengths (kLiveInts)
+  int *order_near, *order_far;      // [cap] each
+  unsigned char* near_flag;   // [cap]
   char* end;
 };
 
@@ -1150,7 +1304,8 @@ static size_t ransac_core_bytes(int64_t n0, int64_t max_iter) {
   return 512 + align256(c1 * sizeof(Hyp)) + align256((size_t)n0 * 32) +
          align256(((size_t)(max_iter < 1 ? 1 : max_iter) + kCandLists * 256) * 8) + align256(kGeoGrid * sizeof(GeoPart)) +
          align256((size_t)rec2_rows(n0) * 48) + 256 + align256(c1 * 4) + align256(c1 * band_words(n0) * 4) +
-         align256(kSelParts * sizeof(SelPart)) + align256((size_t)(n0 + 32) * 8) + 256;
+         align256(kSelParts * sizeof(SelPart)) + align256((size_t)(n0 + 32) * 8) + 256 + align256((size_t)n0 * 32) +
+         align256((size_t)rec2_rows(n0) * 48) + 256 + 2 * align256(c1 * 4) + align256(c1);
 }
 
 static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
@@ -1183,6 +1338,18 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   p += align256(kSelParts * sizeof(SelPart));
   r.rec8 = (unsigned long long*)p;
   p += align256((size_t)(n0 + 32) * 8);
+  r.rec_live = (float4*)p;
+  p += align256((size_t)n0 * 32);
+  r.rec2_live = (float*)p;
+  p += align256((size_t)rec2_rows(n0) * 48);
+  r.live = (int*)p;
+  p += 256;
+  r.order_near = (int*)p;
+  p += align256((size_t)cap * 4);
+  r.order_far = (int*)p;
+  p += align256((size_t)cap * 4);
+  r.near_flag = (unsigned char*)p;
+  p += align256((size_t)cap);
   r.end = p;
   return r;
 }
@@ -1216,10 +1383,19 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
   const int nwords = band_words(n0), nmini = (int)(rec2_rows(n0) / kMini);
   // up to `few` survivors everything is scored in fp64 (APR_RANSAC_COUNT=0, read per call: always -- the A/B and test hook)
   const int few = env_int("APR_RANSAC_COUNT", 1) ? kGeoGrid : 0x7fffffff;
+  // the survivors sorted into NEAR the first one (counted over the correspondences within reach of it) and FAR (over all)
+  const int prune = env_int("APR_RANSAC_PRUNE", 1);      // read per call: A/B and test hook
+  const double m_up = sqrt(thr_lt) * (1.0 + 1e-12);
+  hipLaunchKernelGGL(k_live, dim3(1), dim3(1024), 0, st, r.rec, n0, m_up, r.hyps, r.n_valid, cap, few, r.rec_live, r.rec2_live,
+                     r.live);
+  hipLaunchKernelGGL(k_near, dim3(512), dim3(256), 0, st, r.hyps, r.n_valid, cap, few, r.maxn2, prune, r.order_near, r.order_far,
+                     r.near_flag, r.live, r.band, nwords);
+  hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2_live, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
+                     r.band, few, r.order_near, r.live, (int)kLiveNear, 1);
   hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
-                     r.band, few);
+                     r.band, few, r.order_far, r.live, (int)kLiveFar, 0);
   hipLaunchKernelGGL(k_count_fix, dim3(2048), dim3(256), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, cap, r.band, nwords,
-                     few);
+                     few, r.rec_live, r.live, r.near_flag);
   hipLaunchKernelGGL(k_count_max, dim3(256), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.sel_hdr, few);
   hipLaunchKernelGGL(k_pick, dim3(256), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.sel_hdr, r.sel, few);
   hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.sel_hdr, r.sel, r.part);

@@ -413,6 +413,43 @@ def test_count_path_edge_cases_equal_full_fp64_scoring(dev, n, scale, noise):
     assert i1["inliers"] >= 0.7 * n
 
 
+@pytest.mark.parametrize("n,second_share,spread", [(4000, 0.35, 60.0), (2500, 0.45, 8.0), (900, 0.0, 400.0)])
+def test_count_path_pruning_with_far_hypotheses_equals_full_scoring(dev, n, second_share, spread, monkeypatch):
+    """The count path prunes the correspondences to those within reach of the FIRST surviving hypothesis and counts every
+    survivor NEAR it over the pruned list, the others over all.  Correspondence sets where many survivors are FAR from the
+    first one -- two rigid motions in one set (whichever the first survivor belongs to, the other motion's hypotheses are
+    far), a small cloud with a long lever arm, coordinates 400 m out -- must give the same bits as scoring everything in
+    fp64 and as the unpruned count path (APR_RANSAC_PRUNE=0)."""
+    rng = np.random.default_rng(n)
+    src = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+
+    def motion(ang, t):
+        R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        return src.astype(np.float64) @ R.T + np.asarray(t)
+
+    tgt = motion(0.3, [3.0, -2.0, 0.5])
+    second = rng.random(n) < second_share
+    tgt[second] = motion(-0.2, [-15.0, 9.0, 1.0])[second]
+    tgt = (tgt + rng.normal(0, 0.03, (n, 3))).astype(np.float32)
+    corr = np.arange(n, dtype=np.int64)
+    bad = rng.random(n) < 0.15
+    corr[bad] = rng.integers(0, n, int(bad.sum()))
+    args = (torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), torch.from_numpy(corr).to(dev), 0.3, 0.9, 200000, 5)
+    res = {}
+    for name, env in (("pruned", {}), ("unpruned", {"APR_RANSAC_PRUNE": "0"}), ("fp64", {"APR_RANSAC_COUNT": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res[name] = ops.ransac_pose(*args)
+        for k in env:
+            monkeypatch.delenv(k)
+    T0, i0 = res["fp64"]
+    assert i0["n_valid"] > 2048, i0
+    for name in ("pruned", "unpruned"):
+        T1, i1 = res[name]
+        assert i1 == i0, (name, i1, i0)
+        assert np.array_equal(T1, T0), name
+
+
 def _screen_ab(fn):
     """fn() under APR_RANSAC_SCREEN = 1 (LDS-screened sampling kernel, the default) and 0 (plain kernel)."""
     import os
