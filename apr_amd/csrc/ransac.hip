@@ -599,23 +599,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveInts = 8 };
 constexpr double kPruneReach = 10.0;      // D, metres
 
-__global__ __launch_bounds__(1024) void k_live(const float4* __restrict__ rec, int64_t n0, double m_up,
-                                               const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int few,
-                                               float4* __restrict__ rec_live, float* __restrict__ rec2_live,
-                                               int* __restrict__ live) {
-  __shared__ int s_wave[16];
-  __shared__ int s_base;
+// (the order of the kept records is free: the count is an integer sum, and the squared error of the picked hypotheses is
+// summed over the FULL records by k_score.)  live[kLiveCount] is zero on entry (cleared with the round's counters);
+// k_near finishes the list (padding of the last mini-chunk, mini-chunk / word counts).
+__global__ __launch_bounds__(256) void k_live(const float4* __restrict__ rec, int64_t n0, double m_up,
+                                              const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int few,
+                                              float4* __restrict__ rec_live, float* __restrict__ rec2_live,
+                                              int* __restrict__ live) {
   const int nv = min(*n_valid, cap);
   if (nv <= few) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const Hyp* hp = hyps;      // T_ref: the first survivor
   const double T0 = hp->T[0], T1 = hp->T[1], T2 = hp->T[2], T3 = hp->T[3], T4 = hp->T[4], T5 = hp->T[5];
   const double T6 = hp->T[6], T7 = hp->T[7], T8 = hp->T[8], T9 = hp->T[9], T10 = hp->T[10], T11 = hp->T[11];
   const double reach = m_up + kPruneReach, reach2 = reach * reach;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  for (int64_t c0 = 0; c0 < n0; c0 += 1024) {
-    const int64_t i = c0 + threadIdx.x;
+  const int64_t nround = (n0 + 255) & ~(int64_t)255;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += (int64_t)gridDim.x * blockDim.x) {
     bool keep = false;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (i < n0) {
@@ -625,49 +624,43 @@ __global__ __launch_bounds__(1024) void k_live(const float4* __restrict__ rec, i
       const double dx = T0 * sx + T1 * sy + T2 * sz + T3 - (double)b.x;
       const double dy = T4 * sx + T5 * sy + T6 * sz + T7 - (double)b.y;
       const double dz = T8 * sx + T9 * sy + T10 * sz + T11 - (double)b.z;
-      keep = !(dx * dx + dy * dy + dz * dz >= reach2);      // NaN stays (it is nobody's inlier either way; never dropped on a maybe)
+      keep = !(dx * dx + dy * dy + dz * dz >= reach2);      // NaN stays: never dropped on a maybe
     }
     const unsigned long long mk = __ballot(keep);
-    if (lane == 0) s_wave[wave] = __popcll(mk);
-    __syncthreads();
-    int before = s_base;
-    for (int w = 0; w < wave; ++w) before += s_wave[w];
-    int all = 0;
-    for (int w = 0; w < 16; ++w) all += s_wave[w];
+    int base = 0;
+    if (lane == 0 && mk) base = atomicAdd(live + kLiveCount, __popcll(mk));
+    base = __shfl(base, 0);
     if (keep) {
-      const int pos = before + __popcll(mk & ((1ull << lane) - 1ull));
+      const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
       rec_live[2 * (int64_t)pos] = a;
       rec_live[2 * (int64_t)pos + 1] = b;
       float* row = rec2_live + (int64_t)(pos >> 1) * 12 + (pos & 1);
       row[0] = a.x; row[2] = a.y; row[4] = a.z; row[6] = b.x; row[8] = b.y; row[10] = b.z;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) s_base += all;
-    __syncthreads();
-  }
-  const int n_live = s_base;
-  const int64_t slots = 2 * rec2_rows(n_live);      // pad the last mini-chunk with a correspondence nothing reaches
-  for (int64_t pos = n_live + threadIdx.x; pos < slots; pos += 1024) {
-    float* row = rec2_live + (pos >> 1) * 12 + (pos & 1);
-    row[0] = 0.f; row[2] = 0.f; row[4] = 0.f; row[6] = 3e18f; row[8] = 3e18f; row[10] = 3e18f;
-  }
-  if (threadIdx.x == 0) {
-    const int nmini = (int)(rec2_rows(n_live) / kMini);
-    live[kLiveCount] = n_live;
-    live[kLiveMini] = nmini;
-    live[kLiveWords] = (nmini + 31) / 32;
-    live[kLiveNear] = 0;
-    live[kLiveFar] = 0;
   }
 }
 
 __global__ __launch_bounds__(256) void k_near(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int few,
                                               const unsigned* __restrict__ maxn2, int prune, int* __restrict__ order_near,
                                               int* __restrict__ order_far, unsigned char* __restrict__ near_flag,
-                                              int* __restrict__ live, unsigned* __restrict__ band, int nwords) {
+                                              int* __restrict__ live, unsigned* __restrict__ band, int nwords,
+                                              float* __restrict__ rec2_live) {
   const int nv = min(*n_valid, cap);
   if (nv <= few) return;
   const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0) {      // finish k_live's list: pad the last mini-chunk with a correspondence nothing reaches
+    const int n_live = live[kLiveCount];
+    const int64_t slots = 2 * rec2_rows(n_live);
+    for (int64_t pos = n_live + threadIdx.x; pos < slots; pos += blockDim.x) {
+      float* row = rec2_live + (pos >> 1) * 12 + (pos & 1);
+      row[0] = 0.f; row[2] = 0.f; row[4] = 0.f; row[6] = 3e18f; row[8] = 3e18f; row[10] = 3e18f;
+    }
+    if (threadIdx.x == 0) {
+      const int nmini = (int)(rec2_rows(n_live) / kMini);
+      live[kLiveMini] = nmini;
+      live[kLiveWords] = (nmini + 31) / 32;
+    }
+  }
   const double Mn = sqrt((double)__uint_as_float(*maxn2)) * (1.0 + 1e-6);
   const Hyp* r = hyps;
   const int nround = (nv + 255) & ~255;
@@ -1301,7 +1294,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t ransac_core_bytes(int64_t n0, int64_t max_iter) {
   const int64_t cap = max_iter < kChunk ? max_iter : kChunk;
   const size_t c1 = (size_t)(cap < 1 ? 1 : cap);
-  return 512 + align256(c1 * sizeof(Hyp)) + align256((size_t)n0 * 32) +
+  return 768 + align256(c1 * sizeof(Hyp)) + align256((size_t)n0 * 32) +
          align256(((size_t)(max_iter < 1 ? 1 : max_iter) + kCandLists * 256) * 8) + align256(kGeoGrid * sizeof(GeoPart)) +
          align256((size_t)rec2_rows(n0) * 48) + 256 + align256(c1 * 4) + align256(c1 * band_words(n0) * 4) +
          align256(kSelParts * sizeof(SelPart)) + align256((size_t)(n0 + 32) * 8) + 256 + align256((size_t)n0 * 32) +
@@ -1316,7 +1309,8 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   r.total_valid = (long long*)(p + sizeof(Hyp));
   r.n_valid = (int*)(p + sizeof(Hyp) + 8);
   r.n_cand = (int*)(p + 256);   // kCandLists counters; n_valid .. the last counter: ONE memset (kCountersBytes) clears them
-  p += 512;
+  r.live = (int*)(p + 512);     // ... and the pruned list's counters behind them (counter_words covers both)
+  p += 768;
   r.hyps = (Hyp*)p;
   p += align256((size_t)cap * sizeof(Hyp));
   r.rec = (float4*)p;
@@ -1342,8 +1336,6 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
   p += align256((size_t)n0 * 32);
   r.rec2_live = (float*)p;
   p += align256((size_t)rec2_rows(n0) * 48);
-  r.live = (int*)p;
-  p += 256;
   r.order_near = (int*)p;
   p += align256((size_t)cap * 4);
   r.order_far = (int*)p;
@@ -1386,10 +1378,10 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
   // the survivors sorted into NEAR the first one (counted over the correspondences within reach of it) and FAR (over all)
   const int prune = env_int("APR_RANSAC_PRUNE", 1);      // read per call: A/B and test hook
   const double m_up = sqrt(thr_lt) * (1.0 + 1e-12);
-  hipLaunchKernelGGL(k_live, dim3(1), dim3(1024), 0, st, r.rec, n0, m_up, r.hyps, r.n_valid, cap, few, r.rec_live, r.rec2_live,
+  hipLaunchKernelGGL(k_live, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, r.rec, n0, m_up, r.hyps, r.n_valid, cap, few, r.rec_live, r.rec2_live,
                      r.live);
   hipLaunchKernelGGL(k_near, dim3(512), dim3(256), 0, st, r.hyps, r.n_valid, cap, few, r.maxn2, prune, r.order_near, r.order_far,
-                     r.near_flag, r.live, r.band, nwords);
+                     r.near_flag, r.live, r.band, nwords, r.rec2_live);
   hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2_live, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
                      r.band, few, r.order_near, r.live, (int)kLiveNear, 1);
   hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
@@ -1406,7 +1398,7 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
 }
 
 // sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
-static int counter_words(const RansacScratch& r) { return (int)((r.n_cand + kCandLists) - r.n_valid); }
+static int counter_words(const RansacScratch& r) { return (int)((r.live + kLiveInts) - r.n_valid); }
 
 static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dist, double edge_ratio, int64_t it0,
                               int64_t it1, uint64_t seed, int cap, hipStream_t st, bool counters_cleared = false) {
