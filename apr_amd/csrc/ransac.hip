@@ -590,31 +590,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // first survivor) and the residual r_c = |T_ref s_c - t_c| of every correspondence.  For a hypothesis h,
 //     | |T_h s - t| - |T_ref s - t| | <= |T_h s - T_ref s| <= ||R_h - R_ref||_F |s| + |t_h - t_ref| <= delta_h
 // with delta_h := ||R_h - R_ref||_F * max|s| + |t_h - t_ref|.  So if delta_h <= D, a correspondence with r_c >= m + D is
-// at distance >= m from its target under T_h: not an inlier (inliers need < m).  k_live keeps the correspondences with
-// r_c < m + D (in order) as a second record set; k_near sorts the survivors into NEAR (delta_h <= D: counted over the kept
+// at distance >= m from its target under T_h: not an inlier (inliers need < m).  k_prune keeps the correspondences with
+// r_c < m + D as a second record set and sorts the survivors into NEAR (delta_h <= D: counted over the kept
 // records only) and FAR (counted over all, as before -- also everything when T_ref is a poor draw: only speed is lost).
 // fp64 throughout, D compared with 1e-6 m to spare; counts, picks and errors are those of the full evaluation, bit for bit
 // (tests/test_match_pose_gpu.py).  APR_RANSAC_PRUNE=0: every survivor is FAR.
 // ---------------------------------------------------------------------------------------------------------------
-enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveInts = 8 };
+enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveDone = 5, kLiveInts = 8 };
 constexpr double kPruneReach = 10.0;      // D, metres
 
 // (the order of the kept records is free: the count is an integer sum, and the squared error of the picked hypotheses is
-// summed over the FULL records by k_score.)  live[kLiveCount] is zero on entry (cleared with the round's counters);
-// k_near finishes the list (padding of the last mini-chunk, mini-chunk / word counts).
-__global__ __launch_bounds__(256) void k_live(const float4* __restrict__ rec, int64_t n0, double m_up,
-                                              const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int few,
-                                              float4* __restrict__ rec_live, float* __restrict__ rec2_live,
-                                              int* __restrict__ live) {
-  const int nv = min(*n_valid, cap);
-  if (nv <= few) return;
+// summed over the FULL records by k_score.)  live[kLiveCount] and live[kLiveDone] are zero on entry (cleared with the round's
+// counters); the LAST block of this part to finish pads the last mini-chunk and writes the mini-chunk / word counts.
+__device__ inline void live_part(int blk, int nblk, const float4* __restrict__ rec, int64_t n0, double m_up,
+                                 const Hyp* __restrict__ hyps, float4* __restrict__ rec_live, float* __restrict__ rec2_live,
+                                 int* __restrict__ live) {
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const Hyp* hp = hyps;      // T_ref: the first survivor
   const double T0 = hp->T[0], T1 = hp->T[1], T2 = hp->T[2], T3 = hp->T[3], T4 = hp->T[4], T5 = hp->T[5];
   const double T6 = hp->T[6], T7 = hp->T[7], T8 = hp->T[8], T9 = hp->T[9], T10 = hp->T[10], T11 = hp->T[11];
   const double reach = m_up + kPruneReach, reach2 = reach * reach;
   const int64_t nround = (n0 + 255) & ~(int64_t)255;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)blk * blockDim.x + threadIdx.x; i < nround; i += (int64_t)nblk * blockDim.x) {
     bool keep = false;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (i < n0) {
@@ -638,33 +636,33 @@ __global__ __launch_bounds__(256) void k_live(const float4* __restrict__ rec, in
       row[0] = a.x; row[2] = a.y; row[4] = a.z; row[6] = b.x; row[8] = b.y; row[10] = b.z;
     }
   }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(live + kLiveDone, 1) == nblk - 1;
+  __syncthreads();
+  if (!s_last) return;
+  const int n_live = atomicAdd(live + kLiveCount, 0);      // every block's reservations are in
+  const int64_t slots = 2 * rec2_rows(n_live);
+  for (int64_t pos = n_live + threadIdx.x; pos < slots; pos += blockDim.x) {      // a correspondence nothing reaches
+    float* row = rec2_live + (pos >> 1) * 12 + (pos & 1);
+    row[0] = 0.f; row[2] = 0.f; row[4] = 0.f; row[6] = 3e18f; row[8] = 3e18f; row[10] = 3e18f;
+  }
+  if (threadIdx.x == 0) {
+    const int nmini = (int)(rec2_rows(n_live) / kMini);
+    live[kLiveMini] = nmini;
+    live[kLiveWords] = (nmini + 31) / 32;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_near(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap, int few,
-                                              const unsigned* __restrict__ maxn2, int prune, int* __restrict__ order_near,
-                                              int* __restrict__ order_far, unsigned char* __restrict__ near_flag,
-                                              int* __restrict__ live, unsigned* __restrict__ band, int nwords,
-                                              float* __restrict__ rec2_live) {
-  const int nv = min(*n_valid, cap);
-  if (nv <= few) return;
+__device__ inline void near_part(int blk, int nblk, const Hyp* __restrict__ hyps, int nv, const unsigned* __restrict__ maxn2,
+                                 int prune, int* __restrict__ order_near, int* __restrict__ order_far,
+                                 unsigned char* __restrict__ near_flag, int* __restrict__ live, unsigned* __restrict__ band,
+                                 int nwords) {
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x == 0) {      // finish k_live's list: pad the last mini-chunk with a correspondence nothing reaches
-    const int n_live = live[kLiveCount];
-    const int64_t slots = 2 * rec2_rows(n_live);
-    for (int64_t pos = n_live + threadIdx.x; pos < slots; pos += blockDim.x) {
-      float* row = rec2_live + (pos >> 1) * 12 + (pos & 1);
-      row[0] = 0.f; row[2] = 0.f; row[4] = 0.f; row[6] = 3e18f; row[8] = 3e18f; row[10] = 3e18f;
-    }
-    if (threadIdx.x == 0) {
-      const int nmini = (int)(rec2_rows(n_live) / kMini);
-      live[kLiveMini] = nmini;
-      live[kLiveWords] = (nmini + 31) / 32;
-    }
-  }
   const double Mn = sqrt((double)__uint_as_float(*maxn2)) * (1.0 + 1e-6);
   const Hyp* r = hyps;
   const int nround = (nv + 255) & ~255;
-  for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nround; h += gridDim.x * blockDim.x) {
+  for (int h = blk * blockDim.x + threadIdx.x; h < nround; h += nblk * blockDim.x) {
     bool nr = false;
     if (h < nv && prune) {
       const Hyp* p = hyps + h;
@@ -700,45 +698,65 @@ __global__ __launch_bounds__(256) void k_near(const Hyp* __restrict__ hyps, cons
   }
 }
 
+// ONE launch for both parts (with few survivors -- the random-feature case -- it is one empty launch more per pair, not
+// two): the first n_live_blocks workgroups build the pruned correspondence list, the others sort the survivors.
+__global__ __launch_bounds__(256) void k_prune(const float4* __restrict__ rec, int64_t n0, double m_up, Hyp* __restrict__ hyps,
+                                               const int* __restrict__ n_valid, int cap, int few,
+                                               const unsigned* __restrict__ maxn2, int prune, int n_live_blocks,
+                                               float4* __restrict__ rec_live, float* __restrict__ rec2_live,
+                                               int* __restrict__ live, int* __restrict__ order_near,
+                                               int* __restrict__ order_far, unsigned char* __restrict__ near_flag,
+                                               unsigned* __restrict__ band, int nwords) {
+  const int nv = min(*n_valid, cap);
+  if (nv <= few) return;
+  if ((int)blockIdx.x < n_live_blocks)
+    live_part((int)blockIdx.x, n_live_blocks, rec, n0, m_up, hyps, rec_live, rec2_live, live);
+  else
+    near_part((int)blockIdx.x - n_live_blocks, (int)gridDim.x - n_live_blocks, hyps, nv, maxn2, prune, order_near, order_far,
+              near_flag, live, band, nwords);
+}
+
 __device__ inline int count_parts(int nblk, int nunits) {      // ranges per 256-hypothesis block: ~4096 items in all
   int S = (4096 + nblk - 1) / nblk;
   if (S > nunits) S = nunits;
   return S < 1 ? 1 : S;
 }
 
-// `order` / `live` (both or neither): the hypotheses order[0 .. live[kLiveNear or kLiveFar]) over the correspondence list
-// whose mini-chunk count is live[kLiveMini] (the pruned list of k_live); band rows keep the FULL stride `nwords` and were
-// cleared by k_near.
-__global__ __launch_bounds__(256) void k_count(const float* __restrict__ rec2, int nwords, int nmini, double thr_lt,
+// Both survivor lists in ONE launch: the NEAR list (order_near[0 .. live[kLiveNear])) over the pruned correspondences
+// (rec2_live, live[kLiveMini] mini-chunks), then the FAR list over all of them; band rows have the full stride `nwords` and
+// were cleared by k_prune.
+// Work items = (256 hypotheses, a contiguous range of MINI-CHUNKS).  A thread walks its range row by row behind scalar
+// loads: ~115 us per 32 mini-chunks whatever else runs, so the ranges must be short enough that the grid is many waves
+// per SIMD deep (ranges of whole 32-mini-chunk words left 248 items of 115 us each for the pruned list of a 30 % pair:
+// no faster than the full list).  A range ORs its band bits in.
+__global__ __launch_bounds__(256) void k_count(const float* __restrict__ rec2_full, const float* __restrict__ rec2_live,
+                                               int nwords, int nmini_full, double thr_lt,
                                                const unsigned* __restrict__ maxn2, Hyp* __restrict__ hyps,
                                                const int* __restrict__ n_valid, int cap, unsigned* __restrict__ band,
-                                               int few, const int* __restrict__ order, const int* __restrict__ live,
-                                               int which, int pruned) {
+                                               int few, const int* __restrict__ order_near,
+                                               const int* __restrict__ order_far, const int* __restrict__ live) {
   const int nv_all = min(*n_valid, cap);
   if (nv_all <= few) return;
-  const int nv = order ? live[which] : nv_all;
-  if (nv <= 0) return;
+  const int nvN = live[kLiveNear], nvF = live[kLiveFar], nminiN = live[kLiveMini];
+  const int nblkN = (nvN + 255) >> 8, nblkF = (nvF + 255) >> 8;
+  const int SN = count_parts(nblkN > 0 ? nblkN : 1, nminiN > 0 ? nminiN : 1);
+  const int SF = count_parts(nblkF > 0 ? nblkF : 1, nmini_full > 0 ? nmini_full : 1);
+  const int itemsN = nminiN > 0 ? nblkN * SN : 0, itemsF = nblkF * SF;
   const int nwords_full = nwords;
-  if (pruned) {
-    nmini = live[kLiveMini];
-    nwords = live[kLiveWords];
-  }
-  // Work items = (256 hypotheses, a contiguous range of MINI-CHUNKS).  A thread walks its range row by row behind scalar
-  // loads: ~115 us per 32 mini-chunks whatever else runs, so the ranges must be short enough that the grid is many waves
-  // per SIMD deep (ranges of whole 32-mini-chunk words left 248 items of 115 us each for the pruned list of a 30 % pair:
-  // no faster than the full list).  The band words were cleared by k_near; a range ORs its bits in.
-  const int nblk = (nv + 255) >> 8;
-  const int S = count_parts(nblk, nmini > 0 ? nmini : 1);
   const float Mn = sqrtf(__uint_as_float(*maxn2)) * 1.000001f;
   const float thr = (float)thr_lt;
-  (void)nwords;
-  for (int item = blockIdx.x; item < nblk * S; item += gridDim.x) {
+  for (int item0 = blockIdx.x; item0 < itemsN + itemsF; item0 += gridDim.x) {
+    const bool isN = item0 < itemsN;
+    const int item = isN ? item0 : item0 - itemsN;
+    const int S = isN ? SN : SF, nv = isN ? nvN : nvF, nmini = isN ? nminiN : nmini_full;
+    const int* __restrict__ order = isN ? order_near : order_far;
+    const float* __restrict__ rec2 = isN ? rec2_live : rec2_full;
     const int hb = item / S, part = item - hb * S;
     const int m_begin = (int)((int64_t)nmini * part / S), m_stop = (int)((int64_t)nmini * (part + 1) / S);
     const int w_begin = m_begin >> 5, w_end = (m_stop + 31) >> 5;
     const int slot = hb * 256 + threadIdx.x;
     const bool act = slot < nv;
-    const int h = order ? order[act ? slot : nv - 1] : (act ? slot : nv - 1);
+    const int h = order[act ? slot : nv - 1];
     const Hyp* hp = hyps + h;
     float T[12];
 #pragma unroll
@@ -1279,7 +1297,7 @@ struct RansacScratch {
   unsigned* band;  // [cap][band_words(n0)] flagged mini-chunks
   SelPart* selp;   // [kSelParts]
   unsigned long long* rec8;   // [n0] quantised correspondences for k_sample_screen
-  float4* rec_live;           // [2 n0] the correspondences k_live kept, both layouts, ...
+  float4* rec_live;           // [2 n0] the correspondences k_prune kept, both layouts, ...
   float* rec2_live;
   int* live;                  // ... their counts and the NEAR / FAR list lengths (kLiveInts)
   int *order_near, *order_far;      // [cap] each
@@ -1378,14 +1396,12 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
   // the survivors sorted into NEAR the first one (counted over the correspondences within reach of it) and FAR (over all)
   const int prune = env_int("APR_RANSAC_PRUNE", 1);      // read per call: A/B and test hook
   const double m_up = sqrt(thr_lt) * (1.0 + 1e-12);
-  hipLaunchKernelGGL(k_live, dim3((unsigned)cdiv64(n0, 256)), dim3(256), 0, st, r.rec, n0, m_up, r.hyps, r.n_valid, cap, few, r.rec_live, r.rec2_live,
-                     r.live);
-  hipLaunchKernelGGL(k_near, dim3(512), dim3(256), 0, st, r.hyps, r.n_valid, cap, few, r.maxn2, prune, r.order_near, r.order_far,
-                     r.near_flag, r.live, r.band, nwords, r.rec2_live);
-  hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2_live, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
-                     r.band, few, r.order_near, r.live, (int)kLiveNear, 1);
-  hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2, nwords, nmini, thr_lt, r.maxn2, r.hyps, r.n_valid, cap,
-                     r.band, few, r.order_far, r.live, (int)kLiveFar, 0);
+  const int n_live_blocks = (int)cdiv64(n0, 256);
+  hipLaunchKernelGGL(k_prune, dim3((unsigned)(n_live_blocks + 512)), dim3(256), 0, st, r.rec, n0, m_up, r.hyps, r.n_valid, cap, few,
+                     r.maxn2, prune, n_live_blocks, r.rec_live, r.rec2_live, r.live, r.order_near, r.order_far, r.near_flag,
+                     r.band, nwords);
+  hipLaunchKernelGGL(k_count, dim3(4096), dim3(256), 0, st, r.rec2, r.rec2_live, nwords, nmini, thr_lt, r.maxn2, r.hyps,
+                     r.n_valid, cap, r.band, few, r.order_near, r.order_far, r.live);
   hipLaunchKernelGGL(k_count_fix, dim3(2048), dim3(256), 0, st, r.rec, n0, thr_lt, r.hyps, r.n_valid, cap, r.band, nwords,
                      few, r.rec_live, r.live, r.near_flag);
   hipLaunchKernelGGL(k_count_max, dim3(256), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.sel_hdr, few);
