@@ -596,7 +596,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // fp64 throughout, D compared with 1e-6 m to spare; counts, picks and errors are those of the full evaluation, bit for bit
 // (tests/test_match_pose_gpu.py).  APR_RANSAC_PRUNE=0: every survivor is FAR.
 // ---------------------------------------------------------------------------------------------------------------
-enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveDone = 5, kLiveInts = 8 };
+enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveDone = 5, kLiveSelDone = 6, kLiveInts = 8 };
 constexpr double kPruneReach = 10.0;      // D, metres
 
 // (the order of the kept records is free: the count is an integer sum, and the squared error of the picked hypotheses is
@@ -925,7 +925,7 @@ __global__ void k_select(const Hyp* __restrict__ hyps, const int* __restrict__ n
 }
 
 // Two-stage form of k_select for long hypothesis lists (one workgroup reading 2^18 records of 128 B took 0.5 ms): kSelParts
-// workgroups each keep the best of a slice, k_select_final the best of those and of the running best.
+// workgroups each keep the best of a slice, the last of them the best of those and of the running best (k_select_best).
 constexpr int kSelParts = 256;
 struct SelPart {
   double r;
@@ -933,9 +933,16 @@ struct SelPart {
   int c, h;
 };
 
-__global__ __launch_bounds__(256) void k_select_part(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
-                                                     SelPart* __restrict__ parts) {
+// ONE launch: every workgroup reduces its slice into parts[], the LAST one to finish (ticket counter live[kLiveSelDone],
+// cleared with the round's counters) reduces the parts and updates the running best.  Fixed reduction trees, so the winner
+// does not depend on which workgroup comes last.
+__global__ __launch_bounds__(256) void k_select_best(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                                     SelPart* __restrict__ parts, Hyp* __restrict__ best,
+                                                     long long* __restrict__ total_valid, int* __restrict__ sel_hdr,
+                                                     int* __restrict__ done) {
   __shared__ SelPart s_p[256];
+  __shared__ int s_last;
+  static_assert(kSelParts == 256, "k_select_best reduces kSelParts parts with one 256-thread workgroup");
   const int nv = min(*n_valid, cap);
   SelPart b;
   b.c = -1; b.h = -1; b.r = 0.0; b.it = 0;
@@ -956,13 +963,14 @@ __global__ __launch_bounds__(256) void k_select_part(const Hyp* __restrict__ hyp
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) parts[blockIdx.x] = s_p[0];
-}
-
-__global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid,
-                                                            const SelPart* __restrict__ parts, Hyp* __restrict__ best,
-                                                            long long* __restrict__ total_valid, int* __restrict__ sel_hdr) {
-  __shared__ SelPart s_p[kSelParts];
+  if (threadIdx.x == 0) {
+    parts[blockIdx.x] = s_p[0];
+    __threadfence();
+    s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();      // the other workgroups' parts
   s_p[threadIdx.x] = parts[threadIdx.x];
   __syncthreads();
   for (int stride = kSelParts / 2; stride >= 1; stride >>= 1) {
@@ -974,6 +982,7 @@ __global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restric
   }
   if (threadIdx.x == 0) {
     sel_hdr[0] = sel_hdr[1] = 0;      // ready for the next round's k_count_max / k_pick
+    *done = 0;                        // ... and for the next launch of this kernel
     *total_valid += *n_valid;
     const SelPart w = s_p[0];
     if (w.h >= 0) {
@@ -1408,9 +1417,8 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
   hipLaunchKernelGGL(k_pick, dim3(256), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.sel_hdr, r.sel, few);
   hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.sel_hdr, r.sel, r.part);
   hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.sel_hdr, r.sel, n0, r.part);
-  hipLaunchKernelGGL(k_select_part, dim3(kSelParts), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.selp);
-  hipLaunchKernelGGL(k_select_final, dim3(1), dim3(kSelParts), 0, st, r.hyps, r.n_valid, r.selp, r.best, r.total_valid,
-                     r.sel_hdr);
+  hipLaunchKernelGGL(k_select_best, dim3(kSelParts), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.selp, r.best, r.total_valid,
+                     r.sel_hdr, r.live + kLiveSelDone);
 }
 
 // sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
