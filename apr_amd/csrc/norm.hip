@@ -412,6 +412,21 @@ APR_API int apr_bn_stats(const float* x, int64_t ld, int64_t n, int32_t c, float
   return APR_OK;
 }
 
+// sums[c] = sum over the rows of x[:, c]: the bias gradient of a Linear / 1x1 convolution in the training path (fp64 partial
+// sums per row block combined in fixed order, as apr_bn_stats: the same bits every run)
+APR_API int apr_col_sums(const float* x, int64_t ld, int64_t n, int32_t c, float* sums, void* scratch, size_t scratch_bytes,
+                         void* stream) {
+  APR_CHECK_ARG(n > 0 && c > 0 && ld >= c && sums, "apr_col_sums: bad shape n=%lld c=%d", (long long)n, c);
+  APR_CHECK_ARG(scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_col_sums: scratch too small");
+  const int nblk = (int)cdiv64(n, kRowsPerBlock);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, c,
+                     one_segment(n), (double*)scratch);
+  hipLaunchKernelGGL(k_bn_finish, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream,      // "mean" over ONE row = the sum
+                     (const double*)scratch, nblk, (int64_t)1, c, sums, (float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
 APR_API int apr_norm_params(const float* x, int64_t ld, int64_t n, int32_t c, float eps, float* scale, float* shift,
                             void* scratch, size_t scratch_bytes, void* stream) {
   APR_CHECK_ARG(n > 0 && c > 0 && ld >= c && eps >= 0.f, "apr_norm_params: bad arguments");

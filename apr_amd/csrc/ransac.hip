@@ -157,7 +157,7 @@ __host__ __device__ inline int64_t rec2_rows(int64_t n0) { return ((n0 + 1) / 2 
 
 __global__ void k_pack_pairs(const float* __restrict__ xyz0, const float* __restrict__ xyz1, int64_t n1,
                              const long long* __restrict__ corr, int64_t n0, float4* __restrict__ rec,
-                             float* __restrict__ rec2, unsigned* __restrict__ maxn2) {
+                             float* __restrict__ rec2, unsigned* __restrict__ maxn2, float* __restrict__ rec2_live) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float sx = 0.f, sy = 0.f, sz = 0.f, tx = 3e18f, ty = 3e18f, tz = 3e18f, m = 0.f;
   if (i < n0) {
@@ -172,6 +172,10 @@ __global__ void k_pack_pairs(const float* __restrict__ xyz0, const float* __rest
   if (i < 2 * rec2_rows(n0)) {
     float* row = rec2 + (i >> 1) * 12 + (i & 1);
     row[0] = sx; row[2] = sy; row[4] = sz; row[6] = tx; row[8] = ty; row[10] = tz;
+    // the pruned list of the count path (k_prune) starts out as all padding: whatever it does not overwrite is a
+    // correspondence nothing reaches, so its last mini-chunk needs no finishing pass
+    float* lrow = rec2_live + (i >> 1) * 12 + (i & 1);
+    lrow[0] = 0.f; lrow[2] = 0.f; lrow[4] = 0.f; lrow[6] = 3e18f; lrow[8] = 3e18f; lrow[10] = 3e18f;
   }
   for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxn2, __float_as_uint(m));
@@ -596,16 +600,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // fp64 throughout, D compared with 1e-6 m to spare; counts, picks and errors are those of the full evaluation, bit for bit
 // (tests/test_match_pose_gpu.py).  APR_RANSAC_PRUNE=0: every survivor is FAR.
 // ---------------------------------------------------------------------------------------------------------------
-enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveDone = 5, kLiveSelDone = 6, kLiveInts = 8 };
+enum { kLiveCount = 0, kLiveMini = 1, kLiveWords = 2, kLiveNear = 3, kLiveFar = 4, kLiveInts = 8 };
 constexpr double kPruneReach = 10.0;      // D, metres
 
 // (the order of the kept records is free: the count is an integer sum, and the squared error of the picked hypotheses is
-// summed over the FULL records by k_score.)  live[kLiveCount] and live[kLiveDone] are zero on entry (cleared with the round's
-// counters); the LAST block of this part to finish pads the last mini-chunk and writes the mini-chunk / word counts.
+// summed over the FULL records by k_score.)  live[kLiveCount] is zero on entry (cleared with the round's counters) and
+// rec2_live is all padding (k_pack_pairs): the list needs no finishing pass, its mini-chunk count follows from its length.
+// (A first version let the last block to finish pad the list behind a __threadfence() + ticket; device-scope fences write
+// back and invalidate the L2 under the other streams' kernels -- see k_select_part.)
 __device__ inline void live_part(int blk, int nblk, const float4* __restrict__ rec, int64_t n0, double m_up,
                                  const Hyp* __restrict__ hyps, float4* __restrict__ rec_live, float* __restrict__ rec2_live,
                                  int* __restrict__ live) {
-  __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const Hyp* hp = hyps;      // T_ref: the first survivor
   const double T0 = hp->T[0], T1 = hp->T[1], T2 = hp->T[2], T3 = hp->T[3], T4 = hp->T[4], T5 = hp->T[5];
@@ -635,22 +640,6 @@ __device__ inline void live_part(int blk, int nblk, const float4* __restrict__ r
       float* row = rec2_live + (int64_t)(pos >> 1) * 12 + (pos & 1);
       row[0] = a.x; row[2] = a.y; row[4] = a.z; row[6] = b.x; row[8] = b.y; row[10] = b.z;
     }
-  }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(live + kLiveDone, 1) == nblk - 1;
-  __syncthreads();
-  if (!s_last) return;
-  const int n_live = atomicAdd(live + kLiveCount, 0);      // every block's reservations are in
-  const int64_t slots = 2 * rec2_rows(n_live);
-  for (int64_t pos = n_live + threadIdx.x; pos < slots; pos += blockDim.x) {      // a correspondence nothing reaches
-    float* row = rec2_live + (pos >> 1) * 12 + (pos & 1);
-    row[0] = 0.f; row[2] = 0.f; row[4] = 0.f; row[6] = 3e18f; row[8] = 3e18f; row[10] = 3e18f;
-  }
-  if (threadIdx.x == 0) {
-    const int nmini = (int)(rec2_rows(n_live) / kMini);
-    live[kLiveMini] = nmini;
-    live[kLiveWords] = (nmini + 31) / 32;
   }
 }
 
@@ -723,7 +712,7 @@ __device__ inline int count_parts(int nblk, int nunits) {      // ranges per 256
 }
 
 // Both survivor lists in ONE launch: the NEAR list (order_near[0 .. live[kLiveNear])) over the pruned correspondences
-// (rec2_live, live[kLiveMini] mini-chunks), then the FAR list over all of them; band rows have the full stride `nwords` and
+// (rec2_live; its mini-chunk count follows from live[kLiveCount]), then the FAR list over all of them; band rows have the full stride `nwords` and
 // were cleared by k_prune.
 // Work items = (256 hypotheses, a contiguous range of MINI-CHUNKS).  A thread walks its range row by row behind scalar
 // loads: ~115 us per 32 mini-chunks whatever else runs, so the ranges must be short enough that the grid is many waves
@@ -737,7 +726,7 @@ __global__ __launch_bounds__(256) void k_count(const float* __restrict__ rec2_fu
                                                const int* __restrict__ order_far, const int* __restrict__ live) {
   const int nv_all = min(*n_valid, cap);
   if (nv_all <= few) return;
-  const int nvN = live[kLiveNear], nvF = live[kLiveFar], nminiN = live[kLiveMini];
+  const int nvN = live[kLiveNear], nvF = live[kLiveFar], nminiN = (int)(rec2_rows(live[kLiveCount]) / kMini);
   const int nblkN = (nvN + 255) >> 8, nblkF = (nvF + 255) >> 8;
   const int SN = count_parts(nblkN > 0 ? nblkN : 1, nminiN > 0 ? nminiN : 1);
   const int SF = count_parts(nblkF > 0 ? nblkF : 1, nmini_full > 0 ? nmini_full : 1);
@@ -925,7 +914,9 @@ __global__ void k_select(const Hyp* __restrict__ hyps, const int* __restrict__ n
 }
 
 // Two-stage form of k_select for long hypothesis lists (one workgroup reading 2^18 records of 128 B took 0.5 ms): kSelParts
-// workgroups each keep the best of a slice, the last of them the best of those and of the running best (k_select_best).
+// workgroups each keep the best of a slice, k_select_final the best of those and of the running best.  (One kernel whose
+// last workgroup reduces the parts -- __threadfence() + ticket in all 256 workgroups -- cost the three-steps-in-flight
+// headline 2.5 %: a device-scope fence writes back and invalidates the L2 under the other streams' kernels.)
 constexpr int kSelParts = 256;
 struct SelPart {
   double r;
@@ -933,16 +924,9 @@ struct SelPart {
   int c, h;
 };
 
-// ONE launch: every workgroup reduces its slice into parts[], the LAST one to finish (ticket counter live[kLiveSelDone],
-// cleared with the round's counters) reduces the parts and updates the running best.  Fixed reduction trees, so the winner
-// does not depend on which workgroup comes last.
-__global__ __launch_bounds__(256) void k_select_best(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
-                                                     SelPart* __restrict__ parts, Hyp* __restrict__ best,
-                                                     long long* __restrict__ total_valid, int* __restrict__ sel_hdr,
-                                                     int* __restrict__ done) {
+__global__ __launch_bounds__(256) void k_select_part(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid, int cap,
+                                                     SelPart* __restrict__ parts) {
   __shared__ SelPart s_p[256];
-  __shared__ int s_last;
-  static_assert(kSelParts == 256, "k_select_best reduces kSelParts parts with one 256-thread workgroup");
   const int nv = min(*n_valid, cap);
   SelPart b;
   b.c = -1; b.h = -1; b.r = 0.0; b.it = 0;
@@ -963,14 +947,13 @@ __global__ __launch_bounds__(256) void k_select_best(const Hyp* __restrict__ hyp
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    parts[blockIdx.x] = s_p[0];
-    __threadfence();
-    s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();      // the other workgroups' parts
+  if (threadIdx.x == 0) parts[blockIdx.x] = s_p[0];
+}
+
+__global__ __launch_bounds__(kSelParts) void k_select_final(const Hyp* __restrict__ hyps, const int* __restrict__ n_valid,
+                                                            const SelPart* __restrict__ parts, Hyp* __restrict__ best,
+                                                            long long* __restrict__ total_valid, int* __restrict__ sel_hdr) {
+  __shared__ SelPart s_p[kSelParts];
   s_p[threadIdx.x] = parts[threadIdx.x];
   __syncthreads();
   for (int stride = kSelParts / 2; stride >= 1; stride >>= 1) {
@@ -982,7 +965,6 @@ __global__ __launch_bounds__(256) void k_select_best(const Hyp* __restrict__ hyp
   }
   if (threadIdx.x == 0) {
     sel_hdr[0] = sel_hdr[1] = 0;      // ready for the next round's k_count_max / k_pick
-    *done = 0;                        // ... and for the next launch of this kernel
     *total_valid += *n_valid;
     const SelPart w = s_p[0];
     if (w.h >= 0) {
@@ -1377,7 +1359,7 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
 static void launch_pack(const RansacScratch& r, const float* xyz0, const float* xyz1, int64_t n1, const int64_t* corr,
                         int64_t n0, hipStream_t st) {
   hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(2 * rec2_rows(n0), 256)), dim3(256), 0, st, xyz0, xyz1, n1,
-                     (const long long*)corr, n0, r.rec, r.rec2, r.maxn2);
+                     (const long long*)corr, n0, r.rec, r.rec2, r.maxn2, r.rec2_live);
   if (n0 <= kScreenMaxN0)      // the 8-byte records of k_sample_screen (needs the finished norm bound: its own launch)
     hipLaunchKernelGGL(k_pack_small, dim3((unsigned)cdiv64(n0 + 32, 256)), dim3(256), 0, st, r.rec, n0, r.maxn2, r.rec8);
 }
@@ -1417,8 +1399,9 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
   hipLaunchKernelGGL(k_pick, dim3(256), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.sel_hdr, r.sel, few);
   hipLaunchKernelGGL(k_score, dim3(kGeoGrid), dim3(kScoreThreads), 0, st, r.rec, n0, thr_lt, r.hyps, r.sel_hdr, r.sel, r.part);
   hipLaunchKernelGGL(k_score_finish, dim3(kGeoGrid / 256), dim3(256), 0, st, r.hyps, r.sel_hdr, r.sel, n0, r.part);
-  hipLaunchKernelGGL(k_select_best, dim3(kSelParts), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.selp, r.best, r.total_valid,
-                     r.sel_hdr, r.live + kLiveSelDone);
+  hipLaunchKernelGGL(k_select_part, dim3(kSelParts), dim3(256), 0, st, r.hyps, r.n_valid, cap, r.selp);
+  hipLaunchKernelGGL(k_select_final, dim3(1), dim3(kSelParts), 0, st, r.hyps, r.n_valid, r.selp, r.best, r.total_valid,
+                     r.sel_hdr);
 }
 
 // sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
@@ -1573,11 +1556,14 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
   // survive both checkers (near-perfect correspondences) the rounds are replayed kChunk iterations at a time,
   // where the list cannot overflow.  total_valid tells which case it was.
   const int s_force_rounds = env_int("APR_RANSAC_FORCE_ROUNDS", 0);   // test hook (read per call): skip the fast path
+  bool packed_fresh = true;      // the pruned list of the count path must start out as all padding for EVERY scoring round
   for (int pass = s_force_rounds ? 1 : 0; pass < 2; ++pass) {
     const int64_t step = pass == 0 ? max_iter : cap;
     hipLaunchKernelGGL(k_init_best, dim3(1), dim3(1), 0, st, r.best, r.total_valid, (unsigned*)nullptr, (int*)nullptr, 0);
     for (int64_t it0 = 0; it0 < max_iter; it0 += step) {
       const int64_t it1 = (it0 + step < max_iter) ? it0 + step : max_iter;
+      if (!packed_fresh) launch_pack(r, xyz0, xyz1, n1, corr, n0, st);
+      packed_fresh = false;
       launch_hypotheses(r, n0, max_dist, edge_ratio, it0, it1, seed, (int)cap, st);
       launch_scoring(r, n0, thr_lt, (int)cap, st);
     }

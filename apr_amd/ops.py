@@ -871,6 +871,18 @@ def bn_stats(x):
     return mean, var
 
 
+def col_sums(x):
+    """sum over the rows of every column of x [n, c] -> f32 [c] (apr_col_sums: fp64 partials in fixed order)."""
+    x, ld = _rows(x, "col_sums.x")
+    n, c = x.shape
+    lib = _lib_()
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    check(lib.apr_col_sums(ptr(x), ld, n, c, ptr(out), ptr(scratch), sb, stream()))
+    return out
+
+
 def norm_params(x, eps):
     """(scale, shift) of a no-affine per-channel normalisation over all rows (one fused stats pass)."""
     x, ld = _rows(x, "norm_params.x")

@@ -87,29 +87,32 @@ class LinearFunction(torch.autograd.Function):
     apr_spconv_wgrad with the identity map (deterministic chunked reduction)."""
 
     @staticmethod
-    def forward(ctx, x, weight, wp_info):
+    def forward(ctx, x, weight, wp_info, bias=None):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
-        return linear(x, wp_info)
+        return linear(x, wp_info, shift=None if bias is None else bias.detach())
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         cout, cin = weight.shape
-        dx = dw = None
+        dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = linear(dy, pack_linear(weight.detach()))          # [N, cout] @ [cout, cin]
         if ctx.needs_input_grad[1]:
             dw = ops.spconv_wgrad(x, dy, None, 1, cin, cout)[0].t()  # (x^T dy)^T
-        return dx, dw, None
+        if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3]:
+            db = ops.col_sums(dy)                                  # the bias gradient: column sums, fp64 partials in fixed order
+        return dx, dw, None, db
 
 
-def linear_train(x, weight, wp_info):
-    """The tracked (training) form of a bias-free Linear: forward, d x and d W on the HIP kernels (LinearFunction)."""
+def linear_train(x, weight, wp_info, bias=None):
+    """The tracked (training) form of a Linear / 1x1 convolution on rows: forward, d x, d W (and d bias) on the HIP kernels
+    (LinearFunction)."""
     if HIP_TRAIN_LINEAR and x.shape[0] > 0 and x.dim() == 2:      # any width: `linear` pads to the GEMM's granule
-        return LinearFunction.apply(x, weight, wp_info)
-    return torch.nn.functional.linear(x, weight)
+        return LinearFunction.apply(x, weight, wp_info, bias)
+    return torch.nn.functional.linear(x, weight, bias)
 
 
 HIP_TRAIN_LINEAR = os.environ.get("APR_HIP_TRAIN_LINEAR", "1") != "0"   # A/B switch: 0 = torch's Linear in training

@@ -23,6 +23,7 @@ from .. import kp_ops
 from ..kernels.kernel_points import load_kernels
 
 FUSED_BLOCK = os.environ.get("APR_KP_FUSED_BLOCK", "1") != "0"     # A/B switch: 0 = one library call per op of a block
+KPCONV_TRAIN_HIP = os.environ.get("APR_KPCONV_TRAIN_HIP", "1") != "0"   # A/B switch: 0 = KPConv's training path on torch ops
 _SEG_ARRAYS = {}
 
 
@@ -85,11 +86,15 @@ class KPConv(nn.Module):
 
     def forward(self, q_pts, s_pts, neighb_inds, x):
         if kp_ops.tracking(x, self.weights):
-            if self.in_channels % 64 == 0 and neighb_inds.shape[1] <= 128 and self.out_channels % 32 == 0:
-                # training: forward and both gradients on the HIP kernels
+            # training: forward and both gradients on the HIP kernels.  The input gradient needs
+            # 64-channel multiples (apr_kpconv_dfeat); the first layer (cin = 1) reads the constant input features, which
+            # take no gradient: its forward (the generic correlation kernel) and d W (apr_spconv_wgrad over the recomputed
+            # [N, 15] weighted features) run on HIP as well
+            if (self.in_channels % 64 == 0 or not x.requires_grad) and neighb_inds.shape[1] <= 128 \
+                    and self.out_channels % 32 == 0 and KPCONV_TRAIN_HIP:
                 return kp_ops.KPConvFunction.apply(q_pts, s_pts, neighb_inds, x, self.weights, self.kernel_points,
                                                    self.KP_extent)
-            return self._forward_autograd(q_pts, s_pts, neighb_inds, x)       # first layer (cin = 1): torch ops
+            return self._forward_autograd(q_pts, s_pts, neighb_inds, x)       # other shapes: torch ops
         prof = kp_ops.PROFILE
         if prof is not None:      # bench.py roofline leg: HIP events on the launch stream around the layer's kernels
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

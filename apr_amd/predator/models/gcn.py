@@ -60,7 +60,8 @@ class _PackedHeadMajor:
 def conv1x1(x, conv, cache, relu=False):
     """Conv1d / Conv2d with kernel size 1 on rows: x [N,cin] -> [N,cout] (+ bias)."""
     if kp_ops.tracking(x, conv.weight, conv.bias):
-        y = torch.nn.functional.linear(x, conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1]), conv.bias)
+        # training: forward, d x, d W and d bias on the HIP kernels (kp_ops.LinearFunction; any width -- proj_score is 256 -> 1)
+        y = kp_ops.linear_train(x, conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1]), cache.get(conv), conv.bias)
         return torch.relu(y) if relu else y
     bias = None if conv.bias is None else conv.bias.detach()
     return kp_ops.linear(x, cache.get(conv), shift=bias, relu=relu)

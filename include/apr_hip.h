@@ -394,6 +394,12 @@ int apr_norm_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy
                       const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
                       float* dgamma, float* dbeta, void* scratch, size_t scratch_bytes, void* stream);
 
+/* sums[c] = sum over the n rows of x[:, c] (same scratch as apr_bn_stats; fp64 partial sums in fixed order): the bias
+ * gradient of the 1x1 convolutions with bias in KPFCNN's training path (Predator_APR/models/architectures.py:92-101 under
+ * lib/trainer.py:142-280). */
+int apr_col_sums(const float* x, int64_t ld, int64_t n, int32_t c, float* sums, void* scratch, size_t scratch_bytes,
+                 void* stream);
+
 /* Per-channel normalisation parameters over all rows, no affine: scale = 1/sqrt(var + eps),
  * shift = -mean*scale (InstanceNorm1d over the stacked points, Predator_APR/models/blocks.py:451-466;
  * InstanceNorm2d of the edge convolutions, models/gcn.py:41-48).  Same scratch as apr_bn_stats. */

@@ -440,6 +440,16 @@ def test_linear_training_function_any_width(dev, n, cin, cout):
     (y * proj.to(dev)).sum().backward()
     assert rel_l2(y.detach().cpu(), torch.nn.functional.linear(x.double(), W.double())) < 2e-6
     assert rel_l2(xg.grad.cpu(), xd.grad) < 2e-6 and rel_l2(Wg.grad.cpu(), Wd.grad) < 2e-6
+    # with a bias (the 1x1 convolutions of the bottleneck: architectures.py:92-101): d bias = the column sums of dy
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    xd, Wd, bd = x.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    (torch.nn.functional.linear(xd, Wd, bd) * proj.double()).sum().backward()
+    xg, Wg, bg = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = kp_ops.linear_train(xg, Wg, kp_ops.pack_linear(Wg.detach().t()), bg)
+    (y * proj.to(dev)).sum().backward()
+    assert rel_l2(y.detach().cpu(), torch.nn.functional.linear(x.double(), W.double(), b.double())) < 2e-6
+    assert rel_l2(xg.grad.cpu(), xd.grad) < 2e-6 and rel_l2(Wg.grad.cpu(), Wd.grad) < 2e-6
+    assert rel_l2(bg.grad.cpu(), bd.grad) < 2e-6
 
 
 @pytest.mark.parametrize("mode,ns,nq,H,c", [("max", 3000, 1100, 37, 64), ("max", 500, 2000, 58, 129), ("closest", 900, 4000, 12, 258),
