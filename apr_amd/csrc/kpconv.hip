@@ -344,6 +344,25 @@ __global__ void k_edge_features(const float* __restrict__ f, int64_t ldf, int n,
   }
 }
 
+// backward of k_edge_features w.r.t. f, first half: the centre's own terms d_center[i] = sum_j (de[(i,j), :c] - de[(i,j), c:])
+// (ascending j: the same bits every run) and the neighbours' terms as contiguous contribution rows contrib[(i,j), :] =
+// de[(i,j), c:], which a gather over the reverse table of knn then adds to the rows they point at (apr_reverse_gather_range).
+__global__ void k_edge_features_bwd(const float* __restrict__ de, int n, int c, int k, float* __restrict__ d_center,
+                                    int64_t ldd, float* __restrict__ contrib) {
+  const int64_t total = (int64_t)n * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / c), col = (int)(t - (int64_t)i * c);
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int64_t e = (int64_t)i * k + j;
+      const float a = de[e * 2 * c + col], b = de[e * 2 * c + c + col];
+      acc += a - b;
+      contrib[e * c + col] = b;
+    }
+    d_center[(int64_t)i * ldd + col] = acc;
+  }
+}
+
 // out[i,:] = max_j act(y[i*k + j,:] * scale + shift)   (InstanceNorm2d + LeakyReLU + max over k)
 __global__ void k_group_max(const float* __restrict__ y, int64_t ldy, int n, int k, int c,
                             const float* __restrict__ scale, const float* __restrict__ shift, float slope,
@@ -941,6 +960,17 @@ APR_API int apr_edge_features(const float* f, int64_t ldf, int32_t n, int32_t c,
   int64_t nblk = cdiv64((int64_t)n * k * c, 256);
   if (nblk > 16384) nblk = 16384;
   hipLaunchKernelGGL(k_edge_features, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, f, ldf, n, c, knn, k, out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_edge_features_backward(const float* de, int32_t n, int32_t c, int32_t k, float* d_center, int64_t ldd,
+                                       float* contrib, void* stream) {
+  APR_CHECK_ARG(n > 0 && c > 0 && k > 0 && de && d_center && contrib && ldd >= c, "apr_edge_features_backward: bad arguments");
+  int64_t nblk = cdiv64((int64_t)n * c, 256);
+  if (nblk > 16384) nblk = 16384;
+  hipLaunchKernelGGL(k_edge_features_bwd, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, de, n, c, k, d_center, ldd,
+                     contrib);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

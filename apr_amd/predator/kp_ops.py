@@ -318,6 +318,46 @@ def edge_features(f, knn):
     return out
 
 
+class EdgeFeaturesFunction(torch.autograd.Function):
+    """get_graph_feature as rows (gcn.py:9-35): e[(i, j)] = [f_i, f_knn(i, j) - f_i], with the input gradient on the HIP
+    kernels: the centre's own terms by apr_edge_features_backward, the neighbours' terms gathered over the reverse table of
+    the kNN graph in table order (apr_reverse_gather_range): deterministic, no float atomics."""
+
+    @staticmethod
+    def forward(ctx, f, knn):
+        knn = _i32(knn, "edge_features.knn").contiguous()
+        ctx.save_for_backward(knn)
+        ctx.n, ctx.c = f.shape
+        return edge_features(f.detach(), knn)
+
+    @staticmethod
+    def backward(ctx, de):
+        knn, = ctx.saved_tensors
+        n, c, k = ctx.n, ctx.c, knn.shape[1]
+        de = de.contiguous()
+        lib = _lib.load()
+        dx = torch.empty((n, c), dtype=torch.float32, device=de.device)
+        contrib = torch.empty((n * k, c), dtype=torch.float32, device=de.device)
+        check(lib.apr_edge_features_backward(ptr(de), n, c, k, ptr(dx), c, ptr(contrib), stream()))
+        rev_t, start = reverse_table(knn, n)
+        check(lib.apr_reverse_gather_range(ptr(contrib), c, ptr(rev_t), ptr(start), n, 0, n * k, 1, ptr(dx), c, stream()))
+        return dx, None
+
+
+_GROUP_INDS = {}
+
+
+def group_rows(n, k, device):
+    """int32 [n, k] = the rows i*k + j of an [n*k, c] edge tensor (cached): max over a point's k edges is max_pool over it."""
+    key = (n, k, device)
+    t = _GROUP_INDS.get(key)
+    if t is None:
+        if len(_GROUP_INDS) > 8:
+            _GROUP_INDS.clear()
+        t = _GROUP_INDS[key] = torch.arange(n * k, dtype=torch.int32, device=device).view(n, k)
+    return t
+
+
 def group_max(y, n, k, scale, shift, slope):
     y, ldy = ops._rows(y, "group_max.y")
     c = y.shape[1]

@@ -18,6 +18,8 @@ from .blocks import _param_key
 
 # the overlap-attention module of a pair through ONE library call (apr_gcn_forward); 0: layer by layer (A/B switch)
 GCN_CALL = os.environ.get("APR_GCN_CALL", "1") != "0"
+# the self-attention layers' edge convolutions in training on the HIP kernels; 0: torch ops (A/B switch)
+EDGE_CONV_TRAIN_HIP = os.environ.get("APR_EDGE_CONV_TRAIN_HIP", "1") != "0"
 
 
 class _Packed:
@@ -82,6 +84,14 @@ class SelfAttention(nn.Module):
     def _edge_conv(self, feats, knn, conv, cache, eps):
         n = feats.shape[0]
         if kp_ops.tracking(feats, conv.weight):
+            k = knn.shape[1]
+            if EDGE_CONV_TRAIN_HIP and feats.dim() == 2 and k <= 255:
+                # training on the HIP kernels: edge features (gradient over the reverse table of the kNN graph), the 1x1
+                # convolution (LinearFunction), InstanceNorm2d + LeakyReLU as one Function over the n*k rows, and the max
+                # over a point's k edges as max_pool over the rows i*k .. i*k + k - 1 (arg-max kept, gather backward)
+                e = kp_ops.EdgeFeaturesFunction.apply(feats, knn)
+                y = kp_ops.instance_norm_act(conv1x1(e, conv, cache), eps=eps, leaky=0.2)
+                return kp_ops.pool_train(y, kp_ops.group_rows(n, k, feats.device), "max")
             ctr = feats.unsqueeze(1).expand(-1, knn.shape[1], -1)
             e = torch.cat((ctr, feats[knn.long()] - ctr), dim=2).reshape(n * knn.shape[1], -1)
             y = kp_ops.instance_norm_rows(conv1x1(e, conv, cache), eps)          # InstanceNorm2d over n*k

@@ -708,6 +708,13 @@ int apr_gather_pool_backward(const float* dout, int64_t lddo, int32_t c, const i
 int apr_edge_features(const float* f, int64_t ldf, int32_t n, int32_t c, const int32_t* knn, int32_t k,
                       float* out, void* stream);
 
+/* Training path (gcn.py:9-35 under Predator_APR/lib/trainer.py:142-280): the input gradient of apr_edge_features from
+ * de f32 [n*k, 2c], first half -- d_center[i] = sum_j (de[(i,j), :c] - de[(i,j), c:]) and the neighbours' terms as
+ * contribution rows contrib f32 [n*k, c] = de[:, c:]; apr_reverse_gather_range over the reverse table of knn (ns = n,
+ * accumulate = 1) then adds every row's contributions in table order: deterministic, no float atomics. */
+int apr_edge_features_backward(const float* de, int32_t n, int32_t c, int32_t k, float* d_center, int64_t ldd,
+                               float* contrib, void* stream);
+
 /* out[i,:] = max_j leaky(y[i*k+j,:] * scale + shift)  (InstanceNorm2d + LeakyReLU(0.2) + max, gcn.py:67-72). */
 int apr_group_max(const float* y, int64_t ldy, int32_t n, int32_t k, int32_t c, const float* scale,
                   const float* shift, float slope, float* out, int64_t ldo, void* stream);

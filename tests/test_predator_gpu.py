@@ -518,3 +518,49 @@ def test_gcn_one_call_equals_the_layer_by_layer_module(dev, n0, n1, c, heads, k,
         assert odd._desc() is None
         y0, y1 = odd(p0, p1, torch.randn(n0, 96, device=dev), torch.randn(n1, 96, device=dev))
         assert y0.shape == (n0, 96) and bool(torch.isfinite(y1).all())
+
+
+@pytest.mark.parametrize("n,c,k", [(700, 64, 10), (333, 128, 6), (1500, 256, 10)])
+def test_self_attention_training_path_gradients(dev, n, c, k):
+    """SelfAttention (gcn.py:38-77) under autograd on the HIP kernels -- edge features with the gradient gathered over the
+    reverse table of the kNN graph (apr_edge_features_backward + apr_reverse_gather_range), 1x1 convolutions as
+    LinearFunction, InstanceNorm2d + LeakyReLU as one Function, max over a point's edges as max_pool with the arg-max kept
+    -- against the same layer written out in fp64 torch ops: output and every gradient; deterministic run to run."""
+    from apr_amd.predator.models import gcn as G
+    torch.manual_seed(n + c)
+    layer = G.SelfAttention(c, k).to(dev).train()
+    pts = torch.randn(n, 3, device=dev) * 4
+    x = torch.randn(n, c, device=dev)
+    proj = torch.randn(n, c, device=dev)
+    knn = point_ops.knn(pts, k, skip_first=True).long()
+
+    def ref(x64, W):
+        def edge_conv(f, w, eps):
+            ctr = f.unsqueeze(1).expand(-1, k, -1)
+            e = torch.cat((ctr, f[knn] - ctr), dim=2).reshape(n * k, -1)
+            y = e @ w.reshape(w.shape[0], w.shape[1]).t()
+            y = (y - y.mean(0, keepdim=True)) / torch.sqrt(y.var(0, unbiased=False, keepdim=True) + eps)
+            return torch.nn.functional.leaky_relu(y, 0.2).reshape(n, k, -1).max(1)[0]
+        x1 = edge_conv(x64, W[0], layer.in1.eps)
+        x2 = edge_conv(x1, W[1], layer.in2.eps)
+        y = torch.cat((x64, x1, x2), 1) @ W[2].reshape(W[2].shape[0], W[2].shape[1]).t()
+        y = (y - y.mean(0, keepdim=True)) / torch.sqrt(y.var(0, unbiased=False, keepdim=True) + layer.in3.eps)
+        return torch.nn.functional.leaky_relu(y, 0.2)
+
+    x64 = x.double().requires_grad_(True)
+    W64 = [w.detach().double().requires_grad_(True) for w in (layer.conv1.weight, layer.conv2.weight, layer.conv3.weight)]
+    out64 = ref(x64, W64)
+    (out64 * proj.double()).sum().backward()
+    grads = []
+    for rep in range(2):
+        layer.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        out = layer(pts, xg)
+        (out * proj).sum().backward()
+        grads.append([xg.grad.clone()] + [w.grad.clone() for w in (layer.conv1.weight, layer.conv2.weight, layer.conv3.weight)])
+    assert rel_l2(out.detach().cpu(), out64.detach().cpu()) < 2e-5
+    assert rel_l2(grads[0][0].cpu(), x64.grad.cpu()) < 1e-4
+    for g, w in zip(grads[0][1:], W64):
+        assert rel_l2(g.cpu(), w.grad.cpu()) < 1e-4
+    for a, b in zip(grads[0], grads[1]):
+        assert torch.equal(a, b)                                  # no float atomics anywhere in the path
