@@ -986,6 +986,142 @@ APR_API int apr_group_max(const float* y, int64_t ldy, int32_t n, int32_t k, int
   return APR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-head attention for the TRAINING path (gcn.py:94-116 under lib/trainer.py:142-280): forward with the probabilities
+// kept, backward from them.  Channel c = d * heads + h as the reference's view(-1, dim, heads).  The coarsest level holds
+// ~1.4 k points per cloud: P [heads, n, m] is 31 MB, materialised once; every sum runs in a fixed order (no float atomics:
+// the same bits every run).  Plain VALU kernels -- the inference path keeps k_mha_mfma.
+//   k_mha_probs    block per (h, i): S_j = <q_i, k_j> / sqrt(dim) over the head's channels, P = softmax_j(S)
+//   k_mha_rowmat   out[i, d*H + h] = scale * sum_j A[h, i, j] X[j, d*H + h]      (O = P V;  dQ = dS K / sqrt(dim))
+//   k_mha_colmat   out[j, d*H + h] = scale * sum_i A[h, i, j] X[i, d*H + h]      (dV = P^T dO;  dK = dS^T Q / sqrt(dim))
+//   k_mha_ds       block per (h, i): dP_j = <dO_i, v_j>,  D = sum_j P_j dP_j,  dS_j = P_j (dP_j - D)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline float block_reduce_256(float v, bool is_max, float* s_red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float o = __shfl_xor(v, d);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();                        // s_red may still be read from the previous reduction
+  if ((threadIdx.x & 63) == 0) s_red[wave] = v;
+  __syncthreads();
+  float r = s_red[0];
+  for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, s_red[w]) : r + s_red[w];      // fixed order
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_mha_probs(const float* __restrict__ q, const float* __restrict__ k, int n, int m, int dim,
+                                                   int H, float* __restrict__ P) {
+  extern __shared__ float s_q[];      // [dim] the query's head vector, then 4 reduction slots
+  float* s_red = s_q + dim;
+  const int h = blockIdx.x % H, i = blockIdx.x / H;
+  const int c = dim * H;
+  for (int d = threadIdx.x; d < dim; d += 256) s_q[d] = q[(int64_t)i * c + d * H + h];
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)dim);
+  float* row = P + ((int64_t)h * n + i) * m;
+  float mx = -__builtin_inff();
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const float* kj = k + (int64_t)j * c + h;
+    float acc = 0.f;
+    for (int d = 0; d < dim; ++d) acc += s_q[d] * kj[d * H];
+    acc *= scale;
+    row[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = block_reduce_256(mx, true, s_red);
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const float e = __expf(row[j] - mx);
+    row[j] = e;
+    sum += e;
+  }
+  sum = block_reduce_256(sum, false, s_red);
+  const float inv = 1.0f / sum;
+  for (int j = threadIdx.x; j < m; j += 256) row[j] *= inv;
+}
+
+// thread per (i, channel): the head's row of A is walked in j order
+__global__ void k_mha_rowmat(const float* __restrict__ A, const float* __restrict__ X, int n, int m, int dim, int H, float scale,
+                             float* __restrict__ out) {
+  const int c = dim * H;
+  const int64_t total = (int64_t)n * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / c), ch = (int)(t - (int64_t)i * c), h = ch % H;
+    const float* a = A + ((int64_t)h * n + i) * m;
+    float acc = 0.f;
+    for (int j = 0; j < m; ++j) acc += a[j] * X[(int64_t)j * c + ch];
+    out[t] = acc * scale;
+  }
+}
+
+// thread per (j, channel): the head's column of A is walked in i order
+__global__ void k_mha_colmat(const float* __restrict__ A, const float* __restrict__ X, int n, int m, int dim, int H, float scale,
+                             float* __restrict__ out) {
+  const int c = dim * H;
+  const int64_t total = (int64_t)m * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(t / c), ch = (int)(t - (int64_t)j * c), h = ch % H;
+    const float* a = A + (int64_t)h * n * m + j;
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += a[(int64_t)i * m] * X[(int64_t)i * c + ch];
+    out[t] = acc * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mha_ds(const float* __restrict__ P, const float* __restrict__ dO, const float* __restrict__ v,
+                                                int n, int m, int dim, int H, float* __restrict__ dS) {
+  extern __shared__ float s_q[];      // [dim] dO_i's head vector, then 4 reduction slots
+  float* s_red = s_q + dim;
+  const int h = blockIdx.x % H, i = blockIdx.x / H;
+  const int c = dim * H;
+  for (int d = threadIdx.x; d < dim; d += 256) s_q[d] = dO[(int64_t)i * c + d * H + h];
+  __syncthreads();
+  const float* p = P + ((int64_t)h * n + i) * m;
+  float* ds = dS + ((int64_t)h * n + i) * m;
+  float dsum = 0.f;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const float* vj = v + (int64_t)j * c + h;
+    float acc = 0.f;
+    for (int d = 0; d < dim; ++d) acc += s_q[d] * vj[d * H];
+    ds[j] = acc;                       // dP_j for now
+    dsum += p[j] * acc;
+  }
+  const float D = block_reduce_256(dsum, false, s_red);
+  for (int j = threadIdx.x; j < m; j += 256) ds[j] = p[j] * (ds[j] - D);
+}
+
+APR_API int apr_mha_train_forward(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
+                                  float* P, float* out, void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0 && dim <= 1024 && q && k && v && P && out, "apr_mha_train_forward: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mha_probs, dim3((unsigned)(n * heads)), dim3(256), (size_t)(dim + 4) * 4, st, q, k, n, m, dim, heads, P);
+  int64_t nblk = cdiv64((int64_t)n * dim * heads, 256);
+  hipLaunchKernelGGL(k_mha_rowmat, dim3((unsigned)(nblk > 16384 ? 16384 : nblk)), dim3(256), 0, st, P, v, n, m, dim, heads, 1.0f,
+                     out);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_mha_train_backward(const float* q, const float* k, const float* v, const float* P, const float* dout, int32_t n,
+                                   int32_t m, int32_t dim, int32_t heads, float* dS, float* dq, float* dk, float* dv,
+                                   void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0 && dim <= 1024 && q && k && v && P && dout && dS && dq && dk && dv,
+                "apr_mha_train_backward: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)dim);
+  int64_t nb_n = cdiv64((int64_t)n * dim * heads, 256), nb_m = cdiv64((int64_t)m * dim * heads, 256);
+  nb_n = nb_n > 16384 ? 16384 : nb_n;
+  nb_m = nb_m > 16384 ? 16384 : nb_m;
+  hipLaunchKernelGGL(k_mha_colmat, dim3((unsigned)nb_m), dim3(256), 0, st, P, dout, n, m, dim, heads, 1.0f, dv);
+  hipLaunchKernelGGL(k_mha_ds, dim3((unsigned)(n * heads)), dim3(256), (size_t)(dim + 4) * 4, st, P, dout, v, n, m, dim, heads, dS);
+  hipLaunchKernelGGL(k_mha_rowmat, dim3((unsigned)nb_n), dim3(256), 0, st, dS, k, n, m, dim, heads, scale, dq);
+  hipLaunchKernelGGL(k_mha_colmat, dim3((unsigned)nb_m), dim3(256), 0, st, dS, q, n, m, dim, heads, scale, dk);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
 APR_API int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
                     float* out, void* stream) {
   APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0, "apr_mha: bad arguments");

@@ -374,6 +374,37 @@ def mha(q, k, v, heads):
     return out
 
 
+class MHAFunction(torch.autograd.Function):
+    """Multi-head softmax attention (gcn.py:94-116, channel c = d*heads + h) with forward and backward on the HIP kernels
+    (apr_mha_train_forward / _backward): the forward keeps the probabilities, every sum has a fixed order."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        n, c = q.shape
+        m = k.shape[0]
+        P = torch.empty((heads, n, m), dtype=torch.float32, device=q.device)
+        out = torch.empty_like(q)
+        check(_lib.load().apr_mha_train_forward(ptr(q), ptr(k), ptr(v), n, m, c // heads, heads, ptr(P), ptr(out), stream()))
+        ctx.save_for_backward(q, k, v, P)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, P = ctx.saved_tensors
+        heads = ctx.heads
+        n, c = q.shape
+        m = k.shape[0]
+        dout = dout.contiguous()
+        dS = torch.empty_like(P)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(_lib.load().apr_mha_train_backward(ptr(q), ptr(k), ptr(v), ptr(P), ptr(dout), n, m, c // heads, heads, ptr(dS),
+                                                 ptr(dq), ptr(dk), ptr(dv), stream()))
+        return dq, dk, dv, None
+
+
+HIP_TRAIN_MHA = os.environ.get("APR_HIP_TRAIN_MHA", "1") != "0"     # A/B switch: 0 = the attention of the training path on torch ops
 MHA_MFMA = os.environ.get("APR_MHA", "mfma") != "scalar"      # A/B switch: the scalar kernel on interleaved channels
 
 

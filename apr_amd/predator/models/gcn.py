@@ -142,6 +142,9 @@ class MultiHeadedAttention(nn.Module):
             x = kp_ops.mha_headmajor(q, k, v, self.num_heads)
             return conv1x1(x, self.merge, self._c[3])
         q, k, v = [conv1x1(x, l, c) for l, x, c in zip(self.proj, (query, key, value), self._c[:3])]
+        if kp_ops.tracking(q, k, v) and kp_ops.HIP_TRAIN_MHA:
+            # training: softmax attention forward (probabilities kept) and backward on the HIP kernels
+            return conv1x1(kp_ops.MHAFunction.apply(q, k, v, self.num_heads), self.merge, self._c[3])
         if kp_ops.tracking(q, k, v):
             qh, kh, vh = (t.view(-1, self.dim, self.num_heads) for t in (q, k, v))      # channel c = d*heads + h
             prob = torch.softmax(torch.einsum('ndh,mdh->hnm', qh, kh) / self.dim ** .5, dim=-1)

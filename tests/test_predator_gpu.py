@@ -564,3 +564,31 @@ def test_self_attention_training_path_gradients(dev, n, c, k):
         assert rel_l2(g.cpu(), w.grad.cpu()) < 1e-4
     for a, b in zip(grads[0], grads[1]):
         assert torch.equal(a, b)                                  # no float atomics anywhere in the path
+
+
+@pytest.mark.parametrize("n,m,heads,dim", [(300, 417, 4, 64), (1000, 1400, 4, 64), (64, 50, 2, 32), (5, 700, 1, 16)])
+def test_mha_training_function_gradients(dev, n, m, heads, dim):
+    """kp_ops.MHAFunction (gcn.py:94-116, channel c = d*heads + h): forward and d q / d k / d v on the HIP kernels
+    (apr_mha_train_forward / _backward, probabilities kept, fixed summation orders) against fp64 autograd through the
+    reference's einsum formulation; the inference kernel gives the same forward; the same bits run to run."""
+    rng = np.random.default_rng(n + m)
+    c = heads * dim
+    q, k, v = (torch.from_numpy(rng.standard_normal((r, c)).astype(np.float32)) for r in (n, m, m))
+    proj = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32))
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(-1, dim, heads) for t in (qd, kd, vd))
+    prob = torch.softmax(torch.einsum('ndh,mdh->hnm', qh, kh) / dim ** .5, dim=-1)
+    ref = torch.einsum('hnm,mdh->ndh', prob, vh).reshape(n, -1)
+    (ref * proj.double()).sum().backward()
+    runs = []
+    for rep in range(2):
+        qg, kg, vg = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        out = kp_ops.MHAFunction.apply(qg, kg, vg, heads)
+        (out * proj.to(dev)).sum().backward()
+        runs.append((out.detach(), qg.grad, kg.grad, vg.grad))
+    out, dq, dk, dv = runs[0]
+    assert rel_l2(out.cpu(), ref.detach()) < 5e-6
+    assert rel_l2(dq.cpu(), qd.grad) < 2e-5 and rel_l2(dk.cpu(), kd.grad) < 2e-5 and rel_l2(dv.cpu(), vd.grad) < 2e-5
+    assert rel_l2(kp_ops.mha(q.to(dev), k.to(dev), v.to(dev), heads).cpu(), ref.detach()) < 5e-6
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
