@@ -82,8 +82,8 @@ class GcnDesc(C.Structure):
 # name -> (restype, argtypes); every symbol include/apr_hip.h declares
 PROTOTYPES = {
     "apr_col_sums": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _sz, _p]),
-    "apr_mha_train_forward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
-    "apr_mha_train_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "apr_mha_train_forward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "apr_mha_train_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "apr_edge_features_backward": (C.c_int, [_p, _i32, _i32, _i32, _p, _i64, _p, _p]),
     "apr_gcn_scratch_bytes": (_sz, [_p, _i32, _i32]),
     "apr_gcn_forward": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _sz, _p]),

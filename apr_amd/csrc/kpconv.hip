@@ -1092,32 +1092,38 @@ __global__ __launch_bounds__(256) void k_mha_ds(const float* __restrict__ P, con
   for (int j = threadIdx.x; j < m; j += 256) ds[j] = p[j] * (ds[j] - D);
 }
 
+// vdim: channels per head of v / out / dout (0: the same as dim; 1 with heads = 1: the cross-saliency softmax(<a, b> / T) @ s
+// of architectures.py:176-181, with q pre-scaled by sqrt(dim) / T)
 APR_API int apr_mha_train_forward(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
-                                  float* P, float* out, void* stream) {
-  APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0 && dim <= 1024 && q && k && v && P && out, "apr_mha_train_forward: bad arguments");
+                                  int32_t vdim, float* P, float* out, void* stream) {
+  if (vdim <= 0) vdim = dim;
+  APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0 && dim <= 1024 && vdim <= 1024 && q && k && v && P && out,
+                "apr_mha_train_forward: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_mha_probs, dim3((unsigned)(n * heads)), dim3(256), (size_t)(dim + 4) * 4, st, q, k, n, m, dim, heads, P);
-  int64_t nblk = cdiv64((int64_t)n * dim * heads, 256);
-  hipLaunchKernelGGL(k_mha_rowmat, dim3((unsigned)(nblk > 16384 ? 16384 : nblk)), dim3(256), 0, st, P, v, n, m, dim, heads, 1.0f,
+  int64_t nblk = cdiv64((int64_t)n * vdim * heads, 256);
+  hipLaunchKernelGGL(k_mha_rowmat, dim3((unsigned)(nblk > 16384 ? 16384 : nblk)), dim3(256), 0, st, P, v, n, m, vdim, heads, 1.0f,
                      out);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
 
 APR_API int apr_mha_train_backward(const float* q, const float* k, const float* v, const float* P, const float* dout, int32_t n,
-                                   int32_t m, int32_t dim, int32_t heads, float* dS, float* dq, float* dk, float* dv,
+                                   int32_t m, int32_t dim, int32_t heads, int32_t vdim, float* dS, float* dq, float* dk, float* dv,
                                    void* stream) {
-  APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0 && dim <= 1024 && q && k && v && P && dout && dS && dq && dk && dv,
+  if (vdim <= 0) vdim = dim;
+  APR_CHECK_ARG(n > 0 && m > 0 && dim > 0 && heads > 0 && dim <= 1024 && vdim <= 1024 && q && k && v && P && dout && dS && dq && dk && dv,
                 "apr_mha_train_backward: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)dim);
-  int64_t nb_n = cdiv64((int64_t)n * dim * heads, 256), nb_m = cdiv64((int64_t)m * dim * heads, 256);
-  nb_n = nb_n > 16384 ? 16384 : nb_n;
-  nb_m = nb_m > 16384 ? 16384 : nb_m;
-  hipLaunchKernelGGL(k_mha_colmat, dim3((unsigned)nb_m), dim3(256), 0, st, P, dout, n, m, dim, heads, 1.0f, dv);
-  hipLaunchKernelGGL(k_mha_ds, dim3((unsigned)(n * heads)), dim3(256), (size_t)(dim + 4) * 4, st, P, dout, v, n, m, dim, heads, dS);
-  hipLaunchKernelGGL(k_mha_rowmat, dim3((unsigned)nb_n), dim3(256), 0, st, dS, k, n, m, dim, heads, scale, dq);
-  hipLaunchKernelGGL(k_mha_colmat, dim3((unsigned)nb_m), dim3(256), 0, st, dS, q, n, m, dim, heads, scale, dk);
+  auto blocks = [](int64_t rows, int ch) {
+    int64_t b = cdiv64(rows * ch, 256);
+    return (unsigned)(b > 16384 ? 16384 : b);
+  };
+  hipLaunchKernelGGL(k_mha_colmat, dim3(blocks(m, vdim * heads)), dim3(256), 0, st, P, dout, n, m, vdim, heads, 1.0f, dv);
+  hipLaunchKernelGGL(k_mha_ds, dim3((unsigned)(n * heads)), dim3(256), (size_t)(vdim + 4) * 4, st, P, dout, v, n, m, vdim, heads, dS);
+  hipLaunchKernelGGL(k_mha_rowmat, dim3(blocks(n, dim * heads)), dim3(256), 0, st, dS, k, n, m, dim, heads, scale, dq);
+  hipLaunchKernelGGL(k_mha_colmat, dim3(blocks(m, dim * heads)), dim3(256), 0, st, dS, q, n, m, dim, heads, scale, dk);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import torch
@@ -382,10 +383,11 @@ class MHAFunction(torch.autograd.Function):
     def forward(ctx, q, k, v, heads):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         n, c = q.shape
-        m = k.shape[0]
+        m, cv = k.shape[0], v.shape[1]          # v may be narrower than q / k (the cross saliency: one column)
         P = torch.empty((heads, n, m), dtype=torch.float32, device=q.device)
-        out = torch.empty_like(q)
-        check(_lib.load().apr_mha_train_forward(ptr(q), ptr(k), ptr(v), n, m, c // heads, heads, ptr(P), ptr(out), stream()))
+        out = torch.empty((n, cv), dtype=torch.float32, device=q.device)
+        check(_lib.load().apr_mha_train_forward(ptr(q), ptr(k), ptr(v), n, m, c // heads, heads, cv // heads, ptr(P), ptr(out),
+                                                stream()))
         ctx.save_for_backward(q, k, v, P)
         ctx.heads = heads
         return out
@@ -395,13 +397,22 @@ class MHAFunction(torch.autograd.Function):
         q, k, v, P = ctx.saved_tensors
         heads = ctx.heads
         n, c = q.shape
-        m = k.shape[0]
+        m, cv = k.shape[0], v.shape[1]
         dout = dout.contiguous()
         dS = torch.empty_like(P)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        check(_lib.load().apr_mha_train_backward(ptr(q), ptr(k), ptr(v), ptr(P), ptr(dout), n, m, c // heads, heads, ptr(dS),
-                                                 ptr(dq), ptr(dk), ptr(dv), stream()))
+        check(_lib.load().apr_mha_train_backward(ptr(q), ptr(k), ptr(v), ptr(P), ptr(dout), n, m, c // heads, heads, cv // heads,
+                                                 ptr(dS), ptr(dq), ptr(dk), ptr(dv), stream()))
         return dq, dk, dv, None
+
+
+def softmax_matvec_train(a, b, w, temperature):
+    """softmax_j(<a_i, b_j> / temperature) @ w under autograd on the HIP attention kernels (one head, one value column):
+    the scores are <q_i, b_j> / sqrt(c) with q = a * (sqrt(c) / temperature) -- that scaling is the only torch op, and it
+    carries the gradient of the learned temperature."""
+    c = a.shape[1]
+    q = a * (math.sqrt(c) / temperature)
+    return MHAFunction.apply(q, b, w.reshape(-1, 1), 1).reshape(-1)
 
 
 HIP_TRAIN_MHA = os.environ.get("APR_HIP_TRAIN_MHA", "1") != "0"     # A/B switch: 0 = the attention of the training path on torch ops

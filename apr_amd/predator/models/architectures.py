@@ -230,7 +230,10 @@ class KPFCNN(nn.Module):
             a, b = row0 + lens_c[p], row0 + lens_c[p] + lens_c[p + 1]
             src_n, tgt_n = feats_gnn_norm[row0:a], feats_gnn_norm[a:b]
             src_s, tgt_s = scores_c_raw[row0:a], scores_c_raw[a:b]
-            if grad:    # architectures.py:176-181 (the N_c x N_c product is ~1 k x 1 k at the coarsest level)
+            if grad and kp_ops.HIP_TRAIN_MHA:    # architectures.py:176-181 on the attention kernels of the training path
+                sal_rows += [kp_ops.softmax_matvec_train(src_n, tgt_n, tgt_s, temperature).unsqueeze(1),
+                             kp_ops.softmax_matvec_train(tgt_n, src_n, src_s, temperature).unsqueeze(1)]
+            elif grad:    # the same with torch ops (the N_c x N_c product is ~1 k x 1 k at the coarsest level)
                 inner = torch.matmul(src_n, tgt_n.t())
                 sal_rows += [torch.matmul(torch.softmax(inner / temperature, dim=1), tgt_s),
                              torch.matmul(torch.softmax(inner.t() / temperature, dim=1), src_s)]

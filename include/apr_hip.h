@@ -727,9 +727,12 @@ int apr_mha(const float* q, const float* k, const float* v, int32_t n, int32_t m
  * P f32 [heads, n, m]; the backward turns them and dout f32 [n, dim*heads] into dq, dk, dv (dS f32 [heads, n, m]: scratch).
  * Fixed summation orders, no float atomics: the same bits every run.  No limit on m. */
 int apr_mha_train_forward(const float* q, const float* k, const float* v, int32_t n, int32_t m, int32_t dim, int32_t heads,
-                          float* P, float* out, void* stream);
+                          int32_t vdim, float* P, float* out, void* stream);
 int apr_mha_train_backward(const float* q, const float* k, const float* v, const float* P, const float* dout, int32_t n,
-                           int32_t m, int32_t dim, int32_t heads, float* dS, float* dq, float* dk, float* dv, void* stream);
+                           int32_t m, int32_t dim, int32_t heads, int32_t vdim, float* dS, float* dq, float* dk, float* dv,
+                           void* stream);
+/* vdim: channels per head of v / out / dout (0: = dim).  vdim = 1 with heads = 1 is the cross-saliency
+ * softmax(<a_i, b_j> / T) @ s of Predator_APR/models/architectures.py:176-181 (q = a * sqrt(dim) / T). */
 
 /* apr_mha with q / k / v handed over HEAD-MAJOR (channel h*dim + d: the caller permutes the output channels of the
  * three projections, gcn.py:101-108) and out in apr_mha's interleaved layout; fp32 MFMA, dim = 64 only, q / k / v

@@ -592,3 +592,25 @@ def test_mha_training_function_gradients(dev, n, m, heads, dim):
     assert rel_l2(kp_ops.mha(q.to(dev), k.to(dev), v.to(dev), heads).cpu(), ref.detach()) < 5e-6
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,m,c", [(1300, 1450, 256), (90, 40, 64)])
+def test_cross_saliency_training_function_gradients(dev, n, m, c):
+    """softmax(<a_i, b_j> / T) @ s (architectures.py:176-181) under autograd on the training-path attention kernels (one head,
+    a one-column value): output and the gradients of a, b, s AND of the learned temperature against fp64 autograd."""
+    rng = np.random.default_rng(n)
+    a = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)), dim=1)
+    b = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32)), dim=1)
+    s_ = torch.from_numpy(rng.standard_normal((m, 1)).astype(np.float32))
+    proj = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+    eps = torch.tensor(-1.3)
+    ad, bd, sd, ed = (t.double().requires_grad_(True) for t in (a, b, s_, eps))
+    ref = (torch.softmax(ad @ bd.t() / (torch.exp(ed) + 0.03), dim=1) @ sd).reshape(-1)
+    (ref * proj.double()).sum().backward()
+    ag, bg, sg, eg = (t.to(dev).requires_grad_(True) for t in (a, b, s_, eps))
+    out = kp_ops.softmax_matvec_train(ag, bg, sg, torch.exp(eg) + 0.03)
+    (out * proj.to(dev)).sum().backward()
+    assert rel_l2(out.detach().cpu(), ref.detach()) < 1e-5
+    for g, d in ((ag, ad), (bg, bd), (sg, sd), (eg, ed)):
+        assert rel_l2(g.grad.cpu(), d.grad) < 1e-4
+    assert rel_l2(kp_ops.softmax_matvec(a.to(dev), b.to(dev), s_.to(dev), float(torch.exp(eps) + 0.03)).cpu(), ref.detach()) < 1e-5
