@@ -208,6 +208,7 @@ def test_one_call_front_end_equals_the_tensor_by_tensor_front_end(dev, monkeypat
     cases = [[torch.from_numpy(synth.make_small_frame(s)).to(dev) for s in (0, 1)],
              [torch.from_numpy(synth.make_frame(s)).to(dev) for s in (0, 1, 2)],
              [torch.from_numpy((rng.standard_normal((n, 3)) * 20).astype(np.float32)).to(dev) for n in (5000, 1, 7321, 256)],
+             [torch.from_numpy((rng.standard_normal((n, 3)) * 20).astype(np.float32)).to(dev) for n in (300, 0, 4100)],      # an empty frame in the middle
              [torch.from_numpy(synth.make_frame(3)).to(dev)]]
     for clouds in cases:
         monkeypatch.setattr(P, "FRONT_END_CALL", False)
