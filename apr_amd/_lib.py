@@ -95,6 +95,7 @@ PROTOTYPES = {
     "apr_last_error": (C.c_char_p, []),
     "apr_version": (C.c_int, []),
     "apr_device_count": (C.c_int, []),
+    "apr_struct_sizes": (_i32, [_p, _i32]),
     "apr_event_wait": (C.c_int, [_p, _i32]),
     "apr_hash_capacity": (_i64, [_i64]),
     "apr_map_scratch_bytes": (_sz, [_i64]),

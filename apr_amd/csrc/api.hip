@@ -18,6 +18,17 @@ APR_API const char* apr_last_error(void) { return g_err; }
 
 APR_API int apr_version(void) { return 100; }
 
+// sizeof of every struct that crosses the boundary, in declaration order: a binding checks its own layout against these
+// (tests/test_library_cpu.py does for apr_amd/_lib.py): a field added on one side only would otherwise corrupt silently
+APR_API int32_t apr_struct_sizes(int32_t* out, int32_t n) {
+  const int32_t sizes[] = {(int32_t)sizeof(apr_pair_desc),     (int32_t)sizeof(apr_spconv_desc),  (int32_t)sizeof(apr_resunet_layer),
+                           (int32_t)sizeof(apr_resunet_plan),  (int32_t)sizeof(apr_level_map),    (int32_t)sizeof(apr_pyramid),
+                           (int32_t)sizeof(apr_kp_resnet_desc), (int32_t)sizeof(apr_gcn_layer),   (int32_t)sizeof(apr_gcn_desc)};
+  const int32_t have = (int32_t)(sizeof(sizes) / sizeof(sizes[0]));
+  for (int32_t i = 0; i < have && i < n && out; ++i) out[i] = sizes[i];
+  return have;
+}
+
 APR_API int apr_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {

@@ -38,6 +38,10 @@ const char* apr_last_error(void);
 int apr_version(void);
 /* Number of HIP devices visible; does not initialise a context. */
 int apr_device_count(void);
+/* sizeof of the structs of this header, in declaration order (apr_pair_desc, apr_spconv_desc, apr_resunet_layer,
+ * apr_resunet_plan, apr_level_map, apr_pyramid, apr_kp_resnet_desc, apr_gcn_layer, apr_gcn_desc) -> out[0 .. n); returns how
+ * many there are.  A binding compares them with its own layout at load time. */
+int32_t apr_struct_sizes(int32_t* out, int32_t n);
 /* Host wait for a HIP event (hipEvent_t) by hipEventQuery + nanosleep(poll_us): no spinning CPU (hipEventSynchronize spins on
  * this stack even for hipEventBlockingSync events) and, called through ctypes, no interpreter lock held while waiting.  The
  * reference's loop blocks in `.cpu()` / `.item()` at the same places (FCGF_APR/scripts/test_apr.py:137-146). */

@@ -21,6 +21,44 @@ def test_library_loads_and_exports_every_declared_symbol(lib):
     assert lib.apr_version() >= 100
 
 
+def test_struct_layouts_of_the_binding_match_the_library(lib):
+    """Every struct that crosses the C ABI has the same size in apr_amd/_lib.py (ctypes) as in the compiled library
+    (apr_struct_sizes): a field added on one side only would corrupt descriptors silently."""
+    import ctypes as C
+    from apr_amd import _lib
+    mine = [_lib.PairDesc, _lib.SpconvDesc, _lib.ResunetLayer, _lib.ResunetPlan, _lib.LevelMap, _lib.Pyramid, _lib.KpResnetDesc,
+            _lib.GcnLayer, _lib.GcnDesc]
+    out = (C.c_int32 * 16)()
+    n = lib.apr_struct_sizes(out, 16)
+    assert n == len(mine)
+    assert [C.sizeof(t) for t in mine] == list(out[:n])
+
+
+def test_stage_level_entries_size_and_reject_without_a_gpu(lib):
+    """apr_voxel_pyramid / apr_resunet_encode / apr_gcn_forward: the sizing walks run on the host (dry run of the same walk
+    that launches), bad descriptors are rejected before any launch."""
+    import ctypes as C
+    from apr_amd import _lib
+    assert lib.apr_voxel_pyramid_scratch_bytes(0, 2) == 0 and lib.apr_voxel_pyramid_scratch_bytes(1000, 0) == 0
+    assert lib.apr_voxel_pyramid_scratch_bytes(1000, 65) == 0                       # more than APR_MAX_FRAMES
+    small, big = lib.apr_voxel_pyramid_scratch_bytes(40000, 2), lib.apr_voxel_pyramid_scratch_bytes(1400000, 12)
+    assert 40000 * 40 < small < big < (1 << 30)
+    plan, lv, box = _lib.ResunetPlan(), (_lib.LevelMap * 4)(), (C.c_int32 * 8)(0, 0, 0, 10, 10, 10, 0, 0)
+    assert lib.apr_resunet_encode_supported(C.byref(plan), lv, box) == 0            # empty plan / maps
+    assert lib.apr_resunet_encode_scratch_bytes(C.byref(plan), lv, box) == 0
+    assert lib.apr_resunet_encode(C.byref(plan), lv, box, None, 0, None, 0, None, 32, None) == -1
+    assert b"not covered" in lib.apr_last_error()
+    d = _lib.GcnDesc()
+    assert lib.apr_gcn_scratch_bytes(C.byref(d), 100, 100) == 0                     # no layers
+    d.n_layers, d.c = 1, 96
+    d.layer[0].kind, d.layer[0].k = 0, 10
+    assert lib.apr_gcn_scratch_bytes(C.byref(d), 100, 100) == 0                     # c % 64 != 0
+    d.c = 256
+    d.layer[0].w1 = d.layer[0].w2 = d.layer[0].w3 = 1                               # non-NULL stand-ins: only sized, never read
+    assert lib.apr_gcn_scratch_bytes(C.byref(d), 1400, 1300) > 1400 * 10 * 512 * 4
+    assert lib.apr_gcn_scratch_bytes(C.byref(d), 5, 1300) == 0                      # fewer points than neighbours asked for
+
+
 def test_host_side_sizing_helpers(lib):
     assert lib.apr_hash_capacity(0) == 1024
     assert lib.apr_hash_capacity(15000) == 32768
