@@ -39,3 +39,22 @@ def test_bench_config4_mode_shards_the_pair_list(dev):
     cfg = out["config"]
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and cfg["pairs_total"] == 14
     assert cfg["pairs_this_rank"] == 7 and cfg["poses_gathered"] == [14, 4, 4]
+
+
+def test_bench_under_torch_distributed_run_the_drivers_launch_form(dev):
+    """The driver's N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ... -- here with 2 ranks over gloo on the one GPU of the box: ONE JSON line from rank 0
+    with both ranks in it, and no second launch by bench.py itself (WORLD_SIZE is set)."""
+    from apr_amd.shard import free_port
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(APR_BENCH_BACKEND="gloo", APR_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--pool", "3", "--no-workloads", "--no-cpu-baseline", "--no-roofline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["config"]["per_rank_pairs_per_s"]) == 2
+    assert "launching 2 ranks" not in p.stderr
