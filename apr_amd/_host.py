@@ -45,3 +45,20 @@ def limit_cpu_threads():
         warnings.warn(f"apr_amd: capping torch's intra-op CPU pool at {cap} threads (was {torch.get_num_threads()}; cgroup "
                       f"quota {cpu_quota()} CPUs); APR_CPU_THREADS=0 leaves it alone", RuntimeWarning, stacklevel=2)
         torch.set_num_threads(cap)
+
+
+def cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this process' cgroup so far (cpu.stat; cgroup v2, then v1), or None.  A quota that
+    runs out stalls EVERY thread of the cgroup until the 100 ms period ends: a benchmark window that overlaps such a period
+    -- its own start-up burst, or another process of the same container -- shows it as a gap of up to 0.1 s."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            kv = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if "nr_throttled" in kv:
+            t = kv.get("throttled_usec")
+            if t is None and "throttled_time" in kv:       # v1: nanoseconds
+                t = int(kv["throttled_time"]) // 1000
+            return int(kv["nr_throttled"]), int(t or 0)
+    return None

@@ -1385,6 +1385,14 @@ static void launch_pack(const RansacScratch& r, const float* xyz0, const float* 
     hipLaunchKernelGGL(k_pack_small, dim3((unsigned)cdiv64(n0 + 32, 256)), dim3(256), 0, st, r.rec, n0, r.maxn2, r.rec8);
 }
 
+// Which sampling kernel: k_sample_screen takes the first edge out of a 112 KB table in LDS -- 27 us against 45 for
+// k_sample_check alone on the card, but it owns a CU's whole LDS while it runs, and with several steps in flight on streams
+// of the caller's that costs more than it saves (2634 vs 2654 pairs/s, three alternating runs each: the LDS-heavy conv
+// kernels of the other steps cannot share its CUs).  So: the screen for a caller with ONE step in flight, the plain kernel
+// for a pipelined one -- apr_ransac_set_screen (like the match lanes: the library cannot see the caller's streams);
+// -1 = APR_RANSAC_SCREEN from the environment (default 1, read per call: the A/B and test hook).
+static std::atomic<int> g_ransac_screen{-1};
+
 // k_sample_screen's dynamic LDS (up to 160 KB) needs the per-device opt-in, once, under a lock (several host threads call in)
 static bool screen_ready() {
   static std::mutex s_mu;
@@ -1436,7 +1444,9 @@ static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dis
   // many iterations over a table that fits the LDS: the first edge is screened there (k_sample_screen; same candidates).
   // APR_RANSAC_SCREEN=0 (read per call: the A/B and test hook) keeps the plain kernel.
   const int64_t niter = it1 - it0;
-  if (niter >= 64 * kScreenRound && n0 <= kScreenMaxN0 && env_int("APR_RANSAC_SCREEN", 1) && screen_ready()) {
+  const int screen_set = g_ransac_screen.load(std::memory_order_relaxed);
+  const int want_screen = screen_set >= 0 ? screen_set : env_int("APR_RANSAC_SCREEN", 1);
+  if (niter >= 64 * kScreenRound && n0 <= kScreenMaxN0 && want_screen && screen_ready()) {
     const int64_t swg = 256;                                     // one 1024-thread workgroup per CU; a multiple of kCandLists
     const int64_t per_wg = cdiv64(niter, swg);
     sub_cap = (int)((swg / kCandLists) * per_wg);                // <= niter / 64 + 4: inside the candidate region
@@ -1692,6 +1702,14 @@ int side_streams(hipStream_t caller, SideStreams* out) {
 // Streams the pairs of a batch are dealt over (1 .. 4; see match_lanes above).  Takes effect for the calls that follow; a
 // batch enqueued with a scratch sized under a smaller setting simply runs on the lanes that scratch holds, and the finish
 // call of a batch in flight does not depend on the setting (layout above).
+// 1: k_sample_screen (lowest latency alone on the card), 0: k_sample_check (friendlier to other streams' kernels), -1: the
+// environment's APR_RANSAC_SCREEN (default 1).  Same candidates either way.  Takes effect for the calls that follow.
+APR_API int apr_ransac_set_screen(int32_t mode) {
+  APR_CHECK_ARG(mode >= -1 && mode <= 1, "apr_ransac_set_screen: mode -1, 0 or 1");
+  g_ransac_screen.store(mode, std::memory_order_relaxed);
+  return APR_OK;
+}
+
 APR_API int apr_match_pose_set_lanes(int32_t lanes) {
   APR_CHECK_ARG(lanes >= 1 && lanes <= kMaxLanes, "apr_match_pose_set_lanes: 1 .. %d lanes", kMaxLanes);
   g_match_lanes.store(lanes, std::memory_order_relaxed);

@@ -1130,6 +1130,13 @@ def kernel_map_occ(out_map: CoordMap, in_map: CoordMap, kernel_size: int, scale:
     return nbr
 
 
+def set_ransac_screen(mode):
+    """Which RANSAC sampling kernel the calls that follow use (apr_ransac_set_screen): True = the LDS-screened one (lowest
+    latency with ONE step in flight), False = the plain one (friendlier to the kernels of other streams: a pipelined caller),
+    None = the environment's APR_RANSAC_SCREEN (default on).  Same candidates either way."""
+    check(_lib_().apr_ransac_set_screen(-1 if mode is None else int(bool(mode))))
+
+
 def set_match_lanes(lanes):
     """Streams the pairs of a `match_pose_batch` are dealt over inside libapr_hip (apr_match_pose_set_lanes; 1 .. 4)."""
     check(_lib_().apr_match_pose_set_lanes(int(lanes)))

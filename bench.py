@@ -186,6 +186,12 @@ def extra_workloads(dev, log):
     from apr_amd import MinkowskiEngine as ME
     from apr_amd import ops, synth
     from apr_amd.fcgf.lib import apg
+
+    def screen(on):      # RANSAC sampling kernel per workload: LDS-screened with one step in flight, plain when pipelined
+        if "APR_RANSAC_SCREEN" not in os.environ:
+            ops.set_ransac_screen(on)
+
+    screen(False)        # Predator (geometric RANSAC: unaffected), FatBN and the planted pipeline keep several steps in flight
     from apr_amd.fcgf.pipeline import PairRegistration
     from apr_amd.predator import kp_ops
     from apr_amd.predator.configs.models import kitti_config
@@ -352,10 +358,12 @@ def extra_workloads(dev, log):
             ppipe.register_batch([pool6[i_ % 6]], seeds=[i_])
         return n1 / (sync() - t0)
 
+    screen(True)                        # one step in flight: the LDS-screened sampling kernel
     r_poll = one_at_a_time()            # the process default: sleeping poll (what the headline's ranks use)
     ppipe.fetch_wait = "sync"           # a caller with one step in flight: hipEventSynchronize, one spinning core
     r_sync = one_at_a_time()
     ppipe.fetch_wait = None
+    screen(False)
     n1, t0, t1 = 60, 0.0, 60 / r_sync
     out["fcgf_one_pair"] = {
         "workload": "BASELINE config 2 literally: FCGF_APR encode+match+SVD (ResUNetBN2C / 32, RANSAC 4 M), ONE 2 x 118 k-point "
@@ -386,6 +394,7 @@ def extra_workloads(dev, log):
     # (the headline loop) gives collapsed features: nearly every one of the 4 M hypotheses dies in the edge-length
     # check and the scoring kernels idle.  Trained features put 10-60 % true matches into the correspondence set;
     # the survivors (and the cost of scoring them, survivors x correspondences) grow with the 4th power of that share.
+    screen(True)         # one pair at a time on one stream
     a_h, b_h, T_gt = synth.make_pair(0)
     base = PairRegistration(fat, voxel_size=0.3, ransac_iters=4000000)
     _, pts0, pts1, n0, n1 = base.voxelize_pair(ta, tb)
@@ -523,6 +532,12 @@ def main():
     from apr_amd import _host, ops, shard, synth
     if args.match_lanes > 0:
         ops.set_match_lanes(args.match_lanes)
+    # RANSAC sampling kernel: the LDS-screened one for a single stream, the plain one with several steps in flight (it leaves
+    # the CUs' LDS to the other steps' conv kernels: +0.8 % there, -17 us per pair alone); APR_RANSAC_SCREEN in the
+    # environment overrides both
+    pipelined = args.streams > 1 or args.depth > 1
+    if "APR_RANSAC_SCREEN" not in os.environ:
+        ops.set_ransac_screen(not pipelined)
     from apr_amd.fcgf.pipeline import PairRegistration
 
     model = build_model(args.model, args.n_out, dev)
@@ -689,6 +704,7 @@ def main():
     first = nprime + args.warmup
     poses4.clear()
     barrier()
+    thr0 = _host.cgroup_throttle()           # the container's CPU-quota throttling so far (diagnostic: see config)
     cpu0 = time.process_time()               # CPU seconds of ALL threads of this rank (user + system)
     t0 = time.perf_counter()
     run_steps(first, first + args.steps)     # EXACTLY `steps` steps, `streams` in flight
@@ -697,6 +713,7 @@ def main():
     barrier()
     elapsed_local = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0
+    thr1 = _host.cgroup_throttle()
     elapsed = shard.max_over_ranks(elapsed_local, dev if backend == "nccl" else torch.device("cpu"))   # all-reduce(MAX)
     if not pipelined:
         job["stop"] = True
@@ -740,6 +757,8 @@ def main():
                    "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
                    "pairs_per_step": B, "streams_per_gpu": nhip, "steps_in_flight_per_stream": depth,
                    "match_lanes": args.match_lanes or int(os.environ.get("APR_MATCH_LANES", "1")),
+                   "ransac_sampling_kernel": ("k_sample_check (pipelined caller)" if (args.streams > 1 or args.depth > 1) and
+                                              "APR_RANSAC_SCREEN" not in os.environ else "k_sample_screen or APR_RANSAC_SCREEN"),
                    "host": "one thread, steps resumed on fetch completion" if pipelined else f"{nstreams} threads",
                    "sharding": f"{world} ranks x independent pairs",
                    "host_enqueue_ms_per_step": (None if host_busy["s"] is None
@@ -753,6 +772,12 @@ def main():
                    # the timed region; 8 ranks need 8 x host_cpus_busy CPUs of the node's quota
                    "host_cpu_s_per_step": host_cpu_s / args.steps,
                    "host_cpus_busy": host_cpu_s / elapsed_local,
+                   # a timed window can be hit by something that is not this program: the container's CPU quota running out
+                   # (every thread of the cgroup stalls until the 100 ms period ends).  The median step-completion interval
+                   # next to ms_per_step's mean, and the throttling the cgroup saw inside the window, say whether it was
+                   "step_interval_median_ms": steady_ms,
+                   "cgroup_throttled_in_window": (None if thr0 is None or thr1 is None else
+                                                  {"periods": thr1[0] - thr0[0], "ms": (thr1[1] - thr0[1]) / 1e3}),
                    "host_cpu_quota": _host.cpu_quota(), "fetch_wait": (f"poll {1e6 * ops.FETCH_POLL_S:.0f} us" if ops.FETCH_WAIT != "sync" else "hipEventSynchronize"),
                    "per_rank_host_cpus_busy": [float(r[3] / r[1]) for r in stats.tolist()],
                    "per_rank_pairs_per_s": [float(r[0] / r[1]) for r in stats.tolist()]},

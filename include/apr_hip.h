@@ -528,6 +528,12 @@ int apr_match_pose_batch_finish(const apr_pair_desc* pairs, int32_t B, int32_t c
                                 int64_t max_iter, void* scratch, size_t scratch_bytes, const void* slots_host,
                                 double* results_host, void* stream);
 
+/* Which RANSAC sampling kernel the calls that follow use: 1 = first edge screened out of LDS (k_sample_screen: lowest
+ * latency for a caller with ONE step in flight), 0 = the plain staged checker (k_sample_check: leaves the CUs' LDS to the
+ * kernels of a pipelined caller's other streams), -1 = APR_RANSAC_SCREEN from the environment (default 1).  Same
+ * candidate set either way (FCGF_APR/scripts/test_apr.py:148-156). */
+int apr_ransac_set_screen(int32_t mode);
+
 /* Deal the pairs of a batch over `lanes` streams (1 .. 4): lane 0 is the caller's stream, the others are library-owned
  * streams forked from it by an event and joined back before the result copy, each with its own matching / RANSAC
  * scratch - ordering as seen by the caller is unchanged, results are identical.  Default 1 (or APR_MATCH_LANES): a
