@@ -1385,12 +1385,11 @@ static void launch_pack(const RansacScratch& r, const float* xyz0, const float* 
     hipLaunchKernelGGL(k_pack_small, dim3((unsigned)cdiv64(n0 + 32, 256)), dim3(256), 0, st, r.rec, n0, r.maxn2, r.rec8);
 }
 
-// Which sampling kernel: k_sample_screen takes the first edge out of a 112 KB table in LDS -- 27 us against 45 for
-// k_sample_check alone on the card, but it owns a CU's whole LDS while it runs, and with several steps in flight on streams
-// of the caller's that costs more than it saves (2634 vs 2654 pairs/s, three alternating runs each: the LDS-heavy conv
-// kernels of the other steps cannot share its CUs).  So: the screen for a caller with ONE step in flight, the plain kernel
-// for a pipelined one -- apr_ransac_set_screen (like the match lanes: the library cannot see the caller's streams);
-// -1 = APR_RANSAC_SCREEN from the environment (default 1, read per call: the A/B and test hook).
+// Which sampling kernel: k_sample_screen (default) takes the first edge out of a 112 KB table in LDS; it owns a CU's whole
+// LDS while it runs.  Whether that costs a pipelined caller more than it saves could not be settled on this repo's
+// benchmark (three same-box A/Bs: +0.8 %, -5 %, 0 %; with true matches in the set the screen is 6 % ahead), so the choice
+// is the caller's: apr_ransac_set_screen; -1 = APR_RANSAC_SCREEN from the environment (default 1, read per call: the A/B
+// and test hook).
 static std::atomic<int> g_ransac_screen{-1};
 
 // k_sample_screen's dynamic LDS (up to 160 KB) needs the per-device opt-in, once, under a lock (several host threads call in)

@@ -187,11 +187,7 @@ def extra_workloads(dev, log):
     from apr_amd import ops, synth
     from apr_amd.fcgf.lib import apg
 
-    def screen(on):      # RANSAC sampling kernel per workload: LDS-screened with one step in flight, plain when pipelined
-        if "APR_RANSAC_SCREEN" not in os.environ:
-            ops.set_ransac_screen(on)
 
-    screen(False)        # Predator (geometric RANSAC: unaffected), FatBN and the planted pipeline keep several steps in flight
     from apr_amd.fcgf.pipeline import PairRegistration
     from apr_amd.predator import kp_ops
     from apr_amd.predator.configs.models import kitti_config
@@ -358,12 +354,10 @@ def extra_workloads(dev, log):
             ppipe.register_batch([pool6[i_ % 6]], seeds=[i_])
         return n1 / (sync() - t0)
 
-    screen(True)                        # one step in flight: the LDS-screened sampling kernel
     r_poll = one_at_a_time()            # the process default: sleeping poll (what the headline's ranks use)
     ppipe.fetch_wait = "sync"           # a caller with one step in flight: hipEventSynchronize, one spinning core
     r_sync = one_at_a_time()
     ppipe.fetch_wait = None
-    screen(False)
     n1, t0, t1 = 60, 0.0, 60 / r_sync
     out["fcgf_one_pair"] = {
         "workload": "BASELINE config 2 literally: FCGF_APR encode+match+SVD (ResUNetBN2C / 32, RANSAC 4 M), ONE 2 x 118 k-point "
@@ -394,7 +388,6 @@ def extra_workloads(dev, log):
     # (the headline loop) gives collapsed features: nearly every one of the 4 M hypotheses dies in the edge-length
     # check and the scoring kernels idle.  Trained features put 10-60 % true matches into the correspondence set;
     # the survivors (and the cost of scoring them, survivors x correspondences) grow with the 4th power of that share.
-    screen(True)         # one pair at a time on one stream
     a_h, b_h, T_gt = synth.make_pair(0)
     base = PairRegistration(fat, voxel_size=0.3, ransac_iters=4000000)
     _, pts0, pts1, n0, n1 = base.voxelize_pair(ta, tb)
@@ -532,12 +525,6 @@ def main():
     from apr_amd import _host, ops, shard, synth
     if args.match_lanes > 0:
         ops.set_match_lanes(args.match_lanes)
-    # RANSAC sampling kernel: the LDS-screened one for a single stream, the plain one with several steps in flight (it leaves
-    # the CUs' LDS to the other steps' conv kernels: +0.8 % there, -17 us per pair alone); APR_RANSAC_SCREEN in the
-    # environment overrides both
-    pipelined = args.streams > 1 or args.depth > 1
-    if "APR_RANSAC_SCREEN" not in os.environ:
-        ops.set_ransac_screen(not pipelined)
     from apr_amd.fcgf.pipeline import PairRegistration
 
     model = build_model(args.model, args.n_out, dev)
@@ -757,8 +744,7 @@ def main():
                    "voxels_per_frame": int((info["n0"] + info["n1"]) / 2), "ransac_iterations": args.ransac_iters,
                    "pairs_per_step": B, "streams_per_gpu": nhip, "steps_in_flight_per_stream": depth,
                    "match_lanes": args.match_lanes or int(os.environ.get("APR_MATCH_LANES", "1")),
-                   "ransac_sampling_kernel": ("k_sample_check (pipelined caller)" if (args.streams > 1 or args.depth > 1) and
-                                              "APR_RANSAC_SCREEN" not in os.environ else "k_sample_screen or APR_RANSAC_SCREEN"),
+                   "ransac_sampling_kernel": ("k_sample_check" if os.environ.get("APR_RANSAC_SCREEN") == "0" else "k_sample_screen"),
                    "host": "one thread, steps resumed on fetch completion" if pipelined else f"{nstreams} threads",
                    "sharding": f"{world} ranks x independent pairs",
                    "host_enqueue_ms_per_step": (None if host_busy["s"] is None
