@@ -51,6 +51,31 @@ if "k_ws_reduce" in ks and ("k_ws_gemm" in ks or "k_ws3_gemm" in ks):
     res["kernel"] = "k_ws_gemm_bf3 | k_ws3_gemm_bf3 + k_ws_reduce (one weight-stationary conv layer = one gemm + one reduce launch)"
     res["ws_family"] = {"layers": ks["k_ws_reduce"]["launches"], "hbm_bytes_per_layer": tot / ks["k_ws_reduce"]["launches"]}
     res["hbm_bytes_per_launch"] = res["ws_family"]["hbm_bytes_per_layer"]
+
+
+def whole_step(sub):
+    """Fabric traffic of EVERY kernel of the profiled command, per step (12 frames): which kernels move the bytes.  Steps =
+    launches of conv1's occupancy kernel (one per encode = one per step)."""
+    import re
+    tot = {}
+    for counter, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        for f in glob.glob(os.path.join(out, sub.format(counter), "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") != counter:
+                    continue
+                name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")
+                t = tot.setdefault(name, {"fetch_MB": 0.0, "write_MB": 0.0, "launches": 0})
+                t["fetch_MB" if counter == "FETCH_SIZE" else "write_MB"] += mul * float(r["Counter_Value"]) / 1024.0
+                if counter == "FETCH_SIZE":
+                    t["launches"] += 1
+    steps = max(1, sum(v["launches"] for k, v in tot.items() if k.startswith("k_occ_conv")))
+    rows = sorted(tot.items(), key=lambda kv: -(kv[1]["fetch_MB"] + kv[1]["write_MB"]))
+    return {"steps_profiled": steps, "total_MB_per_step": sum(v["fetch_MB"] + v["write_MB"] for _, v in rows) / steps,
+            "kernels": [{"kernel": k, "MB_per_step": (v["fetch_MB"] + v["write_MB"]) / steps, "fetch_MB_per_step": v["fetch_MB"] / steps,
+                         "write_MB_per_step": v["write_MB"] / steps, "launches_per_step": v["launches"] / steps} for k, v in rows[:20]]}
+
+
+res["whole_step"] = whole_step("pmc_{}")
 pk = table("pred_pmc_{}", ("k_kpconv_weighted_mfma", "k_kpconv_weighted_generic"))
 if pk:
     res["predator_kpconv"] = {"command": "same counters -- python3 scripts/kpconv_bench.py (KPConv step 1 per pyramid "
