@@ -221,3 +221,27 @@ def test_one_call_encode_plan_equals_the_stage_by_stage_plan(dev, name, n_out, s
         assert torch.equal(a.F, b.F), env
         for k in env:
             monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("npts", [1, 7, 300])
+def test_one_call_front_end_and_encode_on_tiny_clouds(dev, npts, monkeypatch):
+    """The stage-level calls at the small end: frames of 1 / 7 / 300 points (maps of a single row on every level, tiles and
+    pair lists with one entry) through apr_voxel_pyramid + apr_resunet_encode == the tensor-by-tensor front end + the stage
+    walk, bit for bit, and finite."""
+    from apr_amd.fcgf import pipeline as P
+    from apr_amd.fcgf.model import resunet as R
+    from apr_amd.fcgf.pipeline import PairRegistration
+    _, hm = model_pair("ResUNetBN2C", 32)
+    hm.eval()
+    rng = np.random.default_rng(npts)
+    clouds = [torch.from_numpy((rng.standard_normal((npts, 3)) * 3).astype(np.float32)).to(dev) for _ in range(2)]
+    pipe = PairRegistration(hm, voxel_size=0.3)
+    outs = []
+    for one_call in (True, False):
+        monkeypatch.setattr(P, "FRONT_END_CALL", one_call)
+        monkeypatch.setattr(R, "ENCODE_PLAN", one_call)
+        cm, counts, first, offs, pts = pipe.voxelize_batch(clouds)
+        outs.append((pipe.encode_batch(cm), counts, pts))
+    (Fa, ca, pa), (Fb, cb, pb) = outs
+    assert ca == cb and torch.equal(pa, pb) and torch.equal(Fa, Fb)
+    assert bool(torch.isfinite(Fa).all()) and Fa.shape == (sum(ca), 32)
