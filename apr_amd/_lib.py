@@ -207,6 +207,7 @@ PROTOTYPES = {
     "apr_crop_scratch_bytes": (_sz, [_i64]),
     "apr_crop_to_radius": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
     "apr_chamfer_sum": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _sz, _p]),
+    "apr_nn3": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
 }
 
 class KpResnetDesc(C.Structure):

@@ -114,6 +114,48 @@ __global__ __launch_bounds__(256) void k_nn3_min(const float* __restrict__ a, in
   if (live) atomicMin(&best_bits[i], __float_as_uint(best));
 }
 
+// the same search keeping the arg-min: packed (bits(d^2) << 32 | j), 64-bit atomicMin (ties: the smallest j)
+__global__ __launch_bounds__(256) void k_nn3_arg(const float* __restrict__ a, int64_t n, const float* __restrict__ b,
+                                                 int64_t m, int chunk, unsigned long long* __restrict__ best) {
+  __shared__ float s_b[kTile * 3];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  const float x = live ? a[3 * i] : 0.f, y = live ? a[3 * i + 1] : 0.f, z = live ? a[3 * i + 2] : 0.f;
+  float bd = __builtin_inff();
+  unsigned bj = 0xFFFFFFFFu;
+  const int64_t t0 = (int64_t)blockIdx.y * chunk, t1 = min((long long)(t0 + chunk), (long long)m);
+  for (int64_t tb = t0; tb < t1; tb += kTile) {
+    const int rows = (int)min((long long)kTile, (long long)(t1 - tb));
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * 3; e += 256) s_b[e] = b[tb * 3 + e];
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+      const float dx = x - s_b[3 * r], dy = y - s_b[3 * r + 1], dz = z - s_b[3 * r + 2];
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (d < bd) {
+        bd = d;
+        bj = (unsigned)(tb + r);
+      }
+    }
+  }
+  if (live && bj != 0xFFFFFFFFu) atomicMin(&best[i], ((unsigned long long)__float_as_uint(bd) << 32) | bj);
+}
+
+// sum of the distances of a packed arg-min array in a FIXED order (one workgroup: lane-strided partials, LDS tree)
+__global__ __launch_bounds__(1024) void k_sum_packed(const unsigned long long* __restrict__ best, int64_t n,
+                                                     double* __restrict__ out) {
+  __shared__ double part[1024];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)__uint_as_float((unsigned)(best[i] >> 32));
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 512; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = part[0];
+}
+
 __global__ void k_sum_bits(const unsigned* __restrict__ bits, int64_t n, double* __restrict__ out) {
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -182,6 +224,22 @@ APR_API int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m
   hipLaunchKernelGGL(k_nn3_min, dim3((unsigned)qb, (unsigned)cdiv64(m, chunk)), dim3(256), 0, st, a, n, b, m, (int)chunk,
                      best);
   hipLaunchKernelGGL(k_sum_bits, dim3(256), dim3(256), 0, st, best, n, out_dev);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, uint64_t* out_packed, double* sum_dev,
+                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APR_CHECK_ARG(n > 0 && m > 0 && m < (1ll << 32) - 1, "apr_nn3: empty or oversized cloud");
+  APR_HIP(hipMemsetAsync(out_packed, 0xFF, (size_t)n * 8, st));
+  const int64_t qb = cdiv64(n, 256);
+  int64_t want = cdiv64(2048, qb);
+  int64_t chunk = cdiv64(cdiv64(m, want), kTile) * kTile;
+  if (chunk < kTile) chunk = kTile;
+  hipLaunchKernelGGL(k_nn3_arg, dim3((unsigned)qb, (unsigned)cdiv64(m, chunk)), dim3(256), 0, st, a, n, b, m, (int)chunk,
+                     (unsigned long long*)out_packed);
+  if (sum_dev) hipLaunchKernelGGL(k_sum_packed, dim3(1), dim3(1024), 0, st, (const unsigned long long*)out_packed, n, sum_dev);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -5,7 +5,8 @@
   get_matching_indices <- FCGF_APR/util/pointcloud.py:53-66 ; Predator_APR/lib/benchmark_utils.py:121-135
   chamfer_distance   <- FCGF_APR/lib/complement_trainer.py:188-196 (chamferdist 1-NN sums, both directions)
   GenerativeMLP*     <- FCGF_APR/model/mlp.py:6-37 (same module / parameter names: `mlp.0.weight` ...)
-  npr_reconstruction_loss <- complement_trainer.py:424-449 (forward value; backward is next-3)
+  npr_reconstruction_loss <- complement_trainer.py:424-449 (differentiable: GEMM / BN / Chamfer forward and backward on
+                        the HIP kernels, apr_amd/npr.py)
 """
 import ctypes as C
 
@@ -13,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import _lib, ops
+from ... import _lib, npr, ops
 from ..._lib import check, ptr, stream
 from ...predator import kp_ops, point_ops
 
@@ -83,8 +84,8 @@ def chamfer_sum(a, b):
 
 
 def chamfer_distance(array1, array2):
-    """forward / n1 + backward / n2 (complement_trainer.py:188-196)."""
-    return chamfer_sum(array1, array2) / len(array1) + chamfer_sum(array2, array1) / len(array2)
+    """forward / n1 + backward / n2 (complement_trainer.py:188-196); differentiable (apr_amd/npr.py)."""
+    return npr.chamfer_distance(array1, array2)
 
 
 class GenerativeMLP(nn.Module):
@@ -99,31 +100,8 @@ class GenerativeMLP(nn.Module):
             nn.Linear(CH[1], CH[2]), nn.ReLU(), nn.BatchNorm1d(CH[2], momentum=bn_momentum),
             nn.Linear(CH[2], out_points * 3), nn.ReLU())
 
-    @torch.no_grad()
     def forward(self, x):
-        mods = list(self.mlp)
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Linear):
-                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = kp_ops.linear(x, kp_ops.pack_linear(m.weight.detach().t(), bf3=False), shift=m.bias.detach(), relu=relu)
-                i += 2 if relu else 1
-            elif isinstance(m, nn.BatchNorm1d):
-                if self.training:
-                    mean, var = ops.bn_stats(x)
-                    n = x.shape[0]
-                    m.running_mean.mul_(1 - m.momentum).add_(mean, alpha=m.momentum)
-                    m.running_var.mul_(1 - m.momentum).add_(var * (n / max(n - 1, 1)), alpha=m.momentum)
-                    m.num_batches_tracked += 1
-                else:
-                    mean, var = m.running_mean, m.running_var
-                scale = m.weight.detach() * torch.rsqrt(var + m.eps)
-                x = ops.affine_act(x, scale=scale.contiguous(), shift=(m.bias.detach() - mean * scale).contiguous())
-                i += 1
-            else:
-                raise NotImplementedError(type(m))
-        return x
+        return npr.run_stack(self.mlp, x)
 
 
 class GenerativeMLP_98(GenerativeMLP):
@@ -136,14 +114,7 @@ class GenerativeMLP_54(GenerativeMLP):
 
 def npr_regulariser(generated, reg_type='L2', alpha=0.1):
     """Length penalty on the generated offsets [N, 3*ratio] (complement_trainer.py:432-440)."""
-    sq = (generated.reshape(-1, 3) ** 2).sum(-1)
-    if reg_type == 'L2':
-        return sq.mean()
-    if reg_type == 'RepelL2':
-        return sq.mean() + (1.0 / (sq + alpha)).mean()
-    if reg_type == 'RepelL1':
-        return ((torch.pow(sq + 1e-5, 0.25) - 1) ** 2).mean()
-    raise ValueError(reg_type)
+    return npr.regulariser(generated, reg_type, alpha)
 
 
 def npr_points(generated, enc_coords, voxel_size, ratio):
@@ -151,11 +122,10 @@ def npr_points(generated, enc_coords, voxel_size, ratio):
     return (generated + voxel_size * enc_coords.to(generated.dtype).repeat(1, ratio)).reshape(-1, 3)
 
 
-@torch.no_grad()
 def npr_reconstruction_loss(generator, enc_feats, enc_coords, pcd_nghb, voxel_size, ratio, reg_strength=0.01,
                             reg_type='L2', alpha=0.1):
     """chamfer(generated + voxel centres, APG cloud) + reg * regulariser for one cloud (complement_trainer.py:424-448)."""
     generated = generator(enc_feats) * voxel_size                                       # [N, 3*ratio]
     reg = npr_regulariser(generated, reg_type, alpha)
     mod = npr_points(generated, enc_coords, voxel_size, ratio)
-    return chamfer_distance(mod, pcd_nghb).float() + reg * reg_strength
+    return chamfer_distance(mod, pcd_nghb) + reg * reg_strength

@@ -108,6 +108,36 @@ class LinearFunction(torch.autograd.Function):
         return dx, dw, None, db
 
 
+class LinearReluFunction(torch.autograd.Function):
+    """relu(x @ W^T + b): nn.Linear followed by nn.ReLU as the NPR decoders stack them (Predator_APR/models/mlp.py:122-127,
+    FCGF_APR/model/mlp.py:16-24).  Forward = the dense GEMM with the bias and the ReLU in its epilogue; backward =
+    apr_act_backward on the saved output, then LinearFunction's three products."""
+
+    @staticmethod
+    def forward(ctx, x, weight, wp_info, bias):
+        x = x.contiguous()
+        y = linear(x, wp_info, shift=None if bias is None else bias.detach(), relu=True).contiguous()   # padded widths: a slice
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = y.shape
+        dz = torch.empty_like(dy)
+        check(_lib.load().apr_act_backward(ptr(dy), c, ptr(y), c, n, c, 1, 0.0, ptr(dz), c, stream()))
+        cout, cin = weight.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear(dz, pack_linear(weight.detach()))
+        if ctx.needs_input_grad[1]:
+            dw = ops.spconv_wgrad(x, dz, None, 1, cin, cout)[0].t()
+        if ctx.needs_input_grad[3]:
+            db = ops.col_sums(dz)
+        return dx, dw, None, db
+
+
 def linear_train(x, weight, wp_info, bias=None):
     """The tracked (training) form of a Linear / 1x1 convolution on rows: forward, d x, d W (and d bias) on the HIP kernels
     (LinearFunction)."""

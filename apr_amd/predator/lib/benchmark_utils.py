@@ -32,6 +32,15 @@ def ransac_pose_estimation(src_pcd, tgt_pcd, src_feat, tgt_feat, mutual=False, d
     return (T, info) if return_info else T
 
 
+def get_correspondences(src_pcd, tgt_pcd, trans, search_voxel_size, K=None):
+    """(i, j) pairs with |T src_i - tgt_j| < search_voxel_size, by i then by distance -> int64 [M, 2] (CPU tensor, as the
+    reference returns it: lib/benchmark_utils.py:121-135).  The clouds are [N,3] arrays / tensors (the reference takes
+    open3d point clouds; open3d is not part of this build) -- the search is the radius-neighbour kernel."""
+    from ...fcgf.lib import apg
+    pts = lambda p: np.asarray(p.points, dtype=np.float32) if hasattr(p, "points") else p
+    return apg.get_matching_indices(pts(src_pcd), pts(tgt_pcd), trans, search_voxel_size, K).cpu()
+
+
 def get_angle_deviation(R_pred, R_gt):
     R = np.matmul(R_pred, R_gt.transpose(0, 2, 1))
     tr = np.trace(R, 0, 1, 2)

@@ -102,37 +102,89 @@ def launch_ranks(cmd, world: int, timeout_s: float = None, grace_s: float = 20.0
     output); the other ranks' stdout is folded into stderr.  The caller must not have initialised the GPU: children
     are fresh processes (subprocess.Popen), nothing is exec'ed over a process that holds a HIP context.  When a rank
     fails, the others get `grace_s` seconds (they usually fail the same way or hang in a collective) and are then
-    killed by PID."""
+    killed by PID.
+
+    No rank outlives the launcher: every child leads its own session (start_new_session), SIGTERM / SIGINT / SIGHUP to
+    the launcher -- a driver's `timeout`, Ctrl-C -- and any exception on the way out terminate every live child's process
+    group (SIGTERM, then SIGKILL after 5 s) before the launcher returns 128 + signal.  `timeout_s` None reads
+    APR_LAUNCH_TIMEOUT_S (default 3600 s): a rank wedged in a collective cannot hold the job for ever.  OMP_NUM_THREADS
+    defaults to 1 as under torch.distributed.run, so host-CPU figures of the two launch forms are comparable."""
+    import signal
     import subprocess
     import time
     if world < 1:
         raise ValueError("launch_ranks: world must be >= 1")
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("APR_LAUNCH_TIMEOUT_S", "3600"))
     port = free_port()
     procs = []
-    for r in range(world):
-        procs.append(subprocess.Popen(list(cmd), env=rank_env(r, world, port),
-                                      stdout=None if r == 0 else sys.stderr))
-    t0 = time.monotonic()
+
+    def stop_all(sig_first=signal.SIGTERM, wait_s=5.0):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig_first)          # the child leads its own group: pgid == pid (ours, by PID)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        t_end = time.monotonic() + wait_s
+        for p in procs:
+            try:
+                p.wait(max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                p.wait()
+
+    class _Signalled(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Signalled(signum)
+
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            old[sg] = signal.signal(sg, on_signal)
+        except ValueError:                               # not the main thread: the try/finally below still cleans up
+            pass
     first_bad, bad_at = 0, None
-    live = set(range(world))
-    while live:
-        for r in sorted(live):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            live.discard(r)
-            if rc != 0 and first_bad == 0:
-                first_bad, bad_at = rc, time.monotonic()
-                print(f"[launch_ranks] rank {r} exited with code {rc}", file=sys.stderr, flush=True)
-        now = time.monotonic()
-        expired = timeout_s is not None and now - t0 > timeout_s
-        if live and (expired or (bad_at is not None and now - bad_at > grace_s)):
+    try:
+        for r in range(world):
+            env = rank_env(r, world, port)
+            env.setdefault("OMP_NUM_THREADS", "1")
+            procs.append(subprocess.Popen(list(cmd), env=env, stdout=None if r == 0 else sys.stderr,
+                                          start_new_session=True))
+        t0 = time.monotonic()
+        live = set(range(world))
+        while live:
             for r in sorted(live):
-                procs[r].kill()
-                procs[r].wait()
-            live.clear()
-            if first_bad == 0:
-                first_bad = 124
-        if live:
-            time.sleep(0.05)
-    return first_bad
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and first_bad == 0:
+                    first_bad, bad_at = rc, time.monotonic()
+                    print(f"[launch_ranks] rank {r} exited with code {rc}", file=sys.stderr, flush=True)
+            now = time.monotonic()
+            expired = now - t0 > timeout_s
+            if live and (expired or (bad_at is not None and now - bad_at > grace_s)):
+                if expired:
+                    print(f"[launch_ranks] {len(live)} rank(s) still running after {timeout_s:.0f} s: stopping them",
+                          file=sys.stderr, flush=True)
+                stop_all()
+                live.clear()
+                if first_bad == 0:
+                    first_bad = 124
+            if live:
+                time.sleep(0.05)
+        return first_bad
+    except _Signalled as e:
+        print(f"[launch_ranks] signal {e.args[0]}: stopping {sum(p.poll() is None for p in procs)} rank(s)",
+              file=sys.stderr, flush=True)
+        return 128 + int(e.args[0])
+    finally:
+        stop_all()
+        for sg, h in old.items():
+            signal.signal(sg, h)

@@ -813,6 +813,13 @@ int apr_crop_to_radius(const float* key_pts, int64_t n_key, const float* pts, in
 int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m, double* out_dev, void* scratch,
                     size_t scratch_bytes, void* stream);
 
+/* Exact 1-NN of every row of a [n,3] among the rows of b [m,3] in fp32 ((dx^2 + dy^2) + dz^2, as chamferdist's
+ * kernel sums it): out_packed[i] = (bits(d^2) << 32) | j, ties -> the smallest j.  sum_dev (may be NULL): f64 sum of
+ * the n minima in a fixed order (bit-reproducible).  The arg-min is what the backward of the Chamfer term needs
+ * (Predator_APR/lib/trainer.py:131-140, 179-183; FCGF_APR/lib/complement_trainer.py:188-196, 446-448): the gradient
+ * of sum_i min_j |a_i - b_j|^2 reaches a_i and b_argmin(i) only. */
+int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, uint64_t* out_packed, double* sum_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

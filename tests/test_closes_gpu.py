@@ -1,5 +1,6 @@
-"""Round-2 closes: calibrate_neighbors, hit ratio, subsampled find_corr, corr_dist, the reserved batch index,
-and the library driven from several host threads / streams at once."""
+"""Round-2 closes: calibrate_neighbors against the oracle's collate, the reserved batch index, and the library driven from
+several host threads / streams at once.  (Hit ratio, corr_dist, find_corr and calibrate_neighbors against the REFERENCE's
+own text: tests/test_predator_ref_fixtures_gpu.py, round 5.)"""
 import threading
 
 import numpy as np
@@ -8,8 +9,6 @@ import torch
 
 from apr_amd import ops, synth
 from apr_amd._lib import AprHipError
-from apr_amd.fcgf.lib import eval as EV
-from apr_amd.fcgf.lib import metrics as MT
 from apr_amd.predator.configs.models import kitti_config
 from apr_amd.predator.datasets.dataloader import calibrate_neighbors, collate_fn_descriptor
 from oracle import kpfcnn_oracle as KO
@@ -43,51 +42,6 @@ def test_calibrate_neighbors_matches_reference_rule(dev):
     # levels >= 2 are built from barycentres summed in a different row order (last-bit differences): +-1 bin
     assert np.all(np.abs(got.astype(np.int64) - want) <= 1), (got, want)
     assert np.array_equal(got[:2], want[:2])
-
-
-def test_hit_ratio_and_corr_dist(dev):
-    rng = np.random.default_rng(3)
-    xyz0 = rng.uniform(-20, 20, (4000, 3)).astype(np.float32)
-    a = np.deg2rad(7.0)
-    T = np.eye(4, dtype=np.float32)
-    T[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
-    T[:3, 3] = [1.0, -2.0, 0.5]
-    xyz1 = xyz0 @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.06, xyz0.shape).astype(np.float32)
-    # FCGF_APR/lib/trainer.py:392-395, restated in numpy
-    d = np.sqrt((((xyz0 @ T[:3, :3].T + T[:3, 3]) - xyz1) ** 2).sum(1) + 1e-6)
-    want = float((d < 0.1).mean())
-    got = EV.evaluate_hit_ratio(torch.from_numpy(xyz0).to(dev), torch.from_numpy(xyz1).to(dev), torch.from_numpy(T), 0.1)
-    assert abs(got - want) < 1e-3
-    # FCGF_APR/lib/metrics.py:13-19
-    est = torch.from_numpy(T).clone()
-    est[:3, 3] += torch.tensor([0.3, 0.0, -0.2])
-    x0 = torch.from_numpy(xyz0)
-    w = torch.from_numpy(rng.random(len(xyz0)).astype(np.float32))
-    ref = torch.clamp(torch.sqrt((((x0 @ est[:3, :3].t() + est[:3, 3]) - (x0 @ torch.from_numpy(T)[:3, :3].t()
-                                  + torch.from_numpy(T)[:3, 3])) ** 2).sum(1)), max=0.25)
-    assert torch.allclose(MT.corr_dist(est, torch.from_numpy(T), x0, None, max_dist=0.25), ref.mean(), atol=1e-6)
-    assert torch.allclose(MT.corr_dist(est, torch.from_numpy(T), x0, None, weight=w, max_dist=0.25), (w * ref).mean(),
-                          atol=1e-6)
-
-
-def test_find_corr_subsample_follows_reference_draws(dev):
-    """scripts/test_apr.py:43-57 with subsample_size=5000: the same two np.random.choice draws, NN on the subsample."""
-    rng = np.random.default_rng(5)
-    F0 = torch.from_numpy(rng.standard_normal((7000, 32)).astype(np.float32)).to(dev)
-    F1 = torch.from_numpy(rng.standard_normal((6500, 32)).astype(np.float32)).to(dev)
-    xyz0 = rng.uniform(-5, 5, (7000, 3)).astype(np.float32)
-    xyz1 = rng.uniform(-5, 5, (6500, 3)).astype(np.float32)
-    np.random.seed(11)
-    a0, a1 = EV.find_corr(xyz0, xyz1, F0, F1, subsample_size=5000)
-    np.random.seed(11)
-    i0 = np.random.choice(7000, 5000, replace=False)
-    i1 = np.random.choice(6500, 5000, replace=False)
-    d = torch.cdist(F0[torch.as_tensor(i0, device=dev)].double(), F1[torch.as_tensor(i1, device=dev)].double())
-    nn = d.argmin(1).cpu().numpy()
-    assert a0.shape == (5000, 3) and np.array_equal(a0, xyz0[i0]) and np.array_equal(a1, xyz1[i1[nn]])
-    # no subsampling when the clouds are smaller than the cap (or the cap is -1)
-    b0, b1 = EV.find_corr(xyz0[:300], xyz1[:400], F0[:300], F1[:400], subsample_size=5000)
-    assert b0.shape == (300, 3) and b1.shape == (300, 3)
 
 
 def test_batch_index_1023_is_reserved(dev):

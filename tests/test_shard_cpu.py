@@ -101,3 +101,48 @@ def test_bench_gpus_flag_plumbing():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in p.stderr, p.stderr
+
+
+def test_launcher_leaves_no_rank_behind_when_it_is_terminated(tmp_path):
+    """SIGTERM to the launcher (a driver's `timeout`) must take every rank with it, and a rank that never exits
+    must not hold the launcher past its deadline."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    pidfile = tmp_path / "pids"
+    child = ("import os, time\n"
+             f"open({str(pidfile)!r}, 'a').write(str(os.getpid()) + '\\n')\n"
+             "time.sleep(600)\n")
+    launcher = ("import sys\n"
+                f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+                "from apr_amd import shard\n"
+                f"sys.exit(shard.launch_ranks([sys.executable, '-c', {child!r}], 3, timeout_s=float(sys.argv[1])))\n")
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:                                       # a zombie still answers kill(0): look at its state
+            return open(f"/proc/{pid}/stat").read().split(") ")[1][0] != "Z"
+        except FileNotFoundError:
+            return False
+
+    def wait_pids():
+        for _ in range(200):
+            if pidfile.exists() and len(pidfile.read_text().split()) == 3:
+                return [int(v) for v in pidfile.read_text().split()]
+            time.sleep(0.05)
+        raise AssertionError("ranks did not start")
+
+    p = subprocess.Popen([sys.executable, "-c", launcher, "600"])
+    pids = wait_pids()
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(30) == 128 + signal.SIGTERM
+    assert not any(alive(q) for q in pids)
+    pidfile.unlink()
+    p = subprocess.Popen([sys.executable, "-c", launcher, "1.0"])      # deadline: ranks sleep for ever
+    pids = wait_pids()
+    assert p.wait(30) == 124
+    assert not any(alive(q) for q in pids)
