@@ -437,6 +437,20 @@ class _ConvBase(nn.Module):
             self._bf3_key = k
         return self._bf3
 
+    def packed_weight_T(self, flip):
+        """(tile pack, bf16-split pack or None) of the input gradient's kernel [K, cout, cin] (offsets mirrored when `flip`:
+        ops.weights_flip_transpose), cached per parameter version like the forward packs -- one pack per optimizer step, not
+        one per call."""
+        k = (self.kernel.data_ptr(), self.kernel._version, self.kernel.device, bool(flip))
+        if getattr(self, "_packT_key", None) != k:
+            w = self.kernel.detach()
+            wt = ops.weights_flip_transpose(w if w.dim() == 3 else w.unsqueeze(0), flip)
+            import os
+            bf3 = None if os.environ.get("APR_WS_BF3", "1") == "0" else ops.pack_weights_bf3(wt)
+            self._packT = (ops.pack_weights(wt), bf3)
+            self._packT_key = k
+        return self._packT
+
     def _maps(self, x: SparseTensor):
         """-> (nbr or None, out tensor stride)."""
         ts = x.coordinate_map_key.stride
@@ -453,12 +467,22 @@ class _ConvBase(nn.Module):
             raise AprHipError("transposed convolution needs the encoder's coordinate map of that stride")
         return cm.kernel_map(ts, ts_out, self.kernel_size, self.stride != 1), ts_out
 
+    def run_T(self, dout, nbr_bwd, n_in, flip, plist=None):
+        """The input gradient: the same routed launch over the reverse map with the flipped-transposed kernel (channels
+        swapped); `plist`: the reverse map's pair lists."""
+        wp, w_bf3 = self.packed_weight_T(flip)
+        os_pairs = plist if isinstance(plist, ops.OsPairs) else None
+        return ops.spconv(dout, nbr_bwd, self.kernel_volume if nbr_bwd is not None else 1, self.out_channels,
+                          self.in_channels, wp, n_out=n_in, plist=None if os_pairs is not None else plist,
+                          w_bf3=w_bf3 if (plist is not None or nbr_bwd is None) else None, os_pairs=os_pairs)
+
     def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None, batch=None,
-            plist=None, l2norm=False):
+            plist=None, l2norm=False, raw=False):
         """Raw fused launch on feature rows (used by the fused encoder plan); `batch` defers the launch; `l2norm`
-        (batched launches only): rows of the result divided by their 2-norm in the same launch."""
-        if shift is None and self.bias is not None:
-            shift = self.bias.view(-1)
+        (batched launches only): rows of the result divided by their 2-norm in the same launch; `raw`: no bias either (the
+        training path's norm follows)."""
+        if shift is None and self.bias is not None and not raw:
+            shift = self.bias.detach().view(-1)
         fn = ops.spconv if batch is None else batch.add
         os_pairs = plist if isinstance(plist, ops.OsPairs) else None     # output-stationary tile lists
         kw = {"l2norm": True} if l2norm else {}
@@ -467,7 +491,7 @@ class _ConvBase(nn.Module):
         return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
                   self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
                   relu=relu, out=out, n_out=n_out, plist=None if os_pairs is not None else plist,
-                  w_bf3=self.packed_weight_bf3() if (plist is not None or (nbr is None and batch is not None)) else None,
+                  w_bf3=self.packed_weight_bf3() if (plist is not None or nbr is None) else None,
                   os_pairs=os_pairs, **kw)
 
     def occ_ready(self, x: SparseTensor):

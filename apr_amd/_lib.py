@@ -124,6 +124,7 @@ PROTOTYPES = {
                                         _p, _p]),
     "apr_spconv_wgrad_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "apr_spconv_wgrad": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    "apr_spconv_wgrad_same_level": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "apr_spconv_fwd_batch": (C.c_int, [_p, _i32, _p]),
     "apr_spconv_fwd_batch_timed": (C.c_int, [_p, _i32, _p, _p]),
     "apr_bn_stats": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
@@ -138,12 +139,18 @@ PROTOTYPES = {
     "apr_spconv_os_fwd": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_norm_backward_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_norm_backward": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "apr_bn_train_fwd": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, C.c_float, C.c_float, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p,
+                                   _p, _p, _sz, _p]),
+    "apr_bn_train_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p, _p,
+                                   _sz, _p]),
+    "apr_weights_flip_transpose": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_dense_gemm_bf3": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_weighted_choice_round": (C.c_int64, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i32]),
     "apr_instance_norm_act_seg": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _i32, _p, _sz, _p]),
     "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _p]),
     "apr_act_backward": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p]),
     "apr_l2_normalize": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
+    "apr_l2_normalize_backward": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),
     "apr_feature_nn": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p]),
     "apr_feature_nn_fast_scratch_bytes": (_sz, [_i64, _i64, _i32]),
     "apr_feature_nn_fast": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p, _sz, _p]),
@@ -207,7 +214,8 @@ PROTOTYPES = {
     "apr_crop_scratch_bytes": (_sz, [_i64]),
     "apr_crop_to_radius": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
     "apr_chamfer_sum": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _sz, _p]),
-    "apr_nn3": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
+    "apr_nn3_scratch_bytes": (_sz, [_i64, _i64]),
+    "apr_nn3": (C.c_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _p, _sz, _p]),
 }
 
 class KpResnetDesc(C.Structure):

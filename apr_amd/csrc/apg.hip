@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256) void k_nn3_min(const float* __restrict__ a, in
   if (live) atomicMin(&best_bits[i], __float_as_uint(best));
 }
 
+__device__ inline float d2_rn(float ax, float ay, float az, float bx, float by, float bz);
+
 // the same search keeping the arg-min: packed (bits(d^2) << 32 | j), 64-bit atomicMin (ties: the smallest j)
 __global__ __launch_bounds__(256) void k_nn3_arg(const float* __restrict__ a, int64_t n, const float* __restrict__ b,
                                                  int64_t m, int chunk, unsigned long long* __restrict__ best) {
@@ -130,15 +132,144 @@ __global__ __launch_bounds__(256) void k_nn3_arg(const float* __restrict__ a, in
     for (int e = threadIdx.x; e < rows * 3; e += 256) s_b[e] = b[tb * 3 + e];
     __syncthreads();
     for (int r = 0; r < rows; ++r) {
-      const float dx = x - s_b[3 * r], dy = y - s_b[3 * r + 1], dz = z - s_b[3 * r + 2];
-      const float d = dx * dx + dy * dy + dz * dz;
-      if (d < bd) {
+      const float d = d2_rn(x, y, z, s_b[3 * r], s_b[3 * r + 1], s_b[3 * r + 2]);
+      if (d < bd) {            // ascending j: the first of equal distances stays
         bd = d;
         bj = (unsigned)(tb + r);
       }
     }
   }
   if (live && bj != 0xFFFFFFFFu) atomicMin(&best[i], ((unsigned long long)__float_as_uint(bd) << 32) | bj);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Grid-accelerated exact 1-NN (round 5).  The brute-force search above is n x m distance evaluations (56 k generated points
+// against a 50-56 k-point APG cloud, both directions, both frames: 3 ms of a training iteration); nearly every query has its
+// neighbour within a voxel or two.  Two uniform grids over the targets (cells c and 8 c: points.hip's search grid), three
+// passes, every one exact:
+//   A  thread per query, fine grid: the 2^3 cells around the query (everything within 0.49 c), then the 4^3 shell (1.47 c);
+//      a query whose best distance is inside the covered radius is DONE -- no closer point can exist outside the cells
+//      read -- the others go to a list (wave-aggregated append; the order of the list does not matter);
+//   B  wave per listed query, coarse grid, same two rings (3.9 c, 11.8 c), lanes stride over a cell's points;
+//   C  wave per still-unresolved query over all m targets.
+// Distances are (dx^2 + dy^2) + dz^2 with explicitly rounded operations in every pass, ties go to the smaller index: the
+// packed result is bit-identical to k_nn3_arg's whatever path a query took (tested).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ inline float d2_rn(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ inline void better(float d, unsigned j, float& bd, unsigned& bj) {
+  if (d < bd || (d == bd && j < bj)) {
+    bd = d;
+    bj = j;
+  }
+}
+
+// cells [base - (ring - 1), base + ring]^3 minus the cube of the previous ring; base = floor(u - 0.5), u = (p - min) / cell
+__device__ inline void cell_base(const AprSearchGrid& g, float x, float y, float z, int* base) {
+  base[0] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(x, g.mins[0]), g.cell), 0.5f));
+  base[1] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(y, g.mins[1]), g.cell), 0.5f));
+  base[2] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(z, g.mins[2]), g.cell), 0.5f));
+}
+
+__global__ __launch_bounds__(256) void k_nn3_grid_thread(const float* __restrict__ a, int64_t n, const float* __restrict__ b,
+                                                         AprSearchGrid g, unsigned long long* __restrict__ best,
+                                                         int* __restrict__ list, int* __restrict__ list_n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  bool unresolved = false;
+  if (live) {
+    const float x = a[3 * i], y = a[3 * i + 1], z = a[3 * i + 2];
+    int base[3];
+    cell_base(g, x, y, z, base);
+    float bd = __builtin_inff();
+    unsigned bj = 0xFFFFFFFFu;
+    bool done = false;
+    for (int ring = 1; ring <= 2 && !done; ++ring) {
+      const int lo = -(ring - 1), hi = ring;
+      for (int cz = lo; cz <= hi; ++cz)
+        for (int cy = lo; cy <= hi; ++cy)
+          for (int cx = lo; cx <= hi; ++cx) {
+            if (ring == 2 && cx >= 0 && cx <= 1 && cy >= 0 && cy <= 1 && cz >= 0 && cz <= 1) continue;   // ring 1 saw it
+            const int X = base[0] + cx, Y = base[1] + cy, Z = base[2] + cz;
+            if (!apr_key_in_range(0, X, Y, Z)) continue;
+            const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+            if (id < 0) continue;
+            const int e1 = g.start[id + 1];
+            for (int e = g.start[id]; e < e1; ++e) {
+              const unsigned j = (unsigned)g.sorted[e];
+              better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
+            }
+          }
+      const float r = ((float)ring - 0.51f) * g.cell;        // every target within r lies in the cells read so far
+      done = bd <= r * r;
+    }
+    if (done) best[i] = ((unsigned long long)__float_as_uint(bd) << 32) | bj;
+    unresolved = !done;
+  }
+  const unsigned long long bal = __ballot(unresolved);
+  if (bal) {
+    const int lane = threadIdx.x & 63;
+    int pos0 = 0;
+    if (lane == 0) pos0 = atomicAdd(list_n, __popcll(bal));
+    pos0 = __shfl(pos0, 0);
+    if (unresolved) list[pos0 + __popcll(bal & ((1ull << lane) - 1ull))] = (int)i;
+  }
+}
+
+// wave per listed query.  g.cell > 0: the two rings of grid g; g.cell == 0: every target (the last resort)
+__global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__ a, const float* __restrict__ b, int64_t m,
+                                                       AprSearchGrid g, const int* __restrict__ list_in,
+                                                       const int* __restrict__ list_in_n, unsigned long long* __restrict__ best,
+                                                       int* __restrict__ list_out, int* __restrict__ list_out_n) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= *list_in_n) return;                               // wave-uniform
+  const int64_t i = list_in[q];
+  const float x = a[3 * i], y = a[3 * i + 1], z = a[3 * i + 2];
+  float bd = __builtin_inff();
+  unsigned bj = 0xFFFFFFFFu;
+  bool done = false;
+  if (g.cell > 0.f) {
+    int base[3];
+    cell_base(g, x, y, z, base);
+    for (int ring = 1; ring <= 2 && !done; ++ring) {
+      const int lo = -(ring - 1), hi = ring;
+      for (int cz = lo; cz <= hi; ++cz)
+        for (int cy = lo; cy <= hi; ++cy)
+          for (int cx = lo; cx <= hi; ++cx) {
+            if (ring == 2 && cx >= 0 && cx <= 1 && cy >= 0 && cy <= 1 && cz >= 0 && cz <= 1) continue;
+            const int X = base[0] + cx, Y = base[1] + cy, Z = base[2] + cz;
+            if (!apr_key_in_range(0, X, Y, Z)) continue;
+            const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+            if (id < 0) continue;
+            const int e1 = g.start[id + 1];
+            for (int e = g.start[id] + lane; e < e1; e += 64) {
+              const unsigned j = (unsigned)g.sorted[e];
+              better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
+            }
+          }
+      float wd = bd;
+      for (int d = 32; d >= 1; d >>= 1) wd = fminf(wd, __shfl_xor(wd, d));
+      const float r = ((float)ring - 0.51f) * g.cell;
+      done = wd <= r * r;
+    }
+  } else {
+    for (int64_t j = lane; j < m; j += 64) better(d2_rn(x, y, z, b[3 * j], b[3 * j + 1], b[3 * j + 2]), (unsigned)j, bd, bj);
+    done = true;
+  }
+  if (done) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float od = __shfl_xor(bd, d);
+      const unsigned oj = (unsigned)__shfl_xor((int)bj, d);
+      better(od, oj, bd, bj);
+    }
+    if (lane == 0) best[i] = ((unsigned long long)__float_as_uint(bd) << 32) | bj;
+  } else if (lane == 0) {
+    list_out[atomicAdd(list_out_n, 1)] = (int)i;
+  }
 }
 
 // sum of the distances of a packed arg-min array in a FIXED order (one workgroup: lane-strided partials, LDS tree)
@@ -228,18 +359,48 @@ APR_API int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m
   return APR_OK;
 }
 
-APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, uint64_t* out_packed, double* sum_dev,
-                    void* stream) {
+APR_API size_t apr_nn3_scratch_bytes(int64_t n, int64_t m) {
+  return 2 * align256(apr_internal_grid_bytes(m)) + 2 * align256((size_t)(n > 0 ? n : 1) * 4) + 1024;
+}
+
+APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
+                    void* scratch, size_t scratch_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  APR_CHECK_ARG(n > 0 && m > 0 && m < (1ll << 32) - 1, "apr_nn3: empty or oversized cloud");
-  APR_HIP(hipMemsetAsync(out_packed, 0xFF, (size_t)n * 8, st));
-  const int64_t qb = cdiv64(n, 256);
-  int64_t want = cdiv64(2048, qb);
-  int64_t chunk = cdiv64(cdiv64(m, want), kTile) * kTile;
-  if (chunk < kTile) chunk = kTile;
-  hipLaunchKernelGGL(k_nn3_arg, dim3((unsigned)qb, (unsigned)cdiv64(m, chunk)), dim3(256), 0, st, a, n, b, m, (int)chunk,
-                     (unsigned long long*)out_packed);
-  if (sum_dev) hipLaunchKernelGGL(k_sum_packed, dim3(1), dim3(1024), 0, st, (const unsigned long long*)out_packed, n, sum_dev);
+  APR_CHECK_ARG(n > 0 && m > 0 && m < (1ll << 31) - 1 && n < (1ll << 31), "apr_nn3: empty or oversized cloud");
+  unsigned long long* best = (unsigned long long*)out_packed;
+  if (cell > 0.f) {
+    APR_CHECK_ARG(scratch && scratch_bytes >= apr_nn3_scratch_bytes(n, m), "apr_nn3: scratch too small");
+    char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    void* g1s = p;
+    p += align256(apr_internal_grid_bytes(m));
+    void* g2s = p;
+    p += align256(apr_internal_grid_bytes(m));
+    int* list1 = (int*)p;
+    p += align256((size_t)n * 4);
+    int* list2 = (int*)p;
+    p += align256((size_t)n * 4);
+    int* counts = (int*)p;                                     // [0] list1, [1] list2
+    AprSearchGrid g1, g2, none;
+    int rc = apr_internal_search_grid(b, m, cell, g1s, &g1, st);
+    if (rc != APR_OK) return rc;
+    rc = apr_internal_search_grid(b, m, 8.f * cell, g2s, &g2, st);
+    if (rc != APR_OK) return rc;
+    memset(&none, 0, sizeof(none));
+    APR_HIP(hipMemsetAsync(counts, 0, 8, st));
+    hipLaunchKernelGGL(k_nn3_grid_thread, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, a, n, b, g1, best, list1, counts);
+    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, g2, list1, counts, best, list2,
+                       counts + 1);
+    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, none, list2, counts + 1, best,
+                       (int*)nullptr, (int*)nullptr);
+  } else {
+    APR_HIP(hipMemsetAsync(out_packed, 0xFF, (size_t)n * 8, st));
+    const int64_t qb = cdiv64(n, 256);
+    int64_t want = cdiv64(2048, qb);
+    int64_t chunk = cdiv64(cdiv64(m, want), kTile) * kTile;
+    if (chunk < kTile) chunk = kTile;
+    hipLaunchKernelGGL(k_nn3_arg, dim3((unsigned)qb, (unsigned)cdiv64(m, chunk)), dim3(256), 0, st, a, n, b, m, (int)chunk, best);
+  }
+  if (sum_dev) hipLaunchKernelGGL(k_sum_packed, dim3(1), dim3(1024), 0, st, (const unsigned long long*)best, n, sum_dev);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

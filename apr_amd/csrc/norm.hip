@@ -296,6 +296,27 @@ __global__ void k_l2_normalize(const float* __restrict__ x, int64_t ldx, int64_t
   for (int col = lane; col < c; col += 64) y[row * ldy + col] = x[row * ldx + col] / nrm;
 }
 
+// backward of y = x / |x|_2 per row: dx = (dy - y (y . dy)) / |x|; one wave per row
+__global__ void k_l2_normalize_bwd(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
+                                   int64_t n, int c, float* __restrict__ dx, int64_t lddx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float ss = 0.f, dot = 0.f;
+  for (int col = lane; col < c; col += 64) {
+    const float v = x[row * ldx + col];
+    ss = fmaf(v, v, ss);
+    dot = fmaf(v, dy[row * lddy + col], dot);
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    ss += __shfl_xor(ss, d);
+    dot += __shfl_xor(dot, d);
+  }
+  const float nrm = sqrtf(ss);
+  const float k = dot / (nrm * nrm);          // (y . dy) / |x| = (x . dy) / |x|^2
+  for (int col = lane; col < c; col += 64) dx[row * lddx + col] = (dy[row * lddy + col] - x[row * ldx + col] * k) / nrm;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of y = (x - mean) * rstd * gamma + beta over the rows of one segment (training-mode MinkowskiBatchNorm,
 // FCGF_APR/model/common.py:6, lib/trainer.py:454-527; gamma = NULL: the affine-free InstanceNorm1d of KPFCNN's blocks,
@@ -367,6 +388,261 @@ __global__ void k_norm_bwd_apply(const float* __restrict__ x, int64_t ldx, const
   const float xh = (x[r * ldx + col] - mean[col]) * rs;
   const float g = gamma ? gamma[col] : 1.f;
   dx[r * lddx + col] = g * rs * (dy[r * lddy + col] - k12[col] - xh * k12[c + col]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm fused with the activation and the residual add, forward and backward (round 5; the unit the
+// APR training step repeats 21 times per encode: conv -> MinkowskiBatchNorm -> (+ x) -> ReLU, FCGF_APR/model/resunet.py:
+// 142-193, model/residual_block.py:37-53 under lib/complement_trainer.py:350-512).  Both directions are the partial-sum
+// launch + ONE apply launch whose workgroups rebuild the per-column constants from the block partials in a fixed order
+// (as k_norm_apply does): 2 launches each, no torch op, deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void column_sums(const double* __restrict__ partial, int nblk, int c, int col, bool live, int tx, int grp,
+                                   double (*s_a)[64], double (*s_q)[64], double& s, double& s2) {
+  s = 0.0;
+  s2 = 0.0;
+  if (live) {
+    for (int b0 = grp; b0 < nblk; b0 += 32) {      // the order of k_bn_finish / k_norm_apply
+      double a[8], q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 4 * u;
+        const bool ok = b < nblk;
+        a[u] = ok ? partial[((int64_t)b * 2 + 0) * c + col] : 0.0;
+        q[u] = ok ? partial[((int64_t)b * 2 + 1) * c + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += a[u];
+        s2 += q[u];
+      }
+    }
+  }
+  s_a[grp][tx] = s;
+  s_q[grp][tx] = s2;
+  __syncthreads();
+  s = ((s_a[0][tx] + s_a[1][tx]) + s_a[2][tx]) + s_a[3][tx];
+  s2 = ((s_q[0][tx] + s_q[1][tx]) + s_q[2][tx]) + s_q[3][tx];
+}
+
+// y = act((z - mean) * (rstd * gamma) + beta (+ residual)); the workgroups of row block 0 also publish mean / rstd and
+// update the running statistics (momentum, unbiased variance: torch.nn.BatchNorm1d's rule)
+__global__ __launch_bounds__(256) void k_bn_train_apply(const float* __restrict__ z, int64_t ldz, int64_t n, int c,
+                                                        const double* __restrict__ partial, int nblk,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, float momentum, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var, const float* __restrict__ residual,
+                                                        int64_t ldr, int relu, float* __restrict__ y, int64_t ldy,
+                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                        long long* __restrict__ num_batches_tracked) {
+  __shared__ double s_a[4][64], s_q[4][64];
+  __shared__ __attribute__((aligned(16))) float s_mean[64];
+  if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  __shared__ __attribute__((aligned(16))) float s_scale[64];
+  __shared__ __attribute__((aligned(16))) float s_shift[64];
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + tx;
+  double s, s2;
+  column_sums(partial, nblk, c, col, col < c, tx, grp, s_a, s_q, s, s2);
+  if (grp == 0 && col < c) {
+    const double m = s / (double)n;
+    const double v = s2 / (double)n - m * m;
+    const float mf = (float)m, vf = (float)(v > 0.0 ? v : 0.0);
+    const float rs = 1.0f / sqrtf(vf + eps);
+    s_mean[tx] = mf;
+    s_scale[tx] = gamma ? rs * gamma[col] : rs;
+    s_shift[tx] = beta ? beta[col] : 0.f;
+    if (blockIdx.x == 0) {
+      save_mean[col] = mf;
+      save_rstd[col] = rs;
+      if (running_mean) {
+        const float unb = n > 1 ? vf * ((float)n / (float)(n - 1)) : vf;
+        running_mean[col] = running_mean[col] * (1.f - momentum) + mf * momentum;
+        running_var[col] = running_var[col] * (1.f - momentum) + unb * momentum;
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * kApplyRows;
+  const int64_t r1 = min((long long)(r0 + kApplyRows), (long long)n);
+  const bool vec = (c & 3) == 0 && (ldz & 3) == 0 && (ldy & 3) == 0 && (!residual || (ldr & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y) |
+                     reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  if (vec) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int c4 = (threadIdx.x & 15) * 4, rr = threadIdx.x >> 4;
+    const int colv = blockIdx.y * 64 + c4;
+    if (colv >= c) return;
+    const f32x4 mv = *reinterpret_cast<const f32x4*>(&s_mean[c4]), scv = *reinterpret_cast<const f32x4*>(&s_scale[c4]),
+                shv = *reinterpret_cast<const f32x4*>(&s_shift[c4]);
+    for (int64_t r = r0 + rr; r < r1; r += 16) {
+      f32x4 v = (*reinterpret_cast<const f32x4*>(z + r * ldz + colv) - mv) * scv + shv;
+      if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * ldr + colv);
+      if (relu)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      *reinterpret_cast<f32x4*>(y + r * ldy + colv) = v;
+    }
+    return;
+  }
+  if (col >= c) return;
+  const float m = s_mean[tx], sc = s_scale[tx], sh = s_shift[tx];
+  for (int64_t r = r0 + grp; r < r1; r += 4) {
+    float v = (z[r * ldz + col] - m) * sc + sh;
+    if (residual) v += residual[r * ldr + col];
+    if (relu) v = fmaxf(v, 0.f);
+    y[r * ldy + col] = v;
+  }
+}
+
+// partial sums of g = act'(y) dy and of g * xhat per 256-row block (fp64); thread = 4 columns x one row of every 16
+__global__ __launch_bounds__(256) void k_bn_train_bwd_partial(const float* __restrict__ z, int64_t ldz,
+                                                              const float* __restrict__ y, int64_t ldy,
+                                                              const float* __restrict__ dy, int64_t lddy, int64_t n, int c,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              int relu, double* __restrict__ partial) {
+  __shared__ double s_v[16][16][8];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int colv = blockIdx.y * 64 + cq * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
+  const int64_t r1 = min((long long)(r0 + kRowsPerBlock), (long long)n);
+  double a4[4] = {0.0, 0.0, 0.0, 0.0}, b4[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool vec = (c & 3) == 0 && (ldz & 3) == 0 && (lddy & 3) == 0 && (!relu || (ldy & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dy) |
+                     (relu ? reinterpret_cast<uintptr_t>(y) : (uintptr_t)0)) & 15) == 0;
+  if (colv < c) {
+    float mv[4], rv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mv[e] = colv + e < c ? mean[colv + e] : 0.f;
+      rv[e] = colv + e < c ? rstd[colv + e] : 0.f;
+    }
+    for (int64_t rb = r0 + rl; rb < r1; rb += 64) {
+      f32x4 zv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = rb + 16 * u;
+        if (r < r1) {
+          if (vec) {
+            zv[u] = *reinterpret_cast<const f32x4*>(z + r * ldz + colv);
+            gv[u] = *reinterpret_cast<const f32x4*>(dy + r * lddy + colv);
+            if (relu) {
+              const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + colv);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) gv[u][e] = yv[e] > 0.f ? gv[u][e] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool in = colv + e < c;
+              zv[u][e] = in ? z[r * ldz + colv + e] : 0.f;
+              float g = in ? dy[r * lddy + colv + e] : 0.f;
+              if (relu && in && !(y[r * ldy + colv + e] > 0.f)) g = 0.f;
+              gv[u][e] = g;
+            }
+          }
+        } else {
+          zv[u] = (f32x4){mv[0], mv[1], mv[2], mv[3]};
+          gv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a4[e] += (double)gv[u][e];
+          b4[e] += (double)gv[u][e] * (double)((zv[u][e] - mv[e]) * rv[e]);
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s_v[rl][cq][e] = a4[e];
+    s_v[rl][cq][4 + e] = b4[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int cc = threadIdx.x & 63, which = threadIdx.x >> 6;
+    const int colw = blockIdx.y * 64 + cc;
+    if (colw < c) {
+      double t = 0.0;
+      for (int g = 0; g < 16; ++g) t += s_v[g][cc >> 2][which * 4 + (cc & 3)];
+      partial[((int64_t)blockIdx.x * 2 + which) * c + colw] = t;
+    }
+  }
+}
+
+// dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)), g = act'(y) dy; dres = g; dgamma / dbeta by row block 0
+__global__ __launch_bounds__(256) void k_bn_train_bwd_apply(const float* __restrict__ z, int64_t ldz,
+                                                            const float* __restrict__ y, int64_t ldy,
+                                                            const float* __restrict__ dy, int64_t lddy, int64_t n, int c,
+                                                            const double* __restrict__ partial, int nblk,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, int relu,
+                                                            float* __restrict__ dx, int64_t lddx, float* __restrict__ dres,
+                                                            int64_t lddres, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  __shared__ double s_a[4][64], s_q[4][64];
+  __shared__ __attribute__((aligned(16))) float s_mean[64];
+  __shared__ __attribute__((aligned(16))) float s_rstd[64];
+  __shared__ __attribute__((aligned(16))) float s_gs[64];
+  __shared__ __attribute__((aligned(16))) float s_k1[64];
+  __shared__ __attribute__((aligned(16))) float s_k2[64];
+  const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + tx;
+  double s, s2;
+  column_sums(partial, nblk, c, col, col < c, tx, grp, s_a, s_q, s, s2);
+  if (grp == 0) {
+    const bool live = col < c;
+    const float rs = live ? rstd[col] : 0.f;
+    s_mean[tx] = live ? mean[col] : 0.f;
+    s_rstd[tx] = rs;
+    s_gs[tx] = live ? (gamma ? gamma[col] * rs : rs) : 0.f;
+    s_k1[tx] = (float)(s / (double)n);
+    s_k2[tx] = (float)(s2 / (double)n);
+    if (live && blockIdx.x == 0) {
+      if (dbeta) dbeta[col] = (float)s;
+      if (dgamma) dgamma[col] = (float)s2;
+    }
+  }
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * kApplyRows;
+  const int64_t r1 = min((long long)(r0 + kApplyRows), (long long)n);
+  const bool vec = (c & 3) == 0 && (ldz & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && (!relu || (ldy & 3) == 0) &&
+                   (!dres || (lddres & 3) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                     reinterpret_cast<uintptr_t>(dres) | (relu ? reinterpret_cast<uintptr_t>(y) : (uintptr_t)0)) & 15) == 0;
+  if (vec) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int c4 = (threadIdx.x & 15) * 4, rr = threadIdx.x >> 4;
+    const int colv = blockIdx.y * 64 + c4;
+    if (colv >= c) return;
+    const f32x4 mv = *reinterpret_cast<const f32x4*>(&s_mean[c4]), rv = *reinterpret_cast<const f32x4*>(&s_rstd[c4]),
+                gs = *reinterpret_cast<const f32x4*>(&s_gs[c4]), k1 = *reinterpret_cast<const f32x4*>(&s_k1[c4]),
+                k2 = *reinterpret_cast<const f32x4*>(&s_k2[c4]);
+    for (int64_t r = r0 + rr; r < r1; r += 16) {
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + r * ldz + colv);
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + colv);
+      if (relu) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + colv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+      }
+      if (dres) *reinterpret_cast<f32x4*>(dres + r * lddres + colv) = g;
+      const f32x4 xh = (zv - mv) * rv;
+      *reinterpret_cast<f32x4*>(dx + r * lddx + colv) = gs * (g - k1 - xh * k2);
+    }
+    return;
+  }
+  if (col >= c) return;
+  for (int64_t r = r0 + grp; r < r1; r += 4) {
+    float g = dy[r * lddy + col];
+    if (relu && !(y[r * ldy + col] > 0.f)) g = 0.f;
+    if (dres) dres[r * lddres + col] = g;
+    const float xh = (z[r * ldz + col] - s_mean[tx]) * s_rstd[tx];
+    dx[r * lddx + col] = s_gs[tx] * (g - s_k1[tx] - xh * s_k2[tx]);
+  }
 }
 
 }  // namespace
@@ -525,6 +801,56 @@ APR_API int apr_act_backward(const float* dy, int64_t lddy, const float* y, int6
   if (nblk > 8192) nblk = 8192;
   hipLaunchKernelGGL(k_act_backward, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, n, c, mode,
                      negative_slope, dz, lddz);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+// Training-mode BatchNorm + residual + ReLU in two launches (statistics, apply) -- see the kernels' header.
+APR_API int apr_bn_train_fwd(const float* z, int64_t ldz, int64_t n, int32_t c, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var, const float* residual,
+                             int64_t ldr, int32_t relu, float* y, int64_t ldy, float* save_mean, float* save_rstd,
+                             int64_t* num_batches_tracked, void* scratch, size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(z && y && save_mean && save_rstd && n > 1 && c > 0 && ldz >= c && ldy >= c && eps >= 0.f,
+                "apr_bn_train_fwd: bad arguments (n=%lld c=%d)", (long long)n, c);
+  APR_CHECK_ARG(!residual || ldr >= c, "apr_bn_train_fwd: ldr < c");
+  APR_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "apr_bn_train_fwd: running_mean / running_var go together");
+  APR_CHECK_ARG(scratch && scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_bn_train_fwd: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv64(n, kRowsPerBlock);
+  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, st, z, ldz, c, one_segment(n), (double*)scratch);
+  hipLaunchKernelGGL(k_bn_train_apply, dim3((unsigned)cdiv64(n, kApplyRows), (c + 63) / 64), dim3(256), 0, st, z, ldz, n, c,
+                     (const double*)scratch, nblk, gamma, beta, eps, momentum, running_mean, running_var, residual, ldr,
+                     relu, y, ldy, save_mean, save_rstd, (long long*)num_batches_tracked);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_bn_train_bwd(const float* z, int64_t ldz, const float* y, int64_t ldy, const float* dy, int64_t lddy,
+                             int64_t n, int32_t c, const float* mean, const float* rstd, const float* gamma, int32_t relu,
+                             float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta, void* scratch,
+                             size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(z && dy && mean && rstd && dx && n > 0 && c > 0 && ldz >= c && lddy >= c && lddx >= c,
+                "apr_bn_train_bwd: bad arguments");
+  APR_CHECK_ARG(!relu || (y && ldy >= c), "apr_bn_train_bwd: the ReLU mask needs the forward's output y");
+  APR_CHECK_ARG(!dres || lddres >= c, "apr_bn_train_bwd: lddres < c");
+  APR_CHECK_ARG(scratch && scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_bn_train_bwd: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv64(n, kRowsPerBlock);
+  hipLaunchKernelGGL(k_bn_train_bwd_partial, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, z, ldz, y, ldy, dy, lddy, n, c, mean,
+                     rstd, relu, (double*)scratch);
+  hipLaunchKernelGGL(k_bn_train_bwd_apply, dim3((unsigned)cdiv64(n, kApplyRows), (c + 63) / 64), dim3(256), 0, st, z, ldz, y,
+                     ldy, dy, lddy, n, c, (const double*)scratch, nblk, mean, rstd, gamma, relu, dx, lddx, dres, lddres,
+                     dgamma, dbeta);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
+APR_API int apr_l2_normalize_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t n, int32_t c,
+                                      float* dx, int64_t lddx, void* stream) {
+  APR_CHECK_ARG(x && dy && dx && n >= 0 && c > 0 && ldx >= c && lddy >= c && lddx >= c, "apr_l2_normalize_backward: bad shape");
+  if (n == 0) return APR_OK;
+  hipLaunchKernelGGL(k_l2_normalize_bwd, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, n,
+                     c, dx, lddx);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -491,6 +491,18 @@ __global__ void k_pack_weights(const float* __restrict__ w, int K, int cin, int 
   wp[(((int64_t)k * (cin >> 2) + (ci >> 2)) * cout + co) * 4 + (ci & 3)] = w[t];
 }
 
+// wt[k'][co][ci] = w[k][ci][co], k' = K-1-k when flip: the kernel of a convolution's input gradient (the same operator
+// over the reverse map: mirrored offsets on a same-level map, transposed channel matrix)
+__global__ void k_flip_transpose(const float* __restrict__ w, int K, int cin, int cout, int flip, float* __restrict__ wt) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)K * cin * cout;
+  if (t >= total) return;
+  int ci = (int)(t % cin);
+  int co = (int)((t / cin) % cout);
+  int k = (int)(t / ((int64_t)cout * cin));
+  wt[t] = w[((int64_t)(flip ? K - 1 - k : k) * cin + ci) * cout + co];
+}
+
 inline bool use_mfma(int K, int cin, int cout) {
   return K <= 32 && cin % 32 == 0 && cout % 32 == 0;
 }
@@ -542,6 +554,16 @@ APR_API int apr_spconv_pack_weights(const float* w, int32_t K, int32_t cin, int3
     APR_HIP(hipMemcpyAsync(w_packed, w, total * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
   }
+  return APR_OK;
+}
+
+APR_API int apr_weights_flip_transpose(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t flip, float* wt,
+                                       void* stream) {
+  APR_CHECK_ARG(w && wt && K > 0 && cin > 0 && cout > 0, "apr_weights_flip_transpose: bad arguments");
+  const int64_t total = (int64_t)K * cin * cout;
+  hipLaunchKernelGGL(k_flip_transpose, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin, cout,
+                     flip, wt);
+  APR_LAUNCH_CHECK();
   return APR_OK;
 }
 

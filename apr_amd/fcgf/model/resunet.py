@@ -52,6 +52,8 @@ OS_MIN_ROWS = int(os.environ.get("APR_OS_MIN_ROWS", "50000"))
 ENCODE_PLAN = os.environ.get("APR_ENCODE_PLAN", "1") != "0"
 
 
+# train() + autograd: the fused-node path (forward_train); 0 = the module-by-module autograd path (A/B switch)
+TRAIN_FUSED = os.environ.get("APR_TRAIN_FUSED", "1") != "0"
 WS3_MAX_ROWS_128 = int(os.environ.get("APR_WS3_MAX_ROWS_128", "100000"))
 WS3_CIN128 = os.environ.get("APR_WS3_CIN128", "1") != "0"      # A/B switch: 0 = triple lists for 64 input channels only
 
@@ -317,9 +319,83 @@ class ResUNet2(ME.MinkowskiNetwork):
         batch.launch()
         return ME.SparseTensor(out, coordinate_map_key=CoordinateMapKey(1), coordinate_manager=cm)
 
+    # ------------------------------------------------------------------ training (round 5)
+    def _can_train_fused(self, x):
+        return (TRAIN_FUSED and self.training and torch.is_grad_enabled() and self.NORM_TYPE == 'BN'
+                and self.BLOCK_NORM_TYPE == 'BN' and x.coordinate_map_key.stride == 1 and x.F.shape[0] >= 2
+                and all(m.bn.weight is not None and m.bn.track_running_stats for m in self.modules()
+                        if isinstance(m, ME.MinkowskiBatchNorm)))
+
+    def forward_train(self, x):
+        """train() + autograd: the same network as `forward_modular`, walked as 23 fused autograd nodes
+        (ops.ConvBnActFunction: routed sparse conv -> training-mode BatchNorm -> (+ residual) -> ReLU, forward and backward
+        on the HIP kernels) instead of ~110 module-level ones with torch elementwise ops between them.  The ReLU the reference
+        applies to a block's output a second time (resunet.py:146-166) is the identity on it, forward and backward."""
+        cm = x.coordinate_manager
+        cm.build_pyramid([2, 4, 8])
+        ws = _ws_stages()
+        ws3 = os.environ.get("APR_WS3", "1") != "0"
+        k1 = self.conv1.kernel_size
+
+        def lists(name, conv, m, cin, has_bf3):
+            """Pair lists of map m for a layer with `cin` input channels, or None (tile kernel)."""
+            if name not in ws or m is None or not ops.ws_supported(27, cin, 64) or not has_bf3:
+                return None
+            tri = ws3 and ops.ws3_supported(27, cin, 64)
+            if tri and cin == 128 and ((m[0] == m[1] and cm.size(m[1]) > WS3_MAX_ROWS_128) or not WS3_CIN128):
+                tri = False
+            return cm.pair_list(*m, triples=tri)
+
+        def reverse(m):
+            ts_in, ts_out, k, tr = m
+            if ts_in == ts_out:
+                return m, True
+            return (ts_out, ts_in, k, not tr), False
+
+        def unit(stage_name, conv, norm, feats, m, relu, residual=None):
+            if m is None:                      # kernel size 1: the identity map
+                nbr = nbr_b = pl = pl_b = None
+                flip, n_out = False, feats.shape[0]
+            else:
+                nbr = cm.kernel_map(*m)
+                mb, flip = reverse(m)
+                nbr_b = nbr if flip else cm.kernel_map(*mb)
+                n_out = cm.size(m[1])
+                ok3 = conv.kernel.dim() == 3 and conv.kernel_volume == 27
+                pl = lists(stage_name, conv, m, conv.in_channels, ok3 and conv.packed_weight_bf3() is not None) \
+                    if conv.out_channels % 64 == 0 else None
+                pl_b = None
+                if feats.requires_grad and ok3 and conv.in_channels % 64 == 0:
+                    pl_b = lists(stage_name, conv, mb, conv.out_channels, conv.packed_weight_T(flip)[1] is not None)
+            cfg = dict(conv=conv, bn=norm, nbr=nbr, plist=pl, nbr_bwd=nbr_b, plist_bwd=pl_b, flip=flip, relu=relu, n_out=n_out)
+            bn = norm.bn if norm is not None else None
+            return ops.ConvBnActFunction.apply(feats, conv.kernel, bn.weight if bn is not None else None,
+                                               bn.bias if bn is not None else None, conv.bias, residual, cfg)
+
+        def stage(name, feats, cmap, bmap):
+            conv, norm, blk = getattr(self, "conv" + name), getattr(self, "norm" + name), getattr(self, "block" + name)
+            a = unit("conv" + name, conv, norm, feats, cmap, False)
+            h = unit("block" + name, blk.conv1, blk.norm1, a, bmap, True)
+            return unit("block" + name, blk.conv2, blk.norm2, h, bmap, True, residual=a)
+
+        s1 = stage("1", x.F, (1, 1, k1, False), (1, 1, 3, False))
+        s2 = stage("2", s1, (1, 2, 3, False), (2, 2, 3, False))
+        s4 = stage("3", s2, (2, 4, 3, False), (4, 4, 3, False))
+        s8 = stage("4", s4, (4, 8, 3, False), (8, 8, 3, False))
+        t4 = stage("4_tr", s8, (8, 4, 3, True), (4, 4, 3, False))
+        t2 = stage("3_tr", torch.cat((t4, s4), 1), (4, 2, 3, True), (2, 2, 3, False))
+        t1 = stage("2_tr", torch.cat((t2, s2), 1), (2, 1, 3, True), (1, 1, 3, False))
+        h = unit("conv1_tr", self.conv1_tr, None, torch.cat((t1, s1), 1), None, True)
+        out = unit("final", self.final, None, h, None, False)
+        if self.normalize_feature:
+            out = ops.L2NormalizeFunction.apply(out)
+        return ME.SparseTensor(out, coordinate_map_key=CoordinateMapKey(1), coordinate_manager=cm)
+
     def forward(self, x):
         if self._can_fuse():
             return self.forward_fused(x)
+        if self._can_train_fused(x):
+            return self.forward_train(x)
         return self.forward_modular(x)
 
 

@@ -25,13 +25,20 @@ def _f32_dev(a):
     return a.to(device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float32)
 
 
-def nn3(a, b, want_sum=True):
+NN3_CELL = 0.6      # grid cell of the accelerated 1-NN (two voxels of the 0.3 m clouds); 0 = brute force (same bits)
+
+
+def nn3(a, b, want_sum=True, cell=None):
     """Exact 1-NN of the rows of a [n,3] in b [m,3] -> (index int64 [n], d2 float32 [n], f64 sum or None)."""
     a, b = a.contiguous(), b.contiguous()
-    n = a.shape[0]
+    n, m = a.shape[0], b.shape[0]
+    cell = NN3_CELL if cell is None else float(cell)
+    lib = _lib.load()
     packed = torch.empty(n, dtype=torch.int64, device=a.device)
     total = torch.empty(1, dtype=torch.float64, device=a.device) if want_sum else None
-    check(_lib.load().apr_nn3(ptr(a), n, ptr(b), b.shape[0], ptr(packed), ptr(total), stream()))
+    sb = int(lib.apr_nn3_scratch_bytes(n, m)) if cell > 0 else 0
+    scratch = torch.empty(sb, dtype=torch.uint8, device=a.device) if sb else None
+    check(lib.apr_nn3(ptr(a), n, ptr(b), m, cell, ptr(packed), ptr(total), ptr(scratch), sb, stream()))
     idx = packed & 0xFFFFFFFF
     d2 = (packed >> 32).to(torch.int32).view(torch.float32)
     return idx, d2, (total[0] if want_sum else None)

@@ -675,6 +675,14 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         residual, ldr = _rows(residual, "spconv.residual")
         if residual.shape[0] != n_out or residual.shape[1] != cout:
             raise _lib.AprHipError("spconv: residual shape mismatch")
+    if (nbr is None and K == 1 and w_bf3 is not None and PROFILE is None and cin % 64 == 0 and cout % 64 == 0 and ldi % 4 == 0
+            and ldo % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
+            and (residual is None or (ldr % 4 == 0 and residual.data_ptr() % 16 == 0))
+            and (scale is None or scale.data_ptr() % 16 == 0) and (shift is None or shift.data_ptr() % 16 == 0)):
+        # identity map, 64-multiple widths: the dense GEMM on the bf16 split (what a batched launch picks as well)
+        check(_lib_().apr_dense_gemm_bf3(ptr(x), ldi, n_out, cin, cout, ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr,
+                                         int(bool(relu)), ptr(out), ldo, stream()))
+        return out
     use_ws = plist is not None and nbr is not None and ws_supported(K, cin, cout)
     use_ws3 = use_ws and isinstance(plist, PairList3)
     if use_ws3 and (w_bf3 is None or not ws3_supported(K, cin, cout)):
@@ -723,8 +731,18 @@ def dense_gemm_bf3(x, w_bf3, cin, cout, scale=None, shift=None, residual=None, r
     return out
 
 
-def spconv_wgrad(x, dout, nbr, K, cin, cout):
-    """dW f32 [K, cin, cout] = sum_j [nbr[j,k] >= 0] x[nbr[j,k]]^T dout[j]  (nbr None: identity map, K = 1)."""
+def weights_flip_transpose(w, flip):
+    """[K, cin, cout] -> [K, cout, cin] with the offsets mirrored when `flip` (apr_weights_flip_transpose)."""
+    w = _f32(w.detach(), "weights_flip_transpose.w").contiguous()
+    K, cin, cout = w.shape
+    wt = torch.empty((K, cout, cin), dtype=torch.float32, device=w.device)
+    check(_lib_().apr_weights_flip_transpose(ptr(w), K, cin, cout, int(bool(flip)), ptr(wt), stream()))
+    return wt
+
+
+def spconv_wgrad(x, dout, nbr, K, cin, cout, same_level=False):
+    """dW f32 [K, cin, cout] = sum_j [nbr[j,k] >= 0] x[nbr[j,k]]^T dout[j]  (nbr None: identity map, K = 1).
+    `same_level`: nbr is a stride-1 map of an odd kernel (its centre column is full): apr_spconv_wgrad_same_level."""
     x, ldi = _rows(x, "spconv_wgrad.x")
     dout, ldo = _rows(dout, "spconv_wgrad.dout")
     n_out = dout.shape[0]
@@ -736,9 +754,119 @@ def spconv_wgrad(x, dout, nbr, K, cin, cout):
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
     sb = int(lib.apr_spconv_wgrad_scratch_bytes(n_out, K, cin, cout))
     scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
-    check(lib.apr_spconv_wgrad(ptr(x), ldi, ptr(dout), ldo, ptr(nbr), n_out, K, cin, cout, ptr(dw), ptr(scratch), sb,
-                               stream()))
+    fn = lib.apr_spconv_wgrad_same_level if (same_level and nbr is not None) else lib.apr_spconv_wgrad
+    check(fn(ptr(x), ldi, ptr(dout), ldo, ptr(nbr), n_out, K, cin, cout, ptr(dw), ptr(scratch), sb, stream()))
     return dw
+
+
+def bn_train_fwd(z, bn, residual=None, relu=False):
+    """y = act(batch_norm(z) (+ residual)) with the batch statistics of z's rows, `bn`'s running statistics updated in place
+    (apr_bn_train_fwd: two launches) -> (y, save_mean, save_rstd)."""
+    z, ldz = _rows(z, "bn_train_fwd.z")
+    n, c = z.shape
+    lib = _lib_()
+    y = torch.empty((n, c), dtype=torch.float32, device=z.device)
+    stats = torch.empty((2, c), dtype=torch.float32, device=z.device)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "bn_train_fwd.residual")
+    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=z.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.0
+    if track:
+        # momentum None (cumulative average) needs the counter's value on the host: one sync per call, not used by APR
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+    g = bn.weight.detach() if bn.weight is not None else None
+    b = bn.bias.detach() if bn.bias is not None else None
+    check(lib.apr_bn_train_fwd(ptr(z), ldz, n, c, ptr(g), ptr(b), float(bn.eps), float(mom),
+                               ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                               ptr(residual), ldr, int(bool(relu)), ptr(y), c, ptr(stats[0]), ptr(stats[1]),
+                               ptr(bn.num_batches_tracked) if track else None, ptr(scratch), sb, stream()))
+    if track:
+        # the library wrote into the buffers behind torch's back: bump their version counters (folded-BN caches key on them)
+        torch.autograd.graph.increment_version((bn.running_mean, bn.running_var, bn.num_batches_tracked))
+    return y, stats[0], stats[1]
+
+
+def bn_train_bwd(z, y, dy, mean, rstd, gamma, relu, want_dres):
+    """-> (dz, dres or None, dgamma, dbeta) of bn_train_fwd (apr_bn_train_bwd: two launches, deterministic)."""
+    z, ldz = _rows(z, "bn_train_bwd.z")
+    dy, lddy = _rows(dy, "bn_train_bwd.dy")
+    n, c = z.shape
+    lib = _lib_()
+    ldy = 0
+    if relu:
+        y, ldy = _rows(y, "bn_train_bwd.y")
+    dz = torch.empty((n, c), dtype=torch.float32, device=z.device)
+    dres = torch.empty((n, c), dtype=torch.float32, device=z.device) if want_dres else None
+    dgb = torch.empty((2, c), dtype=torch.float32, device=z.device)
+    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=z.device)
+    check(lib.apr_bn_train_bwd(ptr(z), ldz, ptr(y) if relu else None, ldy, ptr(dy), lddy, n, c, ptr(mean), ptr(rstd),
+                               ptr(gamma), int(bool(relu)), ptr(dz), c, ptr(dres), c, ptr(dgb[0]), ptr(dgb[1]), ptr(scratch),
+                               sb, stream()))
+    return dz, dres, dgb[0], dgb[1]
+
+
+class ConvBnActFunction(torch.autograd.Function):
+    """One unit of a training encode -- sparse convolution -> training-mode BatchNorm -> (+ residual) -> ReLU
+    (FCGF_APR/model/resunet.py:142-193, model/residual_block.py:37-53 under lib/complement_trainer.py:350-512) -- as ONE
+    autograd node on the HIP kernels:
+      forward   z = conv(x) through the inference routing (weight-stationary / triple lists / tile kernel, no epilogue),
+                y = apr_bn_train_fwd(z) (statistics + apply; running statistics updated by the kernel);
+      backward  apr_bn_train_bwd (ReLU mask, dgamma, dbeta, dz, the residual's gradient), the input gradient = the SAME
+                routed convolution over the reverse map with the flipped-transposed kernel (packed once per optimizer step),
+                the kernel gradient = apr_spconv_wgrad on the bf16-split MFMA.
+    Without a norm (`bn` None: the two K = 1 layers behind the decoder) the bias add / ReLU ride in the conv epilogue.
+    `cfg`: a dict (conv, bn, nbr, plist, nbr_bwd, plist_bwd, flip, relu, n_out)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, gamma, beta, bias, residual, cfg):
+        conv, bn = cfg["conv"], cfg["bn"]
+        x = x.contiguous()
+        n_out = cfg["n_out"]
+        if bn is not None:
+            z = conv.run(x, cfg["nbr"], n_out, plist=cfg["plist"], raw=True)
+            y, mean, rstd = bn_train_fwd(z, bn.bn, residual=residual, relu=cfg["relu"])
+            ctx.save_for_backward(x, kernel, z, y, mean, rstd, gamma)
+        else:
+            y = conv.run(x, cfg["nbr"], n_out, plist=cfg["plist"], relu=cfg["relu"], residual=residual)
+            ctx.save_for_backward(x, kernel, y)
+        ctx.cfg = cfg
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg = ctx.cfg
+        conv, bn = cfg["conv"], cfg["bn"]
+        dy = dy.contiguous()
+        dgamma = dbeta = dbias = dres = None
+        if bn is not None:
+            x, kernel, z, y, mean, rstd, gamma = ctx.saved_tensors
+            dz, dres, dgamma, dbeta = bn_train_bwd(z, y, dy, mean, rstd, gamma.detach() if gamma is not None else None,
+                                                   cfg["relu"], ctx.has_res and ctx.needs_input_grad[5])
+            if gamma is not None:
+                dgamma = dgamma.reshape(gamma.shape)
+        else:
+            x, kernel, y = ctx.saved_tensors
+            dz = dy
+            if cfg["relu"]:
+                dz = torch.empty_like(dy)
+                c = dy.shape[1]
+                check(_lib_().apr_act_backward(ptr(dy), c, ptr(y), c, dy.shape[0], c, 1, 0.0, ptr(dz), c, stream()))
+            if ctx.has_res and ctx.needs_input_grad[5]:
+                dres = dz
+            if conv.bias is not None and ctx.needs_input_grad[4]:
+                dbias = col_sums(dz).reshape(conv.bias.shape)
+        K, cin, cout = conv.kernel_volume if cfg["nbr"] is not None else 1, conv.in_channels, conv.out_channels
+        din = dw = None
+        if ctx.needs_input_grad[0]:
+            din = conv.run_T(dz, cfg["nbr_bwd"], x.shape[0], cfg["flip"], plist=cfg["plist_bwd"])
+        if ctx.needs_input_grad[1]:
+            dw = spconv_wgrad(x, dz, cfg["nbr"], K, cin, cout, same_level=cfg["flip"]).reshape(kernel.shape)
+        return din, dw, dgamma, dbeta, dbias, dres, None
 
 
 class SparseConvFunction(torch.autograd.Function):
@@ -966,6 +1094,25 @@ def l2_normalize(x, out=None):
     out, ldy = _rows(out, "l2_normalize.out")
     check(_lib_().apr_l2_normalize(ptr(x), ldx, n, c, ptr(out), ldy, stream()))
     return out
+
+
+class L2NormalizeFunction(torch.autograd.Function):
+    """Row normalisation F / |F|_2 (FCGF_APR/model/resunet.py:187-190) with its backward on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return l2_normalize(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = x.shape
+        dx = torch.empty_like(x)
+        check(_lib_().apr_l2_normalize_backward(ptr(x), c, ptr(dy), c, n, c, ptr(dx), c, stream()))
+        return dx
 
 
 # ----------------------------------------------------------------------------

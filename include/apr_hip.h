@@ -196,6 +196,12 @@ int64_t apr_spconv_packed_size(int32_t K, int32_t cin, int32_t cout);
 int apr_spconv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout,
                             float* w_packed, void* stream);
 
+/* wt f32[K, cout, cin] = w[K, cin, cout] transposed per offset, offsets mirrored (k -> K-1-k) when flip != 0: the kernel
+ * with which apr_spconv_fwd over the reverse map computes a convolution's INPUT gradient (same-level map: the same table
+ * under the mirrored offset; strided <-> transposed maps: each other's table, no flip).  Backward of
+ * ME.MinkowskiConvolution / ConvolutionTranspose under FCGF_APR/lib/complement_trainer.py:484. */
+int apr_weights_flip_transpose(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t flip, float* wt, void* stream);
+
 int apr_spconv_fwd(const float* in, int64_t ldi, const int32_t* nbr, int64_t n_out,
                    int32_t K, int32_t cin, int32_t cout, const float* w_packed,
                    const float* scale, const float* shift,
@@ -266,6 +272,12 @@ size_t apr_spconv_wgrad_scratch_bytes(int64_t n_out, int32_t K, int32_t cin, int
 int apr_spconv_wgrad(const float* in, int64_t ldi, const float* dout, int64_t ldo, const int32_t* nbr, int64_t n_out,
                      int32_t K, int32_t cin, int32_t cout, float* dw, void* scratch, size_t scratch_bytes,
                      void* stream);
+/* The same when nbr is a SAME-LEVEL map (stride 1, odd kernel: the centre column holds every row, the others about a
+ * quarter): the centre offset's rows are spread over four times as many workgroups.  Identical sums, another grouping of
+ * the partials (results differ from apr_spconv_wgrad in the last bits; each entry point is bit-reproducible). */
+int apr_spconv_wgrad_same_level(const float* in, int64_t ldi, const float* dout, int64_t ldo, const int32_t* nbr,
+                                int64_t n_out, int32_t K, int32_t cin, int32_t cout, float* dw, void* scratch,
+                                size_t scratch_bytes, void* stream);
 
 /* Triple pair lists for 27-offset maps (spconv_ws.hip): offsets are x fastest, so k = 3t + j are the three x-neighbours of
  * one (dy, dz); an ENTRY of triple t is an output row with its up to three input rows, and the gemm writes ONE product
@@ -398,6 +410,25 @@ int apr_norm_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy
                       const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
                       float* dgamma, float* dbeta, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Training-mode BatchNorm fused with the residual add and the ReLU -- the unit a training encode repeats per convolution
+ * (MinkowskiBatchNorm in train(), FCGF_APR/model/common.py:6, model/residual_block.py:37-53, under
+ * lib/complement_trainer.py:350-512 / lib/trainer.py:454-527):
+ *   y = act((z - mean) * rstd * gamma + beta (+ residual)),  mean / biased var over the n rows (fp64 partial sums);
+ *   running_mean / running_var (nullable pair) updated in place as torch.nn.BatchNorm1d does (momentum, unbiased var);
+ *   save_mean / save_rstd [c] kept for the backward; *num_batches_tracked (nullable device int64) += 1.  relu: 0 / 1.
+ *   Two launches.  scratch: apr_bn_stats_scratch_bytes.
+ * apr_bn_train_bwd: g = dy masked by y > 0 (relu = 1); dres (nullable) = g, the residual branch's gradient;
+ *   dgamma = sum g * xhat, dbeta = sum g (nullable); dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)).
+ *   Partial sums in fp64 combined in a fixed order: the same bits every run.  Two launches. */
+int apr_bn_train_fwd(const float* z, int64_t ldz, int64_t n, int32_t c, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, const float* residual,
+                     int64_t ldr, int32_t relu, float* y, int64_t ldy, float* save_mean, float* save_rstd,
+                     int64_t* num_batches_tracked, void* scratch, size_t scratch_bytes, void* stream);
+int apr_bn_train_bwd(const float* z, int64_t ldz, const float* y, int64_t ldy, const float* dy, int64_t lddy,
+                     int64_t n, int32_t c, const float* mean, const float* rstd, const float* gamma, int32_t relu,
+                     float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta, void* scratch,
+                     size_t scratch_bytes, void* stream);
+
 /* sums[c] = sum over the n rows of x[:, c] (same scratch as apr_bn_stats; fp64 partial sums in fixed order): the bias
  * gradient of the 1x1 convolutions with bias in KPFCNN's training path (Predator_APR/models/architectures.py:92-101 under
  * lib/trainer.py:142-280). */
@@ -439,6 +470,10 @@ int apr_act_backward(const float* dy, int64_t lddy, const float* y, int64_t ldy,
 /* Row L2 normalisation F / ||F||_2 (FCGF_APR/model/resunet.py:187-191). */
 int apr_l2_normalize(const float* x, int64_t ldx, int64_t n, int32_t c,
                      float* y, int64_t ldy, void* stream);
+/* Its backward, dx = (dy - y (y . dy)) / |x| per row (the normalisation at the end of ResUNet2.forward under
+ * FCGF_APR/lib/complement_trainer.py:484). */
+int apr_l2_normalize_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t n, int32_t c,
+                              float* dx, int64_t lddx, void* stream);
 
 /* ------------------------------------------------------------------------
  * Feature nearest neighbour (squared L2), replaces find_nn_gpu / pdist
@@ -813,12 +848,17 @@ int apr_crop_to_radius(const float* key_pts, int64_t n_key, const float* pts, in
 int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m, double* out_dev, void* scratch,
                     size_t scratch_bytes, void* stream);
 
-/* Exact 1-NN of every row of a [n,3] among the rows of b [m,3] in fp32 ((dx^2 + dy^2) + dz^2, as chamferdist's
- * kernel sums it): out_packed[i] = (bits(d^2) << 32) | j, ties -> the smallest j.  sum_dev (may be NULL): f64 sum of
+/* Exact 1-NN of every row of a [n,3] among the rows of b [m,3] in fp32, (dx^2 + dy^2) + dz^2 with every operation rounded
+ * (no contraction): out_packed[i] = (bits(d^2) << 32) | j, ties -> the smallest j.  sum_dev (may be NULL): f64 sum of
  * the n minima in a fixed order (bit-reproducible).  The arg-min is what the backward of the Chamfer term needs
  * (Predator_APR/lib/trainer.py:131-140, 179-183; FCGF_APR/lib/complement_trainer.py:188-196, 446-448): the gradient
- * of sum_i min_j |a_i - b_j|^2 reaches a_i and b_argmin(i) only. */
-int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, uint64_t* out_packed, double* sum_dev, void* stream);
+ * of sum_i min_j |a_i - b_j|^2 reaches a_i and b_argmin(i) only.
+ * cell > 0: two uniform grids over b (cells `cell` and 8 * cell) answer the queries whose neighbour lies within ~12 cells,
+ * the rest fall through to the full search -- the same bits as cell = 0 (brute force, scratch unused) for every input.
+ * A good `cell` is a couple of voxel sizes (the clouds here carry one point per 0.3 m voxel). */
+size_t apr_nn3_scratch_bytes(int64_t n, int64_t m);
+int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
+            void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

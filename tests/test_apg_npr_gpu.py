@@ -109,3 +109,34 @@ def test_npr_loss_matches_restatement(dev):
         ref = d2.min(1)[0].sum() / len(mod) + d2.min(0)[0].sum() / len(nghb) + reg * 0.01
     got = apg.npr_reconstruction_loss(gen.to(dev), feats.to(dev), coords.to(dev), nghb.to(dev), 0.3, 4)
     assert abs(float(got) - float(ref)) < 1e-4 * float(ref)
+
+
+def test_grid_nn3_is_bit_identical_to_brute_force(dev):
+    """apr_nn3 with a cell (two grids + fall-through passes) against cell = 0 (brute force): the same packed (d^2, index)
+    for queries that resolve in the fine grid, in the coarse grid, and only in the full search; ties go to the smaller
+    index on both paths."""
+    from apr_amd import npr
+    rng = np.random.default_rng(21)
+    b = rng.uniform(-40, 40, (30000, 3)).astype(np.float32)
+    b[:, 2] = 0.05 * rng.standard_normal(30000).astype(np.float32)              # a ground-like sheet: ~0.5 m spacing
+    b[100] = b[7]                                                                # an exact duplicate: tie -> index 7
+    near = b[rng.integers(0, len(b), 20000)] + rng.normal(0, 0.15, (20000, 3)).astype(np.float32)
+    mid = b[rng.integers(0, len(b), 3000)] + np.array([0, 0, 2.5], np.float32)   # 2.5 m above the sheet: coarse grid
+    far = rng.uniform(-300, 300, (500, 3)).astype(np.float32)                    # tens of metres away: full search
+    a = np.concatenate([near, mid, far, b[7:8]]).astype(np.float32)
+    A, B = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    i0, d0, s0 = npr.nn3(A, B, cell=0.0)
+    for cell in (0.6, 0.25, 3.0):
+        i1, d1, s1 = npr.nn3(A, B, cell=cell)
+        assert torch.equal(i0, i1) and torch.equal(d0, d1) and float(s0) == float(s1), cell
+    assert int(i0[-1]) == 7
+    # against a float64 brute force: same neighbours up to exact-distance ties
+    d = torch.cdist(A[:5000].double(), B.double())
+    assert float((d.argmin(1) != i0[:5000]).float().mean()) < 1e-3
+    assert torch.allclose(d.min(1)[0].float() ** 2, d0[:5000], rtol=1e-4, atol=1e-6)
+    # the other direction of the Chamfer term (few targets, many queries) and a single-point target cloud
+    i2, d2, _ = npr.nn3(B, A[:3000])
+    i3, d3, _ = npr.nn3(B, A[:3000], cell=0.0)
+    assert torch.equal(i2, i3) and torch.equal(d2, d3)
+    i4, _, _ = npr.nn3(A[:100], B[:1])
+    assert int(i4.max()) == 0

@@ -38,6 +38,35 @@ def test_wgrad_kernel_matches_autograd(dev, cin, cout, K, n_in, n_out):
     assert rel_l2(dw.cpu(), W.grad) < 2e-6
     again = ops.spconv_wgrad(x.to(dev), g.to(dev), torch.from_numpy(nbr).to(dev), K, cin, cout)
     assert torch.equal(dw, again)                      # deterministic
+    # the same-level entry point (centre offset spread over more workgroups): same sums, another grouping of the partials
+    same = ops.spconv_wgrad(x.to(dev), g.to(dev), torch.from_numpy(nbr).to(dev), K, cin, cout, same_level=True)
+    assert rel_l2(same.cpu(), W.grad) < 2e-6
+    assert torch.equal(same, ops.spconv_wgrad(x.to(dev), g.to(dev), torch.from_numpy(nbr).to(dev), K, cin, cout, same_level=True))
+
+
+def test_wgrad_identity_map_and_many_row_blocks(dev):
+    """K = 1 with nbr = None (Linear layers, 1x1 convolutions) and a map long enough for several 512-row blocks per work
+    item of the bf16-split kernel, centre column full as on a real stride-1 map."""
+    rng = np.random.default_rng(11)
+    n, cin, cout = 9000, 160, 128
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(dev)
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(dev)
+    dw = ops.spconv_wgrad(x, g, None, 1, cin, cout)
+    ref = x.double().t() @ g.double()
+    assert rel_l2(dw[0].cpu(), ref.cpu()) < 2e-6
+    K, cin, cout = 27, 64, 64
+    nbr = rng.integers(0, n, size=(n, K)).astype(np.int32)
+    nbr[rng.random((n, K)) > 0.25] = -1
+    nbr[:, 13] = np.arange(n)
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(dev)
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(dev)
+    nb = torch.from_numpy(nbr).to(dev)
+    dw = ops.spconv_wgrad(x, g, nb, K, cin, cout, same_level=True)
+    ref = torch.zeros(K, cin, cout, dtype=torch.float64, device=dev)
+    for k in range(K):
+        j = torch.nonzero(nb[:, k] >= 0).squeeze(1)
+        ref[k] = x[nb[j, k].long()].double().t() @ g[j].double()
+    assert rel_l2(dw.cpu(), ref.cpu()) < 2e-6
 
 
 @pytest.mark.parametrize("kind", ["same", "strided", "transposed"])
@@ -88,9 +117,19 @@ def test_conv_module_gradients(dev, kind):
         assert rel_l2(down_h.kernel.grad.cpu(), Wdo.grad) < 1e-5
 
 
-def test_encoder_training_step_gradients(dev):
+@pytest.mark.parametrize("routing", ["tile", "default"])
+def test_encoder_training_step_gradients(dev, routing, monkeypatch):
     """ResUNetBN2C in train mode: forward, a scalar loss, backward — every parameter gradient and the BN running
-    statistics against the oracle network (same state_dict) on the CPU."""
+    statistics against the oracle network (same state_dict) on the CPU.
+
+    Round 5: train() now walks the fused nodes (ResUNet2.forward_train).  "tile": every convolution on the tile kernel, the
+    summation order of rounds 1-4 -- the original 2e-3 bar (measured 1e-6).  "default": the inference routing
+    (weight-stationary / triple-list kernels) -- another summation order, features still equal to 5e-7, but ONE output of
+    the last residual block lands on the other side of its ReLU's kink than in the oracle (scripts/dbg_train_units.py:
+    1 mask flip in 266 k entries; with the oracle's mask the same gradients agree to 3e-7).  A single flipped entry is
+    1 / sqrt(N) = 2e-3 of that layer's gradient norm and rides upstream from there, so this leg's bar is 1e-2."""
+    if routing == "tile":
+        monkeypatch.setenv("APR_WS_STAGES", "none")
     om, hm = model_pair("ResUNetBN2C", 32)
     om.train(); hm.train()
     xyz, _, _ = synth.make_pair(5, n_beams=16, n_azimuth=700)
@@ -108,11 +147,13 @@ def test_encoder_training_step_gradients(dev):
     for name, p in hm.named_parameters():
         assert p.grad is not None, name
         worst = max(worst, rel_l2(p.grad.cpu(), og[name].grad))
-    assert worst < 2e-3, worst                       # fp32 through 23 conv + 22 BN layers, two different BN kernels
+    assert worst < (2e-3 if routing == "tile" else 1e-2), worst   # fp32 through 23 conv + 22 BN layers
     ob = dict(om.named_buffers())
     for name, b in hm.named_buffers():
         if name.endswith("running_mean") or name.endswith("running_var"):
             assert torch.allclose(b.cpu(), ob[name], rtol=1e-3, atol=1e-5), name
+        if name.endswith("num_batches_tracked"):
+            assert int(b) == int(ob[name]) == 1, name
 
 
 def test_hardest_contrastive_loss_backward(dev):
@@ -177,3 +218,35 @@ def test_two_sgd_steps_follow_the_oracle(dev):
     op = dict(om.named_parameters())
     for name, p in hm.named_parameters():
         assert rel_l2(p.detach().cpu(), op[name].detach()) < 1e-3, name
+
+
+def test_fused_training_path_matches_module_path_and_is_reproducible(dev, monkeypatch):
+    """Round 5: ResUNet2.forward_train (23 fused autograd nodes: routed conv -> apr_bn_train_fwd / _bwd, bf16-split wgrad)
+    against the module-by-module autograd path on APR's own encoder (ResUNetFatBN, 128 features): features, every gradient,
+    the running statistics; and the same bits from two runs of the fused path."""
+    from apr_amd.fcgf.model import resunet as RU
+    _, hm = model_pair("ResUNetFatBN", 128, seed=2)
+    hm.train()
+    state0 = {k: v.clone() for k, v in hm.state_dict().items()}
+    xyz, _, _ = synth.make_pair(6, n_beams=32, n_azimuth=900)
+    c, _ = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+    C = torch.from_numpy(OME.batched_coordinates([c])).to(dev)
+    proj = None
+    runs = []
+    for fused in (True, True, False):
+        monkeypatch.setattr(RU, "TRAIN_FUSED", fused)
+        hm.load_state_dict(state0)
+        hm.zero_grad()
+        y = hm(ME.SparseTensor(torch.ones(len(C), 1, device=dev), coordinates=C)).F
+        if proj is None:
+            proj = torch.from_numpy(np.random.default_rng(1).standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+        (y * proj).sum().backward()
+        runs.append((y.detach().clone(), {n: p.grad.clone() for n, p in hm.named_parameters()},
+                     {n: b.clone() for n, b in hm.named_buffers()}))
+    (ya, ga, ba), (yb, gb, bb), (ym, gm, bm) = runs
+    assert torch.equal(ya, yb) and all(torch.equal(ga[n], gb[n]) for n in ga) and all(torch.equal(ba[n], bb[n]) for n in ba)
+    assert rel_l2(ya.cpu(), ym.cpu()) < 1e-4
+    worst = max(rel_l2(ga[n].cpu(), gm[n].cpu()) for n in ga)
+    assert worst < 1e-2, worst          # other summation order in the routed kernels: ReLU kink flips (see the test above)
+    for n in ba:
+        assert torch.allclose(ba[n].float(), bm[n].float(), rtol=1e-4, atol=1e-6), n
