@@ -279,7 +279,9 @@ class SparseTensor:
             c = coordinates.to(device=device)
             if c.dtype.is_floating_point:
                 c = torch.floor(c)
-            self.coordinate_manager = CoordinateManager(c.to(torch.int32).contiguous())
+            c = c.to(torch.int32).contiguous()
+            self._input_coords = c                 # rows keep the input order: .C of a fresh tensor without finalising its map
+            self.coordinate_manager = CoordinateManager(c)
             self.coordinate_map_key = CoordinateMapKey(1)
         else:
             if coordinate_manager is None or coordinate_map_key is None:

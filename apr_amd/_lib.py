@@ -140,9 +140,9 @@ PROTOTYPES = {
     "apr_norm_backward_scratch_bytes": (_sz, [_i64, _i32]),
     "apr_norm_backward": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     "apr_bn_train_fwd": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, C.c_float, C.c_float, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p,
-                                   _p, _p, _sz, _p]),
-    "apr_bn_train_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p, _p,
-                                   _sz, _p]),
+                                   _p, _p, _i32, _p, _sz, _p]),
+    "apr_bn_train_bwd": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p,
+                                   _p, _i32, _p, _sz, _p]),
     "apr_weights_flip_transpose": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_dense_gemm_bf3": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "apr_weighted_choice_round": (C.c_int64, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i32]),

@@ -145,13 +145,14 @@ __global__ __launch_bounds__(256) void k_nn3_arg(const float* __restrict__ a, in
 // ---------------------------------------------------------------------------------------------------------------------
 // Grid-accelerated exact 1-NN (round 5).  The brute-force search above is n x m distance evaluations (56 k generated points
 // against a 50-56 k-point APG cloud, both directions, both frames: 3 ms of a training iteration); nearly every query has its
-// neighbour within a voxel or two.  Two uniform grids over the targets (cells c and 8 c: points.hip's search grid), three
-// passes, every one exact:
-//   A  thread per query, fine grid: the 2^3 cells around the query (everything within 0.49 c), then the 4^3 shell (1.47 c);
+// neighbour within a voxel or two.  One uniform grid over the targets (cell c: points.hip's search grid), two passes, both
+// exact:
+//   A  thread per query: the 2^3 cells around the query (everything within 0.49 c), then the 4^3 shell (1.49 c);
 //      a query whose best distance is inside the covered radius is DONE -- no closer point can exist outside the cells
 //      read -- the others go to a list (wave-aggregated append; the order of the list does not matter);
-//   B  wave per listed query, coarse grid, same two rings (3.9 c, 11.8 c), lanes stride over a cell's points;
-//   C  wave per still-unresolved query over all m targets.
+//   B  wave per listed query over all m targets (lanes stride): a few per cent of the queries on LiDAR clouds.
+//   (A coarser second grid between the two was built and dropped: its build costs ~20 launches per call, more host time
+//   than the full search of the few remaining queries costs on the GPU.)
 // Distances are (dx^2 + dy^2) + dz^2 with explicitly rounded operations in every pass, ties go to the smaller index: the
 // packed result is bit-identical to k_nn3_arg's whatever path a query took (tested).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -360,7 +361,7 @@ APR_API int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m
 }
 
 APR_API size_t apr_nn3_scratch_bytes(int64_t n, int64_t m) {
-  return 2 * align256(apr_internal_grid_bytes(m)) + 2 * align256((size_t)(n > 0 ? n : 1) * 4) + 1024;
+  return align256(apr_internal_grid_bytes(m)) + align256((size_t)(n > 0 ? n : 1) * 4) + 1024;
 }
 
 APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
@@ -373,24 +374,16 @@ APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float 
     char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     void* g1s = p;
     p += align256(apr_internal_grid_bytes(m));
-    void* g2s = p;
-    p += align256(apr_internal_grid_bytes(m));
     int* list1 = (int*)p;
     p += align256((size_t)n * 4);
-    int* list2 = (int*)p;
-    p += align256((size_t)n * 4);
-    int* counts = (int*)p;                                     // [0] list1, [1] list2
-    AprSearchGrid g1, g2, none;
+    int* counts = (int*)p;
+    AprSearchGrid g1, none;
     int rc = apr_internal_search_grid(b, m, cell, g1s, &g1, st);
-    if (rc != APR_OK) return rc;
-    rc = apr_internal_search_grid(b, m, 8.f * cell, g2s, &g2, st);
     if (rc != APR_OK) return rc;
     memset(&none, 0, sizeof(none));
     APR_HIP(hipMemsetAsync(counts, 0, 8, st));
     hipLaunchKernelGGL(k_nn3_grid_thread, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, a, n, b, g1, best, list1, counts);
-    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, g2, list1, counts, best, list2,
-                       counts + 1);
-    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, none, list2, counts + 1, best,
+    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, none, list1, counts, best,
                        (int*)nullptr, (int*)nullptr);
   } else {
     APR_HIP(hipMemsetAsync(out_packed, 0xFF, (size_t)n * 8, st));

@@ -425,10 +425,12 @@ __device__ inline void column_sums(const double* __restrict__ partial, int nblk,
   s2 = ((s_q[0][tx] + s_q[1][tx]) + s_q[2][tx]) + s_q[3][tx];
 }
 
-// y = act((z - mean) * (rstd * gamma) + beta (+ residual)); the workgroups of row block 0 also publish mean / rstd and
-// update the running statistics (momentum, unbiased variance: torch.nn.BatchNorm1d's rule)
-__global__ __launch_bounds__(256) void k_bn_train_apply(const float* __restrict__ z, int64_t ldz, int64_t n, int c,
-                                                        const double* __restrict__ partial, int nblk,
+// y = act((z - mean) * (rstd * gamma) + beta (+ residual)) per row segment (blockIdx.z; a segment = one forward call of the
+// reference: the two frames of a pair stacked into one launch keep their own statistics); the workgroups of a segment's
+// row block 0 publish its mean / rstd, and those of segment 0 update the running statistics segment after segment in
+// order (momentum, unbiased variance: what torch.nn.BatchNorm1d does over consecutive calls)
+__global__ __launch_bounds__(256) void k_bn_train_apply(const float* __restrict__ z, int64_t ldz, int c, Segs sg, int nseg,
+                                                        const double* __restrict__ partial,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, float momentum, float* __restrict__ running_mean,
                                                         float* __restrict__ running_var, const float* __restrict__ residual,
@@ -437,13 +439,36 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float* __restrict_
                                                         long long* __restrict__ num_batches_tracked) {
   __shared__ double s_a[4][64], s_q[4][64];
   __shared__ __attribute__((aligned(16))) float s_mean[64];
-  if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   __shared__ __attribute__((aligned(16))) float s_scale[64];
   __shared__ __attribute__((aligned(16))) float s_shift[64];
+  const int seg = blockIdx.z;
+  const int64_t n = sg.row0[seg + 1] - sg.row0[seg];
+  if ((int64_t)blockIdx.x * kApplyRows >= n) return;                       // workgroup-uniform: shorter segment
+  if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && seg == 0 && threadIdx.x == 0) *num_batches_tracked += nseg;
   const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 + tx;
   double s, s2;
-  column_sums(partial, nblk, c, col, col < c, tx, grp, s_a, s_q, s, s2);
+  if (running_mean && blockIdx.x == 0 && seg == 0) {                       // workgroup-uniform
+    float rm = 0.f, rv = 0.f;
+    if (grp == 0 && col < c) rm = running_mean[col], rv = running_var[col];
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+      const int64_t ns = sg.row0[sgi + 1] - sg.row0[sgi];
+      column_sums(partial + (int64_t)sg.blk0[sgi] * 2 * c, sg.blk0[sgi + 1] - sg.blk0[sgi], c, col, col < c, tx, grp, s_a, s_q, s,
+                  s2);
+      if (grp == 0 && col < c) {
+        const double m = s / (double)ns;
+        const double v = s2 / (double)ns - m * m;
+        const float mf = (float)m, vf = (float)(v > 0.0 ? v : 0.0);
+        const float unb = ns > 1 ? vf * ((float)ns / (float)(ns - 1)) : vf;
+        rm = rm * (1.f - momentum) + mf * momentum;
+        rv = rv * (1.f - momentum) + unb * momentum;
+      }
+      __syncthreads();                                                     // s_a / s_q are reused by the next segment
+    }
+    if (grp == 0 && col < c) running_mean[col] = rm, running_var[col] = rv;
+  }
+  const int nblk = sg.blk0[seg + 1] - sg.blk0[seg];
+  column_sums(partial + (int64_t)sg.blk0[seg] * 2 * c, nblk, c, col, col < c, tx, grp, s_a, s_q, s, s2);
   if (grp == 0 && col < c) {
     const double m = s / (double)n;
     const double v = s2 / (double)n - m * m;
@@ -453,16 +478,14 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float* __restrict_
     s_scale[tx] = gamma ? rs * gamma[col] : rs;
     s_shift[tx] = beta ? beta[col] : 0.f;
     if (blockIdx.x == 0) {
-      save_mean[col] = mf;
-      save_rstd[col] = rs;
-      if (running_mean) {
-        const float unb = n > 1 ? vf * ((float)n / (float)(n - 1)) : vf;
-        running_mean[col] = running_mean[col] * (1.f - momentum) + mf * momentum;
-        running_var[col] = running_var[col] * (1.f - momentum) + unb * momentum;
-      }
+      save_mean[(int64_t)seg * c + col] = mf;
+      save_rstd[(int64_t)seg * c + col] = rs;
     }
   }
   __syncthreads();
+  z += sg.row0[seg] * ldz;
+  y += sg.row0[seg] * ldy;
+  if (residual) residual += sg.row0[seg] * ldr;
   const int64_t r0 = (int64_t)blockIdx.x * kApplyRows;
   const int64_t r1 = min((long long)(r0 + kApplyRows), (long long)n);
   const bool vec = (c & 3) == 0 && (ldz & 3) == 0 && (ldy & 3) == 0 && (!residual || (ldr & 3) == 0) &&
@@ -498,11 +521,20 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float* __restrict_
 // partial sums of g = act'(y) dy and of g * xhat per 256-row block (fp64); thread = 4 columns x one row of every 16
 __global__ __launch_bounds__(256) void k_bn_train_bwd_partial(const float* __restrict__ z, int64_t ldz,
                                                               const float* __restrict__ y, int64_t ldy,
-                                                              const float* __restrict__ dy, int64_t lddy, int64_t n, int c,
+                                                              const float* __restrict__ dy, int64_t lddy, Segs sg, int c,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               int relu, double* __restrict__ partial) {
   __shared__ double s_v[16][16][8];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int seg = blockIdx.z;
+  if ((int)blockIdx.x >= sg.blk0[seg + 1] - sg.blk0[seg]) return;        // workgroup-uniform: shorter segment
+  const int64_t n = sg.row0[seg + 1] - sg.row0[seg];
+  z += sg.row0[seg] * ldz;
+  dy += sg.row0[seg] * lddy;
+  if (relu) y += sg.row0[seg] * ldy;
+  mean += (int64_t)seg * c;
+  rstd += (int64_t)seg * c;
+  partial += (int64_t)sg.blk0[seg] * 2 * c;
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int colv = blockIdx.y * 64 + cq * 4;
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
@@ -573,11 +605,12 @@ __global__ __launch_bounds__(256) void k_bn_train_bwd_partial(const float* __res
   }
 }
 
-// dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)), g = act'(y) dy; dres = g; dgamma / dbeta by row block 0
+// dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) with the segment's own means, g = act'(y) dy; dres = g;
+// dgamma / dbeta (sums over ALL segments, in segment order) by the workgroups of segment 0's row block 0
 __global__ __launch_bounds__(256) void k_bn_train_bwd_apply(const float* __restrict__ z, int64_t ldz,
                                                             const float* __restrict__ y, int64_t ldy,
-                                                            const float* __restrict__ dy, int64_t lddy, int64_t n, int c,
-                                                            const double* __restrict__ partial, int nblk,
+                                                            const float* __restrict__ dy, int64_t lddy, Segs sg, int nseg, int c,
+                                                            const double* __restrict__ partial,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int relu,
                                                             float* __restrict__ dx, int64_t lddx, float* __restrict__ dres,
@@ -589,24 +622,42 @@ __global__ __launch_bounds__(256) void k_bn_train_bwd_apply(const float* __restr
   __shared__ __attribute__((aligned(16))) float s_gs[64];
   __shared__ __attribute__((aligned(16))) float s_k1[64];
   __shared__ __attribute__((aligned(16))) float s_k2[64];
+  const int seg = blockIdx.z;
+  const int64_t n = sg.row0[seg + 1] - sg.row0[seg];
+  if ((int64_t)blockIdx.x * kApplyRows >= n) return;                       // workgroup-uniform: shorter segment
   const int tx = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 + tx;
   double s, s2;
-  column_sums(partial, nblk, c, col, col < c, tx, grp, s_a, s_q, s, s2);
+  if ((dgamma || dbeta) && blockIdx.x == 0 && seg == 0) {                  // workgroup-uniform
+    double ta = 0.0, tb = 0.0;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+      column_sums(partial + (int64_t)sg.blk0[sgi] * 2 * c, sg.blk0[sgi + 1] - sg.blk0[sgi], c, col, col < c, tx, grp, s_a, s_q, s,
+                  s2);
+      ta += s;
+      tb += s2;
+      __syncthreads();
+    }
+    if (grp == 0 && col < c) {
+      if (dbeta) dbeta[col] = (float)ta;
+      if (dgamma) dgamma[col] = (float)tb;
+    }
+  }
+  column_sums(partial + (int64_t)sg.blk0[seg] * 2 * c, sg.blk0[seg + 1] - sg.blk0[seg], c, col, col < c, tx, grp, s_a, s_q, s, s2);
   if (grp == 0) {
     const bool live = col < c;
-    const float rs = live ? rstd[col] : 0.f;
-    s_mean[tx] = live ? mean[col] : 0.f;
+    const float rs = live ? rstd[(int64_t)seg * c + col] : 0.f;
+    s_mean[tx] = live ? mean[(int64_t)seg * c + col] : 0.f;
     s_rstd[tx] = rs;
     s_gs[tx] = live ? (gamma ? gamma[col] * rs : rs) : 0.f;
     s_k1[tx] = (float)(s / (double)n);
     s_k2[tx] = (float)(s2 / (double)n);
-    if (live && blockIdx.x == 0) {
-      if (dbeta) dbeta[col] = (float)s;
-      if (dgamma) dgamma[col] = (float)s2;
-    }
   }
   __syncthreads();
+  z += sg.row0[seg] * ldz;
+  dy += sg.row0[seg] * lddy;
+  dx += sg.row0[seg] * lddx;
+  if (relu) y += sg.row0[seg] * ldy;
+  if (dres) dres += sg.row0[seg] * lddres;
   const int64_t r0 = (int64_t)blockIdx.x * kApplyRows;
   const int64_t r1 = min((long long)(r0 + kApplyRows), (long long)n);
   const bool vec = (c & 3) == 0 && (ldz & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && (!relu || (ldy & 3) == 0) &&
@@ -806,20 +857,45 @@ APR_API int apr_act_backward(const float* dy, int64_t lddy, const float* y, int6
 }
 
 // Training-mode BatchNorm + residual + ReLU in two launches (statistics, apply) -- see the kernels' header.
+static int make_segs(const int64_t* seg_offsets_host, int32_t nseg, int64_t n, Segs& sg, int64_t& max_rows) {
+  if (!seg_offsets_host || nseg <= 1) {
+    sg = one_segment(n);
+    max_rows = n;
+    return 1;
+  }
+  if (nseg > kMaxSeg || seg_offsets_host[0] != 0 || seg_offsets_host[nseg] != n) return -1;
+  sg.row0[0] = 0;
+  sg.blk0[0] = 0;
+  max_rows = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const int64_t rows = seg_offsets_host[i + 1] - seg_offsets_host[i];
+    if (rows < 2) return -1;
+    sg.row0[i + 1] = seg_offsets_host[i + 1];
+    sg.blk0[i + 1] = sg.blk0[i] + (int)cdiv64(rows, kRowsPerBlock);
+    if (rows > max_rows) max_rows = rows;
+  }
+  return nseg;
+}
+
 APR_API int apr_bn_train_fwd(const float* z, int64_t ldz, int64_t n, int32_t c, const float* gamma, const float* beta,
                              float eps, float momentum, float* running_mean, float* running_var, const float* residual,
                              int64_t ldr, int32_t relu, float* y, int64_t ldy, float* save_mean, float* save_rstd,
-                             int64_t* num_batches_tracked, void* scratch, size_t scratch_bytes, void* stream) {
+                             int64_t* num_batches_tracked, const int64_t* seg_offsets_host, int32_t nseg, void* scratch,
+                             size_t scratch_bytes, void* stream) {
   APR_CHECK_ARG(z && y && save_mean && save_rstd && n > 1 && c > 0 && ldz >= c && ldy >= c && eps >= 0.f,
                 "apr_bn_train_fwd: bad arguments (n=%lld c=%d)", (long long)n, c);
   APR_CHECK_ARG(!residual || ldr >= c, "apr_bn_train_fwd: ldr < c");
   APR_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "apr_bn_train_fwd: running_mean / running_var go together");
-  APR_CHECK_ARG(scratch && scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_bn_train_fwd: scratch too small");
+  Segs sg;
+  int64_t max_rows;
+  const int ns = make_segs(seg_offsets_host, nseg, n, sg, max_rows);
+  APR_CHECK_ARG(ns >= 1, "apr_bn_train_fwd: segment offsets must run 0 .. n in at most %d segments of >= 2 rows", kMaxSeg);
+  APR_CHECK_ARG(scratch && scratch_bytes >= apr_bn_stats_scratch_bytes(n + 256 * (int64_t)ns, c), "apr_bn_train_fwd: scratch too small");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)cdiv64(n, kRowsPerBlock);
-  hipLaunchKernelGGL(k_bn_partial, dim3(nblk, (c + 63) / 64), dim3(1024), 0, st, z, ldz, c, one_segment(n), (double*)scratch);
-  hipLaunchKernelGGL(k_bn_train_apply, dim3((unsigned)cdiv64(n, kApplyRows), (c + 63) / 64), dim3(256), 0, st, z, ldz, n, c,
-                     (const double*)scratch, nblk, gamma, beta, eps, momentum, running_mean, running_var, residual, ldr,
+  hipLaunchKernelGGL(k_bn_partial, dim3((unsigned)cdiv64(max_rows, kRowsPerBlock), (c + 63) / 64, ns), dim3(1024), 0, st, z, ldz,
+                     c, sg, (double*)scratch);
+  hipLaunchKernelGGL(k_bn_train_apply, dim3((unsigned)cdiv64(max_rows, kApplyRows), (c + 63) / 64, ns), dim3(256), 0, st, z, ldz,
+                     c, sg, ns, (const double*)scratch, gamma, beta, eps, momentum, running_mean, running_var, residual, ldr,
                      relu, y, ldy, save_mean, save_rstd, (long long*)num_batches_tracked);
   APR_LAUNCH_CHECK();
   return APR_OK;
@@ -827,19 +903,22 @@ APR_API int apr_bn_train_fwd(const float* z, int64_t ldz, int64_t n, int32_t c, 
 
 APR_API int apr_bn_train_bwd(const float* z, int64_t ldz, const float* y, int64_t ldy, const float* dy, int64_t lddy,
                              int64_t n, int32_t c, const float* mean, const float* rstd, const float* gamma, int32_t relu,
-                             float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta, void* scratch,
-                             size_t scratch_bytes, void* stream) {
+                             float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta,
+                             const int64_t* seg_offsets_host, int32_t nseg, void* scratch, size_t scratch_bytes, void* stream) {
   APR_CHECK_ARG(z && dy && mean && rstd && dx && n > 0 && c > 0 && ldz >= c && lddy >= c && lddx >= c,
                 "apr_bn_train_bwd: bad arguments");
   APR_CHECK_ARG(!relu || (y && ldy >= c), "apr_bn_train_bwd: the ReLU mask needs the forward's output y");
   APR_CHECK_ARG(!dres || lddres >= c, "apr_bn_train_bwd: lddres < c");
-  APR_CHECK_ARG(scratch && scratch_bytes >= apr_bn_stats_scratch_bytes(n, c), "apr_bn_train_bwd: scratch too small");
+  Segs sg;
+  int64_t max_rows;
+  const int ns = make_segs(seg_offsets_host, nseg, n, sg, max_rows);
+  APR_CHECK_ARG(ns >= 1, "apr_bn_train_bwd: segment offsets must run 0 .. n in at most %d segments of >= 2 rows", kMaxSeg);
+  APR_CHECK_ARG(scratch && scratch_bytes >= apr_bn_stats_scratch_bytes(n + 256 * (int64_t)ns, c), "apr_bn_train_bwd: scratch too small");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)cdiv64(n, kRowsPerBlock);
-  hipLaunchKernelGGL(k_bn_train_bwd_partial, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, z, ldz, y, ldy, dy, lddy, n, c, mean,
-                     rstd, relu, (double*)scratch);
-  hipLaunchKernelGGL(k_bn_train_bwd_apply, dim3((unsigned)cdiv64(n, kApplyRows), (c + 63) / 64), dim3(256), 0, st, z, ldz, y,
-                     ldy, dy, lddy, n, c, (const double*)scratch, nblk, mean, rstd, gamma, relu, dx, lddx, dres, lddres,
+  hipLaunchKernelGGL(k_bn_train_bwd_partial, dim3((unsigned)cdiv64(max_rows, kRowsPerBlock), (c + 63) / 64, ns), dim3(256), 0, st,
+                     z, ldz, y, ldy, dy, lddy, sg, c, mean, rstd, relu, (double*)scratch);
+  hipLaunchKernelGGL(k_bn_train_bwd_apply, dim3((unsigned)cdiv64(max_rows, kApplyRows), (c + 63) / 64, ns), dim3(256), 0, st, z,
+                     ldz, y, ldy, dy, lddy, sg, ns, c, (const double*)scratch, mean, rstd, gamma, relu, dx, lddx, dres, lddres,
                      dgamma, dbeta);
   APR_LAUNCH_CHECK();
   return APR_OK;

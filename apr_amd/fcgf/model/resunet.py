@@ -17,6 +17,7 @@ Two execution paths produce the same numbers:
 """
 import os
 
+import numpy as np
 import torch
 
 from ... import MinkowskiEngine as ME
@@ -326,13 +327,53 @@ class ResUNet2(ME.MinkowskiNetwork):
                 and all(m.bn.weight is not None and m.bn.track_running_stats for m in self.modules()
                         if isinstance(m, ME.MinkowskiBatchNorm)))
 
-    def forward_train(self, x):
+    def forward_frames(self, tensors):
+        """Several forward calls of the reference in ONE walk of the network: `tensors` = the SparseTensors the trainer would
+        pass one after the other (the two frames of a pair, FCGF_APR/lib/complement_trainer.py:386-394; lib/trainer.py:
+        478-489) -> their outputs, in order.  The frames ride in one batched tensor (batch indices shifted), every launch
+        covers all of them, and each BatchNorm keeps one set of batch statistics PER CALL and feeds them to the running
+        statistics in call order (apr_bn_train_fwd's segments) -- the numbers of separate calls, half the launches.
+        Outside train() + autograd (or for the IN variants) it simply loops."""
+        tensors = list(tensors)
+        if len(tensors) < 2 or not all(self._can_train_fused(t) for t in tensors):
+            return [self(t) for t in tensors]
+        coords, shift = [], None                      # batch indices of call i shifted past those of calls 0 .. i-1 (on the device)
+        for t in tensors:
+            c = getattr(t, "_input_coords", None)
+            c = t.C if c is None else c
+            coords.append(c if shift is None else torch.cat((c[:, :1] + shift, c[:, 1:]), 1))
+            top = coords[-1][:, 0].max() + 1
+            shift = top if shift is None else torch.maximum(shift, top)
+        rows = [int(t.F.shape[0]) for t in tensors]
+        x = ME.SparseTensor(torch.cat([t.F for t in tensors], 0), coordinates=torch.cat(coords, 0))
+        out = self.forward_train(x, frame_rows=rows)
+        res, r0 = [], 0
+        for t, n in zip(tensors, rows):
+            res.append(ME.SparseTensor(out.F[r0:r0 + n], coordinate_map_key=t.coordinate_map_key,
+                                       coordinate_manager=t.coordinate_manager))
+            r0 += n
+        return res
+
+    def forward_train(self, x, frame_rows=None):
         """train() + autograd: the same network as `forward_modular`, walked as 23 fused autograd nodes
         (ops.ConvBnActFunction: routed sparse conv -> training-mode BatchNorm -> (+ residual) -> ReLU, forward and backward
         on the HIP kernels) instead of ~110 module-level ones with torch elementwise ops between them.  The ReLU the reference
-        applies to a block's output a second time (resunet.py:146-166) is the identity on it, forward and backward."""
+        applies to a block's output a second time (resunet.py:146-166) is the identity on it, forward and backward.
+        `frame_rows`: x stacks several forward calls (forward_frames): rows per call at stride 1."""
         cm = x.coordinate_manager
         cm.build_pyramid([2, 4, 8])
+        segs = {}
+        if frame_rows is not None and len(frame_rows) > 1:
+            # rows of every pyramid level per call: a level's rows keep the order of the first voxel they cover, so a call's
+            # rows are contiguous and start where the batch index first reaches the call's first cloud
+            C1 = cm.get_map(1).coords
+            bounds = torch.tensor([0] + list(np.cumsum(frame_rows)[:-1]), device=C1.device)
+            first_batch = C1[bounds, 0].contiguous()                     # batch index of each call's first cloud
+            per = [torch.searchsorted(cm.get_map(ts).coords[:cm.size(ts), 0].contiguous(), first_batch) for ts in (2, 4, 8)]
+            host = torch.stack(per).cpu().tolist()                       # one small fetch per encode
+            segs[1] = [0] + [int(v) for v in np.cumsum(frame_rows)]
+            for ts, b in zip((2, 4, 8), host):
+                segs[ts] = [int(v) for v in b] + [cm.size(ts)]
         ws = _ws_stages()
         ws3 = os.environ.get("APR_WS3", "1") != "0"
         k1 = self.conv1.kernel_size
@@ -367,7 +408,8 @@ class ResUNet2(ME.MinkowskiNetwork):
                 pl_b = None
                 if feats.requires_grad and ok3 and conv.in_channels % 64 == 0:
                     pl_b = lists(stage_name, conv, mb, conv.out_channels, conv.packed_weight_T(flip)[1] is not None)
-            cfg = dict(conv=conv, bn=norm, nbr=nbr, plist=pl, nbr_bwd=nbr_b, plist_bwd=pl_b, flip=flip, relu=relu, n_out=n_out)
+            cfg = dict(conv=conv, bn=norm, nbr=nbr, plist=pl, nbr_bwd=nbr_b, plist_bwd=pl_b, flip=flip, relu=relu, n_out=n_out,
+                       segs=segs.get(m[1] if m is not None else 1))
             bn = norm.bn if norm is not None else None
             return ops.ConvBnActFunction.apply(feats, conv.kernel, bn.weight if bn is not None else None,
                                                bn.bias if bn is not None else None, conv.bias, residual, cfg)

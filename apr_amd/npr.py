@@ -25,7 +25,7 @@ def _f32_dev(a):
     return a.to(device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float32)
 
 
-NN3_CELL = 0.6      # grid cell of the accelerated 1-NN (two voxels of the 0.3 m clouds); 0 = brute force (same bits)
+NN3_CELL = 1.2      # grid cell of the accelerated 1-NN (four voxels of the 0.3 m clouds); 0 = brute force (same bits)
 
 
 def nn3(a, b, want_sum=True, cell=None):

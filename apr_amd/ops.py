@@ -759,18 +759,29 @@ def spconv_wgrad(x, dout, nbr, K, cin, cout, same_level=False):
     return dw
 
 
-def bn_train_fwd(z, bn, residual=None, relu=False):
+def _seg_array(segments, n):
+    """(ctypes int64 array or None, nseg) for the BN-train entry points; `segments`: row offsets [0, ..., n] or None."""
+    if segments is None or len(segments) <= 2:
+        return None, 0
+    if int(segments[0]) != 0 or int(segments[-1]) != n:
+        raise _lib.AprHipError("bn_train: segment offsets must run 0 .. n")
+    return (C.c_int64 * len(segments))(*[int(v) for v in segments]), len(segments) - 1
+
+
+def bn_train_fwd(z, bn, residual=None, relu=False, segments=None):
     """y = act(batch_norm(z) (+ residual)) with the batch statistics of z's rows, `bn`'s running statistics updated in place
-    (apr_bn_train_fwd: two launches) -> (y, save_mean, save_rstd)."""
+    (apr_bn_train_fwd: two launches) -> (y, save_mean, save_rstd).  `segments` (row offsets): the rows of several
+    forward calls stacked into one launch, each normalised on its own (statistics [nseg, c])."""
     z, ldz = _rows(z, "bn_train_fwd.z")
     n, c = z.shape
     lib = _lib_()
+    segs, nseg = _seg_array(segments, n)
     y = torch.empty((n, c), dtype=torch.float32, device=z.device)
-    stats = torch.empty((2, c), dtype=torch.float32, device=z.device)
+    stats = torch.empty((2, max(nseg, 1), c), dtype=torch.float32, device=z.device)
     ldr = 0
     if residual is not None:
         residual, ldr = _rows(residual, "bn_train_fwd.residual")
-    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    sb = int(lib.apr_bn_stats_scratch_bytes(n + 256 * max(nseg, 1), c))
     scratch = torch.empty(sb, dtype=torch.uint8, device=z.device)
     track = bn.track_running_stats and bn.running_mean is not None
     mom = 0.0
@@ -782,30 +793,31 @@ def bn_train_fwd(z, bn, residual=None, relu=False):
     check(lib.apr_bn_train_fwd(ptr(z), ldz, n, c, ptr(g), ptr(b), float(bn.eps), float(mom),
                                ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                                ptr(residual), ldr, int(bool(relu)), ptr(y), c, ptr(stats[0]), ptr(stats[1]),
-                               ptr(bn.num_batches_tracked) if track else None, ptr(scratch), sb, stream()))
+                               ptr(bn.num_batches_tracked) if track else None, segs, nseg, ptr(scratch), sb, stream()))
     if track:
         # the library wrote into the buffers behind torch's back: bump their version counters (folded-BN caches key on them)
         torch.autograd.graph.increment_version((bn.running_mean, bn.running_var, bn.num_batches_tracked))
     return y, stats[0], stats[1]
 
 
-def bn_train_bwd(z, y, dy, mean, rstd, gamma, relu, want_dres):
+def bn_train_bwd(z, y, dy, mean, rstd, gamma, relu, want_dres, segments=None):
     """-> (dz, dres or None, dgamma, dbeta) of bn_train_fwd (apr_bn_train_bwd: two launches, deterministic)."""
     z, ldz = _rows(z, "bn_train_bwd.z")
     dy, lddy = _rows(dy, "bn_train_bwd.dy")
     n, c = z.shape
     lib = _lib_()
+    segs, nseg = _seg_array(segments, n)
     ldy = 0
     if relu:
         y, ldy = _rows(y, "bn_train_bwd.y")
     dz = torch.empty((n, c), dtype=torch.float32, device=z.device)
     dres = torch.empty((n, c), dtype=torch.float32, device=z.device) if want_dres else None
     dgb = torch.empty((2, c), dtype=torch.float32, device=z.device)
-    sb = int(lib.apr_bn_stats_scratch_bytes(n, c))
+    sb = int(lib.apr_bn_stats_scratch_bytes(n + 256 * max(nseg, 1), c))
     scratch = torch.empty(sb, dtype=torch.uint8, device=z.device)
     check(lib.apr_bn_train_bwd(ptr(z), ldz, ptr(y) if relu else None, ldy, ptr(dy), lddy, n, c, ptr(mean), ptr(rstd),
-                               ptr(gamma), int(bool(relu)), ptr(dz), c, ptr(dres), c, ptr(dgb[0]), ptr(dgb[1]), ptr(scratch),
-                               sb, stream()))
+                               ptr(gamma), int(bool(relu)), ptr(dz), c, ptr(dres), c, ptr(dgb[0]), ptr(dgb[1]), segs, nseg,
+                               ptr(scratch), sb, stream()))
     return dz, dres, dgb[0], dgb[1]
 
 
@@ -819,7 +831,8 @@ class ConvBnActFunction(torch.autograd.Function):
                 routed convolution over the reverse map with the flipped-transposed kernel (packed once per optimizer step),
                 the kernel gradient = apr_spconv_wgrad on the bf16-split MFMA.
     Without a norm (`bn` None: the two K = 1 layers behind the decoder) the bias add / ReLU ride in the conv epilogue.
-    `cfg`: a dict (conv, bn, nbr, plist, nbr_bwd, plist_bwd, flip, relu, n_out)."""
+    `cfg`: a dict (conv, bn, nbr, plist, nbr_bwd, plist_bwd, flip, relu, n_out[, segs: the row offsets of the stacked forward
+    calls, each with its own batch statistics])."""
 
     @staticmethod
     def forward(ctx, x, kernel, gamma, beta, bias, residual, cfg):
@@ -828,7 +841,7 @@ class ConvBnActFunction(torch.autograd.Function):
         n_out = cfg["n_out"]
         if bn is not None:
             z = conv.run(x, cfg["nbr"], n_out, plist=cfg["plist"], raw=True)
-            y, mean, rstd = bn_train_fwd(z, bn.bn, residual=residual, relu=cfg["relu"])
+            y, mean, rstd = bn_train_fwd(z, bn.bn, residual=residual, relu=cfg["relu"], segments=cfg.get("segs"))
             ctx.save_for_backward(x, kernel, z, y, mean, rstd, gamma)
         else:
             y = conv.run(x, cfg["nbr"], n_out, plist=cfg["plist"], relu=cfg["relu"], residual=residual)
@@ -846,7 +859,7 @@ class ConvBnActFunction(torch.autograd.Function):
         if bn is not None:
             x, kernel, z, y, mean, rstd, gamma = ctx.saved_tensors
             dz, dres, dgamma, dbeta = bn_train_bwd(z, y, dy, mean, rstd, gamma.detach() if gamma is not None else None,
-                                                   cfg["relu"], ctx.has_res and ctx.needs_input_grad[5])
+                                                   cfg["relu"], ctx.has_res and ctx.needs_input_grad[5], segments=cfg.get("segs"))
             if gamma is not None:
                 dgamma = dgamma.reshape(gamma.shape)
         else:

@@ -419,15 +419,21 @@ int apr_norm_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy
  *   Two launches.  scratch: apr_bn_stats_scratch_bytes.
  * apr_bn_train_bwd: g = dy masked by y > 0 (relu = 1); dres (nullable) = g, the residual branch's gradient;
  *   dgamma = sum g * xhat, dbeta = sum g (nullable); dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)).
- *   Partial sums in fp64 combined in a fixed order: the same bits every run.  Two launches. */
+ *   Partial sums in fp64 combined in a fixed order: the same bits every run.  Two launches.
+ * seg_offsets_host (int64 [nseg + 1], 0 .. n; NULL / nseg <= 1: one segment): the rows of several forward calls of the
+ *   reference stacked into one launch -- the two frames of a pair, FCGF_APR/lib/complement_trainer.py:386-394 -- each
+ *   normalised with its own statistics (save_mean / save_rstd [nseg, c]); the running statistics take the segments'
+ *   updates in order and *num_batches_tracked += nseg, exactly as consecutive calls would; dgamma / dbeta sum over all
+ *   segments.  scratch: apr_bn_stats_scratch_bytes(n + 256 * nseg, c). */
 int apr_bn_train_fwd(const float* z, int64_t ldz, int64_t n, int32_t c, const float* gamma, const float* beta,
                      float eps, float momentum, float* running_mean, float* running_var, const float* residual,
                      int64_t ldr, int32_t relu, float* y, int64_t ldy, float* save_mean, float* save_rstd,
-                     int64_t* num_batches_tracked, void* scratch, size_t scratch_bytes, void* stream);
+                     int64_t* num_batches_tracked, const int64_t* seg_offsets_host, int32_t nseg, void* scratch,
+                     size_t scratch_bytes, void* stream);
 int apr_bn_train_bwd(const float* z, int64_t ldz, const float* y, int64_t ldy, const float* dy, int64_t lddy,
                      int64_t n, int32_t c, const float* mean, const float* rstd, const float* gamma, int32_t relu,
-                     float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta, void* scratch,
-                     size_t scratch_bytes, void* stream);
+                     float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta,
+                     const int64_t* seg_offsets_host, int32_t nseg, void* scratch, size_t scratch_bytes, void* stream);
 
 /* sums[c] = sum over the n rows of x[:, c] (same scratch as apr_bn_stats; fp64 partial sums in fixed order): the bias
  * gradient of the 1x1 convolutions with bias in KPFCNN's training path (Predator_APR/models/architectures.py:92-101 under
@@ -853,9 +859,9 @@ int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m, double
  * the n minima in a fixed order (bit-reproducible).  The arg-min is what the backward of the Chamfer term needs
  * (Predator_APR/lib/trainer.py:131-140, 179-183; FCGF_APR/lib/complement_trainer.py:188-196, 446-448): the gradient
  * of sum_i min_j |a_i - b_j|^2 reaches a_i and b_argmin(i) only.
- * cell > 0: two uniform grids over b (cells `cell` and 8 * cell) answer the queries whose neighbour lies within ~12 cells,
- * the rest fall through to the full search -- the same bits as cell = 0 (brute force, scratch unused) for every input.
- * A good `cell` is a couple of voxel sizes (the clouds here carry one point per 0.3 m voxel). */
+ * cell > 0: a uniform grid over b answers the queries whose neighbour lies within ~1.5 cells, the rest fall through to
+ * the full search -- the same bits as cell = 0 (brute force, scratch unused) for every input.
+ * A good `cell` is a few voxel sizes (the clouds here carry one point per 0.3 m voxel). */
 size_t apr_nn3_scratch_bytes(int64_t n, int64_t m);
 int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
             void* scratch, size_t scratch_bytes, void* stream);

@@ -250,3 +250,41 @@ def test_fused_training_path_matches_module_path_and_is_reproducible(dev, monkey
     assert worst < 1e-2, worst          # other summation order in the routed kernels: ReLU kink flips (see the test above)
     for n in ba:
         assert torch.allclose(ba[n].float(), bm[n].float(), rtol=1e-4, atol=1e-6), n
+
+
+def test_stacked_frames_equal_separate_calls(dev):
+    """ResUNet2.forward_frames: the two encoder calls of a training iteration in one walk of the network (per-call BatchNorm
+    statistics through apr_bn_train_fwd's segments) against two separate calls: features, every gradient, and the running
+    statistics / num_batches_tracked after both calls."""
+    _, hm = model_pair("ResUNetFatBN", 128, seed=5)
+    hm.train()
+    state0 = {k: v.clone() for k, v in hm.state_dict().items()}
+    Cs = []
+    for seed, beams in ((3, 32), (4, 16)):
+        xyz, _, _ = synth.make_pair(seed, n_beams=beams, n_azimuth=800)
+        c, _ = OME.sparse_quantize(xyz / np.float32(0.3), return_index=True)
+        Cs.append(torch.from_numpy(OME.batched_coordinates([c])).to(dev))
+    projs, runs = None, []
+    for stacked in (False, True, True):
+        hm.load_state_dict(state0)
+        hm.zero_grad()
+        xs = [ME.SparseTensor(torch.ones(len(C), 1, device=dev), coordinates=C) for C in Cs]
+        ys = hm.forward_frames(xs) if stacked else [hm(x) for x in xs]
+        assert [tuple(y.F.shape) for y in ys] == [(len(C), 128) for C in Cs]
+        if projs is None:
+            g = torch.Generator().manual_seed(0)
+            projs = [torch.randn(tuple(y.F.shape), generator=g).to(dev) for y in ys]
+        sum((y.F * p).sum() for y, p in zip(ys, projs)).backward()
+        runs.append(([y.F.detach().clone() for y in ys], {n: p.grad.clone() for n, p in hm.named_parameters()},
+                     {n: b.clone() for n, b in hm.named_buffers()}))
+    (ya, ga, ba), (yb, gb, bb), (yc, gc, bc) = runs
+    assert all(torch.equal(u, v) for u, v in zip(yb, yc)) and all(torch.equal(gb[n], gc[n]) for n in gb)      # reproducible
+    for u, v in zip(ya, yb):
+        assert rel_l2(v.cpu(), u.cpu()) < 1e-5
+    worst = max(rel_l2(gb[n].cpu(), ga[n].cpu()) for n in ga)
+    assert worst < 1e-2, worst                       # other summation order: ReLU kink flips, see the routing test above
+    for n in ba:
+        if n.endswith("num_batches_tracked"):
+            assert int(ba[n]) == int(bb[n]) == 2, n
+        else:
+            assert torch.allclose(ba[n], bb[n], rtol=1e-4, atol=1e-6), n
