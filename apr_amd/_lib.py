@@ -97,7 +97,9 @@ PROTOTYPES = {
     "apr_device_count": (C.c_int, []),
     "apr_struct_sizes": (_i32, [_p, _i32]),
     "apr_ransac_set_screen": (C.c_int, [_i32]),
+    "apr_ransac_sampling_launches": (C.c_int, [_p]),
     "apr_event_wait": (C.c_int, [_p, _i32]),
+    "apr_event_wait_timeout": (C.c_int, [_p, _i32, _i64]),
     "apr_hash_capacity": (_i64, [_i64]),
     "apr_map_scratch_bytes": (_sz, [_i64]),
     "apr_voxelize": (C.c_int, [_p, _i64, _f32, _i32, _p, _p]),

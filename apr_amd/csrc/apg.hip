@@ -142,17 +142,54 @@ __global__ __launch_bounds__(256) void k_nn3_arg(const float* __restrict__ a, in
   if (live && bj != 0xFFFFFFFFu) atomicMin(&best[i], ((unsigned long long)__float_as_uint(bd) << 32) | bj);
 }
 
+// k_nn3_arg over a LIST of queries whose length lives on the device (the queries the grid passes left open): workgroup =
+// 256 listed queries x one chunk of targets, targets tiled through LDS; workgroups past the end of the list leave at once
+__global__ __launch_bounds__(256) void k_nn3_arg_list(const float* __restrict__ a, const int* __restrict__ list,
+                                                      const int* __restrict__ list_n, const float* __restrict__ b, int64_t m,
+                                                      int chunk, unsigned long long* __restrict__ best) {
+  __shared__ float s_b[kTile * 3];
+  const int cnt = *list_n;
+  if ((int64_t)blockIdx.x * 256 >= cnt) return;              // workgroup-uniform
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < cnt;
+  const int64_t i = live ? list[q] : 0;
+  const float x = live ? a[3 * i] : 0.f, y = live ? a[3 * i + 1] : 0.f, z = live ? a[3 * i + 2] : 0.f;
+  float bd = __builtin_inff();
+  unsigned bj = 0xFFFFFFFFu;
+  const int64_t t0 = (int64_t)blockIdx.y * chunk, t1 = min((long long)(t0 + chunk), (long long)m);
+  for (int64_t tb = t0; tb < t1; tb += kTile) {
+    const int rows = (int)min((long long)kTile, (long long)(t1 - tb));
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * 3; e += 256) s_b[e] = b[tb * 3 + e];
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+      const float d = d2_rn(x, y, z, s_b[3 * r], s_b[3 * r + 1], s_b[3 * r + 2]);
+      if (d < bd) {
+        bd = d;
+        bj = (unsigned)(tb + r);
+      }
+    }
+  }
+  if (live && bj != 0xFFFFFFFFu) atomicMin(&best[i], ((unsigned long long)__float_as_uint(bd) << 32) | bj);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Grid-accelerated exact 1-NN (round 5).  The brute-force search above is n x m distance evaluations (56 k generated points
 // against a 50-56 k-point APG cloud, both directions, both frames: 3 ms of a training iteration); nearly every query has its
-// neighbour within a voxel or two.  One uniform grid over the targets (cell c: points.hip's search grid), two passes, both
-// exact:
-//   A  thread per query: the 2^3 cells around the query (everything within 0.49 c), then the 4^3 shell (1.49 c);
-//      a query whose best distance is inside the covered radius is DONE -- no closer point can exist outside the cells
-//      read -- the others go to a list (wave-aggregated append; the order of the list does not matter);
-//   B  wave per listed query over all m targets (lanes stride): a few per cent of the queries on LiDAR clouds.
-//   (A coarser second grid between the two was built and dropped: its build costs ~20 launches per call, more host time
-//   than the full search of the few remaining queries costs on the GPU.)
+// neighbour within a voxel or two -- in ONE direction.  Generated points sit on the key frame's voxels, so 97 % of them find
+// an APG point within 0.6 m; the APG cloud also covers what the key frame never saw, and 40 % of ITS points have their nearest
+// generated point more than 1.8 m away, 15 % more than 9 m (scripts/dbg_nn_dist.py).  One uniform grid over the targets (cell
+// c: points.hip's search grid), two passes, both exact:
+//   A  thread per query: the 2^3 cells around the query -- everything within 0.49 c; a query whose best distance is inside
+//      that radius is DONE (no closer point can exist outside the cells read), the others go to a list (wave-aggregated
+//      append; the order of the list does not matter);
+//   B  wave per listed query: ring after ring of the same grid (the cube of 2k cells per axis covers (k - 0.51) c), the lanes
+//      sharing a shell's cells, until the wave-wide best distance is inside the covered radius; what is still open after
+//      kMaxRing rings (6.6 m at c = 1.2 m) goes to a second list;
+//   C  the tiled full search (k_nn3_arg's loop) over that list.
+//   (Tried and dropped: the 4^3 shell inside the thread pass -- divergent, 380 us per call; a second, coarser grid -- its
+//   build is ~20 launches per call; a wave-per-query full search for everything pass A leaves -- every wave re-reads all
+//   targets from L2, 420 us per call.)
 // Distances are (dx^2 + dy^2) + dz^2 with explicitly rounded operations in every pass, ties go to the smaller index: the
 // packed result is bit-identical to k_nn3_arg's whatever path a query took (tested).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -188,23 +225,20 @@ __global__ __launch_bounds__(256) void k_nn3_grid_thread(const float* __restrict
     float bd = __builtin_inff();
     unsigned bj = 0xFFFFFFFFu;
     bool done = false;
-    for (int ring = 1; ring <= 2 && !done; ++ring) {
-      const int lo = -(ring - 1), hi = ring;
-      for (int cz = lo; cz <= hi; ++cz)
-        for (int cy = lo; cy <= hi; ++cy)
-          for (int cx = lo; cx <= hi; ++cx) {
-            if (ring == 2 && cx >= 0 && cx <= 1 && cy >= 0 && cy <= 1 && cz >= 0 && cz <= 1) continue;   // ring 1 saw it
-            const int X = base[0] + cx, Y = base[1] + cy, Z = base[2] + cz;
-            if (!apr_key_in_range(0, X, Y, Z)) continue;
-            const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
-            if (id < 0) continue;
-            const int e1 = g.start[id + 1];
-            for (int e = g.start[id]; e < e1; ++e) {
-              const unsigned j = (unsigned)g.sorted[e];
-              better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
-            }
-          }
-      const float r = ((float)ring - 0.51f) * g.cell;        // every target within r lies in the cells read so far
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {                               // ring 1: the 2^3 cells around the query
+      const int X = base[0] + (o & 1), Y = base[1] + ((o >> 1) & 1), Z = base[2] + (o >> 2);
+      if (!apr_key_in_range(0, X, Y, Z)) continue;
+      const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+      if (id < 0) continue;
+      const int e1 = g.start[id + 1];
+      for (int e = g.start[id]; e < e1; ++e) {
+        const unsigned j = (unsigned)g.sorted[e];
+        better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
+      }
+    }
+    {
+      const float r = 0.49f * g.cell;                           // every target within r lies in the cells read
       done = bd <= r * r;
     }
     if (done) best[i] = ((unsigned long long)__float_as_uint(bd) << 32) | bj;
@@ -220,7 +254,10 @@ __global__ __launch_bounds__(256) void k_nn3_grid_thread(const float* __restrict
   }
 }
 
-// wave per listed query.  g.cell > 0: the two rings of grid g; g.cell == 0: every target (the last resort)
+// wave per listed query: the shells of rings 2 .. kMaxRing of the same grid, the LANES taking the shell's cells in turn (a far
+// query's cost is hash probes into mostly empty cells: 64 of them in flight per wave), a wave-wide minimum after every
+// ring; what is still open after the last ring -- or when the grid is absent (g.cell == 0) -- takes every target
+constexpr int kMaxRing = 6;
 __global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__ a, const float* __restrict__ b, int64_t m,
                                                        AprSearchGrid g, const int* __restrict__ list_in,
                                                        const int* __restrict__ list_in_n, unsigned long long* __restrict__ best,
@@ -236,41 +273,52 @@ __global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__
   if (g.cell > 0.f) {
     int base[3];
     cell_base(g, x, y, z, base);
-    for (int ring = 1; ring <= 2 && !done; ++ring) {
-      const int lo = -(ring - 1), hi = ring;
-      for (int cz = lo; cz <= hi; ++cz)
-        for (int cy = lo; cy <= hi; ++cy)
-          for (int cx = lo; cx <= hi; ++cx) {
-            if (ring == 2 && cx >= 0 && cx <= 1 && cy >= 0 && cy <= 1 && cz >= 0 && cz <= 1) continue;
-            const int X = base[0] + cx, Y = base[1] + cy, Z = base[2] + cz;
-            if (!apr_key_in_range(0, X, Y, Z)) continue;
-            const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
-            if (id < 0) continue;
-            const int e1 = g.start[id + 1];
-            for (int e = g.start[id] + lane; e < e1; e += 64) {
-              const unsigned j = (unsigned)g.sorted[e];
-              better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
-            }
-          }
+    // ring 1 again (the thread pass does not hand its candidate over): 8 cells, lanes over the cells' points
+    for (int o = 0; o < 8; ++o) {
+      const int X = base[0] + (o & 1), Y = base[1] + ((o >> 1) & 1), Z = base[2] + (o >> 2);
+      if (!apr_key_in_range(0, X, Y, Z)) continue;
+      const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+      if (id < 0) continue;
+      const int e1 = g.start[id + 1];
+      for (int e = g.start[id] + lane; e < e1; e += 64) {
+        const unsigned j = (unsigned)g.sorted[e];
+        better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
+      }
+    }
+    for (int ring = 2; ring <= kMaxRing && !done; ++ring) {
+      const int L = 2 * ring, lo = -(ring - 1);
+      for (int t = lane; t < L * L * L; t += 64) {
+        const int cx = lo + t % L, cy = lo + (t / L) % L, cz = lo + t / (L * L);
+        if (cx > lo && cx < ring && cy > lo && cy < ring && cz > lo && cz < ring) continue;      // the previous rings' cube
+        const int X = base[0] + cx, Y = base[1] + cy, Z = base[2] + cz;
+        if (!apr_key_in_range(0, X, Y, Z)) continue;
+        const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+        if (id < 0) continue;
+        const int e1 = g.start[id + 1];
+        for (int e = g.start[id]; e < e1; ++e) {
+          const unsigned j = (unsigned)g.sorted[e];
+          better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
+        }
+      }
       float wd = bd;
       for (int d = 32; d >= 1; d >>= 1) wd = fminf(wd, __shfl_xor(wd, d));
-      const float r = ((float)ring - 0.51f) * g.cell;
+      const float r = ((float)ring - 0.51f) * g.cell;          // every target within r lies in the cube read so far
       done = wd <= r * r;
     }
-  } else {
-    for (int64_t j = lane; j < m; j += 64) better(d2_rn(x, y, z, b[3 * j], b[3 * j + 1], b[3 * j + 2]), (unsigned)j, bd, bj);
-    done = true;
   }
-  if (done) {
-    for (int d = 32; d >= 1; d >>= 1) {
-      const float od = __shfl_xor(bd, d);
-      const unsigned oj = (unsigned)__shfl_xor((int)bj, d);
-      better(od, oj, bd, bj);
+  if (!done) {                                               // the tiled full search takes it (k_nn3_arg_list)
+    if (lane == 0) {
+      best[i] = ~0ull;
+      list_out[atomicAdd(list_out_n, 1)] = (int)i;
     }
-    if (lane == 0) best[i] = ((unsigned long long)__float_as_uint(bd) << 32) | bj;
-  } else if (lane == 0) {
-    list_out[atomicAdd(list_out_n, 1)] = (int)i;
+    return;
   }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float od = __shfl_xor(bd, d);
+    const unsigned oj = (unsigned)__shfl_xor((int)bj, d);
+    better(od, oj, bd, bj);
+  }
+  if (lane == 0) best[i] = ((unsigned long long)__float_as_uint(bd) << 32) | bj;
 }
 
 // sum of the distances of a packed arg-min array in a FIXED order (one workgroup: lane-strided partials, LDS tree)
@@ -361,7 +409,7 @@ APR_API int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m
 }
 
 APR_API size_t apr_nn3_scratch_bytes(int64_t n, int64_t m) {
-  return align256(apr_internal_grid_bytes(m)) + align256((size_t)(n > 0 ? n : 1) * 4) + 1024;
+  return align256(apr_internal_grid_bytes(m)) + 2 * align256((size_t)(n > 0 ? n : 1) * 4) + 1024;
 }
 
 APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
@@ -376,15 +424,24 @@ APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float 
     p += align256(apr_internal_grid_bytes(m));
     int* list1 = (int*)p;
     p += align256((size_t)n * 4);
-    int* counts = (int*)p;
-    AprSearchGrid g1, none;
+    int* list2 = (int*)p;
+    p += align256((size_t)n * 4);
+    int* counts = (int*)p;                                     // [0] list1, [1] list2
+    AprSearchGrid g1;
     int rc = apr_internal_search_grid(b, m, cell, g1s, &g1, st);
     if (rc != APR_OK) return rc;
-    memset(&none, 0, sizeof(none));
     APR_HIP(hipMemsetAsync(counts, 0, 8, st));
     hipLaunchKernelGGL(k_nn3_grid_thread, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, a, n, b, g1, best, list1, counts);
-    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, none, list1, counts, best,
-                       (int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, g1, list1, counts, best, list2,
+                       counts + 1);
+    {
+      const int64_t qb = cdiv64(n, 256);
+      int64_t want = cdiv64(2048, qb);
+      int64_t chunk = cdiv64(cdiv64(m, want), kTile) * kTile;
+      if (chunk < kTile) chunk = kTile;
+      hipLaunchKernelGGL(k_nn3_arg_list, dim3((unsigned)qb, (unsigned)cdiv64(m, chunk)), dim3(256), 0, st, a, list2, counts + 1, b,
+                         m, (int)chunk, best);
+    }
   } else {
     APR_HIP(hipMemsetAsync(out_packed, 0xFF, (size_t)n * 8, st));
     const int64_t qb = cdiv64(n, 256);

@@ -1433,6 +1433,10 @@ static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, in
 }
 
 // sample + edge check over [it0, it1) -> compacted candidates -> Kabsch + distance check -> hypothesis list
+// launches of the two sampling kernels since the library was loaded ([0] k_sample_check, [1] k_sample_screen): what a
+// measurement reports instead of the switch it asked for (apr_ransac_sampling_launches)
+static std::atomic<long long> g_sampling_launches[2];
+
 static int counter_words(const RansacScratch& r) { return (int)((r.live + kLiveInts) - r.n_valid); }
 
 static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dist, double edge_ratio, int64_t it0,
@@ -1445,7 +1449,9 @@ static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dis
   const int64_t niter = it1 - it0;
   const int screen_set = g_ransac_screen.load(std::memory_order_relaxed);
   const int want_screen = screen_set >= 0 ? screen_set : env_int("APR_RANSAC_SCREEN", 1);
-  if (niter >= 64 * kScreenRound && n0 <= kScreenMaxN0 && want_screen && screen_ready()) {
+  const bool screened = niter >= 64 * kScreenRound && n0 <= kScreenMaxN0 && want_screen && screen_ready();
+  g_sampling_launches[screened ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
+  if (screened) {
     const int64_t swg = 256;                                     // one 1024-thread workgroup per CU; a multiple of kCandLists
     const int64_t per_wg = cdiv64(niter, swg);
     sub_cap = (int)((swg / kCandLists) * per_wg);                // <= niter / 64 + 4: inside the candidate region
@@ -1706,6 +1712,16 @@ int side_streams(hipStream_t caller, SideStreams* out) {
 APR_API int apr_ransac_set_screen(int32_t mode) {
   APR_CHECK_ARG(mode >= -1 && mode <= 1, "apr_ransac_set_screen: mode -1, 0 or 1");
   g_ransac_screen.store(mode, std::memory_order_relaxed);
+  return APR_OK;
+}
+
+// The sampling kernel that actually RAN: launch counts since load, out[0] = k_sample_check, out[1] = k_sample_screen (the
+// library falls back to the former when the table does not fit the LDS, the call has few iterations, or the 160 KB opt-in
+// failed -- whatever apr_ransac_set_screen / APR_RANSAC_SCREEN asked for).
+APR_API int apr_ransac_sampling_launches(int64_t* out2) {
+  APR_CHECK_ARG(out2 != nullptr, "apr_ransac_sampling_launches: NULL output");
+  out2[0] = g_sampling_launches[0].load(std::memory_order_relaxed);
+  out2[1] = g_sampling_launches[1].load(std::memory_order_relaxed);
   return APR_OK;
 }
 

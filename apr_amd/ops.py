@@ -292,13 +292,16 @@ BLOCKING_EVENTS = os.environ.get("APR_BLOCKING_EVENTS", "1") != "0"
 # APR_FETCH_WAIT=pypoll the Python loop.
 FETCH_WAIT = os.environ.get("APR_FETCH_WAIT", "poll")
 FETCH_POLL_S = float(os.environ.get("APR_FETCH_POLL_US", "25")) * 1e-6
+FETCH_TIMEOUT_S = float(os.environ.get("APR_FETCH_TIMEOUT_S", "300"))
 _SLACK = __import__("threading").local()
 
 
 def fine_sleep_slack():
     """Linux rounds a thread's sleeps up by its timer slack (50 us by default): a 25 us poll would really be a 75 us one and a
     caller with ONE step in flight (two fetches per pair) pays the difference as latency (measured: 1.36 -> 1.50 ms per pair).
-    PR_SET_TIMERSLACK = 1 us for the calling thread, once per thread; silently skipped where prctl is missing."""
+    PR_SET_TIMERSLACK = 1 us for the calling thread, once per thread; silently skipped where prctl is missing.  Only the
+    APR_FETCH_WAIT=pypoll diagnostics path calls this (a lasting change of the caller's thread); the default wait lowers the
+    slack inside the library for the duration of the wait and restores it (apr_event_wait)."""
     if getattr(_SLACK, "done", False):
         return
     _SLACK.done = True
@@ -329,7 +332,12 @@ def wait_event(ev, mode=None):
         return
     if ev.query():      # landed already (or never recorded): nothing to wait for
         return
-    check(_lib_().apr_event_wait(C.c_void_p(ev.cuda_event), int(FETCH_POLL_S * 1e6)))
+    # a deadline instead of waiting for ever on a wedged queue (APR_FETCH_TIMEOUT_S, default 300 s; 0 = none): the library
+    # returns APR_ETIMEOUT and `check` raises, with the GIL free the whole time
+    if FETCH_TIMEOUT_S > 0:
+        check(_lib_().apr_event_wait_timeout(C.c_void_p(ev.cuda_event), int(FETCH_POLL_S * 1e6), int(FETCH_TIMEOUT_S * 1e6)))
+    else:
+        check(_lib_().apr_event_wait(C.c_void_p(ev.cuda_event), int(FETCH_POLL_S * 1e6)))
 
 
 class PendingFetch:
@@ -731,6 +739,9 @@ def dense_gemm_bf3(x, w_bf3, cin, cout, scale=None, shift=None, residual=None, r
     return out
 
 
+WGRAD_PAD = os.environ.get("APR_WGRAD_PAD", "1") != "0"      # A/B switch: 0 = odd widths on the fp32 scalar-gather kernel
+
+
 def weights_flip_transpose(w, flip):
     """[K, cin, cout] -> [K, cout, cin] with the offsets mirrored when `flip` (apr_weights_flip_transpose)."""
     w = _f32(w.detach(), "weights_flip_transpose.w").contiguous()
@@ -743,11 +754,18 @@ def weights_flip_transpose(w, flip):
 def spconv_wgrad(x, dout, nbr, K, cin, cout, same_level=False):
     """dW f32 [K, cin, cout] = sum_j [nbr[j,k] >= 0] x[nbr[j,k]]^T dout[j]  (nbr None: identity map, K = 1).
     `same_level`: nbr is a stride-1 map of an odd kernel (its centre column is full): apr_spconv_wgrad_same_level."""
+    if x.shape[1] != cin or dout.shape[1] != cout:
+        raise _lib.AprHipError("spconv_wgrad: channel mismatch")
+    if (cin % 32 or cout % 32) and WGRAD_PAD and x.shape[0] * (-cin % 32) + dout.shape[0] * (-cout % 32) < (1 << 26):
+        # odd widths (conv1's single input channel, a decoder's 12 outputs) ride on the bf16-split MFMA kernel zero-padded to
+        # its 32-channel granule instead of the scalar-gather fallback (180 us per call at a frame's row count)
+        cp, op = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+        xp = torch.nn.functional.pad(x, (0, cp - cin)) if cp != cin else x
+        dp = torch.nn.functional.pad(dout, (0, op - cout)) if op != cout else dout
+        return spconv_wgrad(xp, dp, nbr, K, cp, op, same_level=same_level)[:, :cin, :cout]
     x, ldi = _rows(x, "spconv_wgrad.x")
     dout, ldo = _rows(dout, "spconv_wgrad.dout")
     n_out = dout.shape[0]
-    if x.shape[1] != cin or dout.shape[1] != cout:
-        raise _lib.AprHipError("spconv_wgrad: channel mismatch")
     if nbr is not None and (nbr.dtype != torch.int32 or not nbr.is_contiguous() or tuple(nbr.shape) != (n_out, K)):
         raise _lib.AprHipError("spconv_wgrad: nbr must be a contiguous int32 [n_out, K] tensor")
     lib = _lib_()
@@ -1275,14 +1293,19 @@ def occ_conv(coords, n, bbox, kernel_size, w, scale=None, shift=None, relu=False
     check(lib.apr_occ_conv(ptr(coords), int(n), box, int(kernel_size), ptr(w), cout, ptr(scale), ptr(shift), ptr(residual),
                            ldr, int(bool(relu)), ptr(out), ldo, ptr(scratch), sb, stream()))
     if keep is not None:
-        keep.append((scratch, tuple(int(v) for v in bbox), int(kernel_size)))
+        # with the rows it covers: a bitmap built from a SUBSET of a map must not answer probes for the whole map (a clear bit
+        # inside the box reads as "no voxel"): kernel_map_occ checks (row count, coordinate storage) against the map it is given
+        keep.append((scratch, tuple(int(v) for v in bbox), int(kernel_size), int(n), coords.data_ptr()))
     return out
 
 
 def kernel_map_occ(out_map: CoordMap, in_map: CoordMap, kernel_size: int, scale: int, occ) -> torch.Tensor:
-    """`kernel_map` with the occupancy bitmap `occ` = (scratch, bbox, bitmap kernel size) that `occ_conv(keep=...)` left
-    for `in_map` as a pre-filter of the probes (apr_kernel_map_occ): same table."""
-    scratch, bbox, bks = occ
+    """`kernel_map` with the occupancy bitmap `occ` = (scratch, bbox, bitmap kernel size, rows, coordinate storage) that
+    `occ_conv(keep=...)` left for `in_map` as a pre-filter of the probes (apr_kernel_map_occ): same table.  A bitmap that was
+    not built from EVERY row of `in_map` is not used: the plain hash-table map is returned instead."""
+    scratch, bbox, bks = occ[:3]
+    if len(occ) < 5 or in_map.n is None or occ[3] != in_map.n or occ[4] != in_map.coords.data_ptr():
+        return kernel_map(out_map, in_map, kernel_size, scale)
     nbr = torch.empty((out_map.n, kernel_size ** 3), dtype=torch.int32, device=out_map.coords.device)
     box = (C.c_int32 * 8)(*bbox)
     check(_lib_().apr_kernel_map_occ(ptr(out_map.coords), out_map.n, None, ptr(in_map.keys), ptr(in_map.vals), in_map.cap,
@@ -1295,6 +1318,13 @@ def set_ransac_screen(mode):
     latency with ONE step in flight), False = the plain one (friendlier to the kernels of other streams: a pipelined caller),
     None = the environment's APR_RANSAC_SCREEN (default on).  Same candidates either way."""
     check(_lib_().apr_ransac_set_screen(-1 if mode is None else int(bool(mode))))
+
+
+def ransac_sampling_launches():
+    """(k_sample_check launches, k_sample_screen launches) since the library was loaded."""
+    out = (C.c_int64 * 2)()
+    check(_lib_().apr_ransac_sampling_launches(out))
+    return int(out[0]), int(out[1])
 
 
 def set_match_lanes(lanes):

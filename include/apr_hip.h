@@ -32,6 +32,7 @@ extern "C" {
 #define APR_OK 0
 #define APR_EINVAL (-1)   /* bad argument / shape */
 #define APR_EHIP (-2)     /* HIP runtime error */
+#define APR_ETIMEOUT (-3) /* apr_event_wait_timeout: the event was not reached before the deadline */
 #define APR_ERANGE (-3)   /* coordinate outside the packed-key range */
 
 const char* apr_last_error(void);
@@ -44,8 +45,13 @@ int apr_device_count(void);
 int32_t apr_struct_sizes(int32_t* out, int32_t n);
 /* Host wait for a HIP event (hipEvent_t) by hipEventQuery + nanosleep(poll_us): no spinning CPU (hipEventSynchronize spins on
  * this stack even for hipEventBlockingSync events) and, called through ctypes, no interpreter lock held while waiting.  The
- * reference's loop blocks in `.cpu()` / `.item()` at the same places (FCGF_APR/scripts/test_apr.py:137-146). */
+ * reference's loop blocks in `.cpu()` / `.item()` at the same places (FCGF_APR/scripts/test_apr.py:137-146).
+ * While it sleeps the calling thread's timer slack is 1 us (PR_SET_TIMERSLACK; the default 50 us would triple a 25 us poll);
+ * the thread's previous value is restored before the call returns.
+ * apr_event_wait_timeout: the same with a deadline (microseconds): APR_ETIMEOUT when the event has not been reached by then
+ * (a wedged queue), so that a caller can report a hang instead of blocking for ever with the GIL released. */
 int apr_event_wait(void* event, int32_t poll_us);
+int apr_event_wait_timeout(void* event, int32_t poll_us, int64_t timeout_us);
 
 /* ------------------------------------------------------------------------
  * Voxel hashing / coordinate maps
@@ -574,6 +580,11 @@ int apr_match_pose_batch_finish(const apr_pair_desc* pairs, int32_t B, int32_t c
  * kernels of a pipelined caller's other streams), -1 = APR_RANSAC_SCREEN from the environment (default 1).  Same
  * candidate set either way (FCGF_APR/scripts/test_apr.py:148-156). */
 int apr_ransac_set_screen(int32_t mode);
+/* Launch counts of the two sampling kernels since the library was loaded: out2[0] = k_sample_check, out2[1] =
+ * k_sample_screen.  The library silently takes the former when the correspondence table does not fit the LDS, a call has
+ * fewer than 2^17 iterations or the 160 KB LDS opt-in failed: a measurement reports the difference of two readings, not
+ * the switch it asked for (bench.py `config.ransac_sampling_kernel`). */
+int apr_ransac_sampling_launches(int64_t* out2);
 
 /* Deal the pairs of a batch over `lanes` streams (1 .. 4): lane 0 is the caller's stream, the others are library-owned
  * streams forked from it by an event and joined back before the result copy, each with its own matching / RANSAC
@@ -859,9 +870,9 @@ int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m, double
  * the n minima in a fixed order (bit-reproducible).  The arg-min is what the backward of the Chamfer term needs
  * (Predator_APR/lib/trainer.py:131-140, 179-183; FCGF_APR/lib/complement_trainer.py:188-196, 446-448): the gradient
  * of sum_i min_j |a_i - b_j|^2 reaches a_i and b_argmin(i) only.
- * cell > 0: a uniform grid over b answers the queries whose neighbour lies within ~1.5 cells, the rest fall through to
- * the full search -- the same bits as cell = 0 (brute force, scratch unused) for every input.
- * A good `cell` is a few voxel sizes (the clouds here carry one point per 0.3 m voxel). */
+ * cell > 0: a uniform grid over b answers the queries whose neighbour lies within ~6.5 cells (ring after ring), the rest
+ * fall through to the full search -- the same bits as cell = 0 (brute force, scratch unused) for every input.
+ * A good `cell` is several voxel sizes (the clouds here carry one point per 0.3 m voxel; the Python layer passes 1.2 m). */
 size_t apr_nn3_scratch_bytes(int64_t n, int64_t m);
 int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
             void* scratch, size_t scratch_bytes, void* stream);

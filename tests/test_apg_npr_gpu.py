@@ -126,7 +126,7 @@ def test_grid_nn3_is_bit_identical_to_brute_force(dev):
     a = np.concatenate([near, mid, far, b[7:8]]).astype(np.float32)
     A, B = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     i0, d0, s0 = npr.nn3(A, B, cell=0.0)
-    for cell in (0.6, 0.25, 3.0):
+    for cell in (2.4, 0.6, 0.25, 8.0):
         i1, d1, s1 = npr.nn3(A, B, cell=cell)
         assert torch.equal(i0, i1) and torch.equal(d0, d1) and float(s0) == float(s1), cell
     assert int(i0[-1]) == 7

@@ -392,6 +392,14 @@ def test_kernel_map_with_occupancy_prefilter(dev, bks, n, nbatch, lo, hi, spread
         ops.occ_conv(m.coords, N, box, bks, w, keep=keep)
         assert torch.equal(ops.kernel_map_occ(m, m, 3, 1, keep[0]), ref_same)
         assert torch.equal(ops.kernel_map_occ(m2, m, 3, 1, keep[0]), ref_down)
+    if N > 8:
+        # a bitmap built from a SUBSET of the map's rows (round-4 advice): a clear bit inside its box would read as "no voxel"
+        # -- the wrapper notices that the bitmap does not cover the map it is asked about and takes the hash-table path
+        part = []
+        ops.occ_conv(m.coords, N // 2, bbox, bks, w, keep=part)
+        assert part[0][3] == N // 2
+        assert torch.equal(ops.kernel_map_occ(m, m, 3, 1, part[0]), ref_same)
+        assert torch.equal(ops.kernel_map_occ(m2, m, 3, 1, part[0]), ref_down)
 
 
 @pytest.mark.parametrize("ks,cout,n,nbatch,lo,hi,spread", [
