@@ -439,19 +439,25 @@ class _ConvBase(nn.Module):
             self._bf3_key = k
         return self._bf3
 
-    def packed_weight_T(self, flip):
-        """(tile pack, bf16-split pack or None) of the input gradient's kernel [K, cout, cin] (offsets mirrored when `flip`:
-        ops.weights_flip_transpose), cached per parameter version like the forward packs -- one pack per optimizer step, not
-        one per call."""
+    def packed_weight_T(self, flip, tile=True, bf3=True):
+        """(tile pack or None, bf16-split pack or None) of the input gradient's kernel [K, cout, cin] (offsets mirrored when
+        `flip`: ops.weights_flip_transpose), cached per parameter version like the forward packs -- one pack per optimizer
+        step, not one per call -- and built only for the route that asks (`tile` / `bf3`)."""
         k = (self.kernel.data_ptr(), self.kernel._version, self.kernel.device, bool(flip))
         if getattr(self, "_packT_key", None) != k:
-            w = self.kernel.detach()
-            wt = ops.weights_flip_transpose(w if w.dim() == 3 else w.unsqueeze(0), flip)
-            import os
-            bf3 = None if os.environ.get("APR_WS_BF3", "1") == "0" else ops.pack_weights_bf3(wt)
-            self._packT = (ops.pack_weights(wt), bf3)
+            self._packT = {}
             self._packT_key = k
-        return self._packT
+        c = self._packT
+        if (tile and "tile" not in c) or (bf3 and "bf3" not in c):
+            if "wt" not in c:
+                w = self.kernel.detach()
+                c["wt"] = ops.weights_flip_transpose(w if w.dim() == 3 else w.unsqueeze(0), flip)
+            if tile and "tile" not in c:
+                c["tile"] = ops.pack_weights(c["wt"])
+            if bf3 and "bf3" not in c:
+                import os
+                c["bf3"] = None if os.environ.get("APR_WS_BF3", "1") == "0" else ops.pack_weights_bf3(c["wt"])
+        return c.get("tile"), c.get("bf3")
 
     def _maps(self, x: SparseTensor):
         """-> (nbr or None, out tensor stride)."""
@@ -469,14 +475,21 @@ class _ConvBase(nn.Module):
             raise AprHipError("transposed convolution needs the encoder's coordinate map of that stride")
         return cm.kernel_map(ts, ts_out, self.kernel_size, self.stride != 1), ts_out
 
+    def _bf3_only(self, plist, cin, w_bf3):
+        """The launch reads the bf16-split image alone (weight-stationary / triple-list / output-stationary kernels at the
+        channel counts they cover): the tile pack need not exist."""
+        return plist is not None and w_bf3 is not None and cin in (64, 128, 192, 256, 384)
+
     def run_T(self, dout, nbr_bwd, n_in, flip, plist=None):
         """The input gradient: the same routed launch over the reverse map with the flipped-transposed kernel (channels
         swapped); `plist`: the reverse map's pair lists."""
-        wp, w_bf3 = self.packed_weight_T(flip)
+        want_bf3 = plist is not None or nbr_bwd is None
+        w_bf3 = self.packed_weight_T(flip, tile=False, bf3=True)[1] if want_bf3 else None
+        wp = None if self._bf3_only(plist, self.out_channels, w_bf3) else self.packed_weight_T(flip, tile=True, bf3=False)[0]
         os_pairs = plist if isinstance(plist, ops.OsPairs) else None
         return ops.spconv(dout, nbr_bwd, self.kernel_volume if nbr_bwd is not None else 1, self.out_channels,
                           self.in_channels, wp, n_out=n_in, plist=None if os_pairs is not None else plist,
-                          w_bf3=w_bf3 if (plist is not None or nbr_bwd is None) else None, os_pairs=os_pairs)
+                          w_bf3=w_bf3, os_pairs=os_pairs)
 
     def run(self, feats, nbr, n_out, scale=None, shift=None, residual=None, relu=False, out=None, batch=None,
             plist=None, l2norm=False, raw=False):
@@ -490,11 +503,14 @@ class _ConvBase(nn.Module):
         kw = {"l2norm": True} if l2norm else {}
         if l2norm and batch is None:
             raise AprHipError("conv.run(l2norm=True) needs a SpconvBatch")
+        w_bf3 = self.packed_weight_bf3() if (plist is not None or nbr is None) else None
+        # a direct (un-batched) launch on a route that reads the split image alone does not need the tile pack: a training
+        # step re-packs every kernel once per optimizer step, so what is not read is not built
+        wp = None if (batch is None and self._bf3_only(plist, self.in_channels, w_bf3)) else self.packed_weight()
         return fn(feats, nbr, self.kernel_volume if nbr is not None else 1, self.in_channels,
-                  self.out_channels, self.packed_weight(), scale=scale, shift=shift, residual=residual,
+                  self.out_channels, wp, scale=scale, shift=shift, residual=residual,
                   relu=relu, out=out, n_out=n_out, plist=None if os_pairs is not None else plist,
-                  w_bf3=self.packed_weight_bf3() if (plist is not None or nbr is None) else None,
-                  os_pairs=os_pairs, **kw)
+                  w_bf3=w_bf3, os_pairs=os_pairs, **kw)
 
     def occ_ready(self, x: SparseTensor):
         """True if this layer on this input is the occupancy special case (ops.occ_conv): constant-1 features, one input
