@@ -147,6 +147,9 @@ PROTOTYPES = {
                                    _p, _i32, _p, _sz, _p]),
     "apr_weights_flip_transpose": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_dense_gemm_bf3": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "apr_dense_gemm_bf3_norm_scratch_bytes": (_sz, [_i64, _i32, _i32]),
+    "apr_dense_gemm_bf3_norm_act": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _i32, _p,
+                                              _sz, _p]),
     "apr_weighted_choice_round": (C.c_int64, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i32]),
     "apr_instance_norm_act_seg": (C.c_int, [_p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _i32, _p, _sz, _p]),
     "apr_affine_act": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _i32, _f32, _p, _i64, _p]),

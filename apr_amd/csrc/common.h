@@ -52,6 +52,12 @@ int apr_internal_dense_gemm(const float* in, int64_t ldi, int64_t M, int32_t cin
                             const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
                             float* out, int64_t ldo, hipStream_t st);
 
+// norm.hip: y = act((x - mean) * rstd (+ residual)) per row segment, mean / rstd rebuilt from per-block column sums
+// partial[blk][2][c] (fp64; segment s owns blocks blk0[s] .. blk0[s + 1]) that another kernel left behind
+int apr_internal_norm_apply_partials(const float* x, int64_t ldx, int32_t c, const int64_t* seg_row0, const int* seg_blk0,
+                                     int32_t nseg, const double* partial, float eps, const float* residual, int64_t ldr,
+                                     int32_t act_mode, float negative_slope, float* y, int64_t ldy, hipStream_t st);
+
 #ifdef __HIPCC__
 // Inclusive prefix sum over the 64 lanes with DPP adds only (no ds_bpermute round trips, ~6 VALU instead of 6
 // LDS-crossbar shuffles): 4 shifts inside each row of 16 lanes, then the row totals are broadcast into the

@@ -138,13 +138,24 @@ __global__ __launch_bounds__(256) void k_dense_gemm(const float* __restrict__ in
 // fragment reads are the conflict-free ds_read_b128 of the sparse kernel.  A rows stream from global memory one chunk
 // ahead (lane (row r16, quad q): 8 consecutive channels per 32-channel step) and are split in registers per step.
 // ---------------------------------------------------------------------------------------------------------------
-template <int G>
+// STATS (round 5): the rows come in SEGMENTS (the scan pairs stacked into one KPFCNN forward; one segment otherwise) and row
+// tiles never straddle a segment: tile_m -> (segment, tile within it) by a scan of <= 32 entries; the epilogue also leaves the
+// tile's per-column sum and sum of squares (fp64, rows in order) in partial[tile][2][cout] -- exactly what k_bn_partial would
+// compute in a launch of its own for the InstanceNorm that follows every Linear of KPFCNN (blocks.py:459-468).
+struct DenseSegs {
+  int nseg;
+  int row0[33];
+  int tile0[33];
+};
+
+template <int G, bool STATS>
 __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restrict__ in, int64_t ldi, int M, int cin,
                                                            int cout, const unsigned char* __restrict__ wp3,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ residual, int64_t ldr, int relu,
-                                                           float* __restrict__ out, int64_t ldo) {
+                                                           float* __restrict__ out, int64_t ldo, DenseSegs sg,
+                                                           double* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) unsigned char s_w[2][3 * 8192];   // [buf][plane][step 2][col 64][quad 4][16 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,7 +169,15 @@ __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restri
   const int xcd = bid & 7, loc = bid >> 3;
   const int lin = xcd * (nb >> 3) + min(xcd, nb & 7) + loc;
   const int tile_m = lin / ncol, tile_n = lin - tile_m * ncol;
-  const int row0 = tile_m * (64 * G) + wave * (16 * G);
+  int tile_base = tile_m * (64 * G);      // first row of the workgroup's tile; rows >= row_end are not there
+  int row_end = M;
+  if (STATS) {
+    int sgi = 0;
+    while (sgi + 1 < sg.nseg && tile_m >= sg.tile0[sgi + 1]) ++sgi;
+    tile_base = sg.row0[sgi] + (tile_m - sg.tile0[sgi]) * (64 * G);
+    row_end = sg.row0[sgi + 1];
+  }
+  const int row0 = tile_base + wave * (16 * G);
   const int col0 = tile_n * 64;
   const int nchunk = cin >> 6;
   const int64_t plane_bytes = (int64_t)(cin >> 5) * 4096;
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restri
 #pragma unroll
   for (int gi = 0; gi < G; ++gi) {
     const int r = row0 + gi * 16 + r16;
-    arow[gi] = in + (int64_t)(r < M ? r : M - 1) * ldi + q * 8;
+    arow[gi] = in + (int64_t)(r < row_end ? r : row_end - 1) * ldi + q * 8;
   }
   f32x4 abuf[2][G][4];
   f32x4 acc[G][4];
@@ -249,10 +268,43 @@ __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restri
 #undef APR_DENSE3_CHUNK
 #undef APR_DENSE3_STAGE
 
+  if (STATS) {
+    // the tile's image [64 G rows][64 columns] fp32 through the weight buffers (free: the last chunk ended in a barrier),
+    // absent rows as zeros; then thread = (column, quarter of the rows): fp64 sums in row order, quarters combined in order
+    float* s_t = reinterpret_cast<float*>(&s_w[0][0]);
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+      const int rl = wave * (16 * G) + gi * 16 + r16;
+      const bool live = row0 + gi * 16 + r16 < row_end;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        *reinterpret_cast<f32x4*>(s_t + rl * 64 + cb * 16 + q * 4) = live ? acc[gi][cb] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int cc = tid & 63, part = tid >> 6;
+    double a = 0.0, b = 0.0;
+#pragma unroll 4
+    for (int rr = 0; rr < 16 * G; ++rr) {
+      const double d = (double)s_t[(part * (16 * G) + rr) * 64 + cc];
+      a += d;
+      b += d * d;
+    }
+    __syncthreads();
+    double* s_d = reinterpret_cast<double*>(&s_w[1][0]);
+    s_d[(part * 64 + cc) * 2] = a;
+    s_d[(part * 64 + cc) * 2 + 1] = b;
+    __syncthreads();
+    if (tid < 128) {
+      const int c2 = tid & 63, which = tid >> 6;
+      const double t = ((s_d[(0 * 64 + c2) * 2 + which] + s_d[(1 * 64 + c2) * 2 + which]) + s_d[(2 * 64 + c2) * 2 + which]) +
+                       s_d[(3 * 64 + c2) * 2 + which];
+      partial[((int64_t)tile_m * 2 + which) * cout + col0 + c2] = t;
+    }
+  }
 #pragma unroll
   for (int gi = 0; gi < G; ++gi) {
     const int r = row0 + gi * 16 + r16;
-    if (r >= M) continue;
+    if (r >= row_end) continue;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       const int col = col0 + cb * 16 + q * 4;
@@ -315,11 +367,64 @@ APR_API int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t 
   const int64_t ncol = cout / 64;
   static const int s_g = env_int("APR_DENSE_G", 0);      // A/B switch: force 64-row (1) or 128-row (2) tiles
   if (s_g == 2 || (s_g == 0 && cdiv64(M, 128) * ncol >= 512))
-    hipLaunchKernelGGL(k_dense_gemm_bf3<2>, dim3((unsigned)(cdiv64(M, 128) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
-                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo);
+    hipLaunchKernelGGL((k_dense_gemm_bf3<2, false>), dim3((unsigned)(cdiv64(M, 128) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
+                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, DenseSegs{},
+                       (double*)nullptr);
   else
-    hipLaunchKernelGGL(k_dense_gemm_bf3<1>, dim3((unsigned)(cdiv64(M, 64) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
-                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo);
+    hipLaunchKernelGGL((k_dense_gemm_bf3<1, false>), dim3((unsigned)(cdiv64(M, 64) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
+                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, DenseSegs{},
+                       (double*)nullptr);
   APR_LAUNCH_CHECK();
   return APR_OK;
+}
+
+// out = act(instance_norm(in @ W) (+ residual)) per row segment in TWO launches: the GEMM leaves the raw product in `out`
+// and the per-tile column sums in scratch (k_dense_gemm_bf3<G, true>), norm.hip's apply kernel rebuilds mean / rstd from them
+// and normalises in place.  Replaces apr_dense_gemm_bf3 + apr_instance_norm_act[_seg] (three launches).
+APR_API size_t apr_dense_gemm_bf3_norm_scratch_bytes(int64_t M, int32_t cout, int32_t nseg) {
+  return (size_t)(cdiv64(M > 0 ? M : 1, 64) + (nseg > 0 ? nseg : 1)) * 2 * (size_t)cout * sizeof(double) + 256;
+}
+
+APR_API int apr_dense_gemm_bf3_norm_act(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const void* w_bf3,
+                                        float eps, const float* residual, int64_t ldr, int32_t act_mode, float negative_slope,
+                                        float* out, int64_t ldo, const int64_t* seg_offsets_host, int32_t nseg, void* scratch,
+                                        size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(in && out && w_bf3 && M > 0 && M < (1ll << 31) && cin >= 64 && cin % 64 == 0 && cout >= 64 && cout % 64 == 0,
+                "apr_dense_gemm_bf3_norm_act: needs M > 0, cin %% 64 == 0, cout %% 64 == 0");
+  APR_CHECK_ARG(ldi >= cin && ldo >= cout && ldi % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                "apr_dense_gemm_bf3_norm_act: rows of in / out must be 16-byte aligned");
+  APR_CHECK_ARG(!residual || ldr >= cout, "apr_dense_gemm_bf3_norm_act: ldr < cout");
+  APR_CHECK_ARG(eps >= 0.f && act_mode >= 0 && act_mode <= 2, "apr_dense_gemm_bf3_norm_act: bad eps / act_mode");
+  const int ns = (seg_offsets_host && nseg > 1) ? nseg : 1;
+  APR_CHECK_ARG(ns <= 32, "apr_dense_gemm_bf3_norm_act: at most 32 segments");
+  APR_CHECK_ARG(scratch && scratch_bytes >= apr_dense_gemm_bf3_norm_scratch_bytes(M, cout, ns), "apr_dense_gemm_bf3_norm_act: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ncol = cout / 64;
+  static const int s_g = env_int("APR_DENSE_G", 0);
+  const int G = (s_g == 2 || (s_g == 0 && cdiv64(M, 128) * ncol >= 512)) ? 2 : 1;
+  DenseSegs sg;
+  sg.nseg = ns;
+  sg.row0[0] = 0;
+  sg.tile0[0] = 0;
+  int64_t offs[33];
+  for (int i = 0; i <= ns; ++i) offs[i] = ns == 1 ? (i == 0 ? 0 : M) : seg_offsets_host[i];
+  APR_CHECK_ARG(offs[0] == 0 && offs[ns] == M, "apr_dense_gemm_bf3_norm_act: segment offsets must run 0 .. M");
+  for (int i = 0; i < ns; ++i) {
+    APR_CHECK_ARG(offs[i + 1] > offs[i], "apr_dense_gemm_bf3_norm_act: empty segment %d", i);
+    sg.row0[i + 1] = (int)offs[i + 1];
+    sg.tile0[i + 1] = sg.tile0[i] + (int)cdiv64(offs[i + 1] - offs[i], 64 * G);
+  }
+  const int ntile = sg.tile0[ns];
+  double* partial = (double*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  if (G == 2)
+    hipLaunchKernelGGL((k_dense_gemm_bf3<2, true>), dim3((unsigned)(ntile * ncol)), dim3(256), 0, st, in, ldi, (int)M, cin, cout,
+                       (const unsigned char*)w_bf3, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (int64_t)0, 0, out, ldo, sg, partial);
+  else
+    hipLaunchKernelGGL((k_dense_gemm_bf3<1, true>), dim3((unsigned)(ntile * ncol)), dim3(256), 0, st, in, ldi, (int)M, cin, cout,
+                       (const unsigned char*)w_bf3, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (int64_t)0, 0, out, ldo, sg, partial);
+  APR_LAUNCH_CHECK();
+  return apr_internal_norm_apply_partials(out, ldo, cout, offs, sg.tile0, ns, partial, eps, residual, ldr, act_mode, negative_slope,
+                                          out, ldo, st);
 }

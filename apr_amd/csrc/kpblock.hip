@@ -38,6 +38,8 @@ KpCarve kp_carve(const apr_kp_resnet_desc& d, void* scratch) {
   const int64_t nmax = ni > no ? ni : no;
   const int32_t cmax = d.out_dim > d.in_dim ? d.out_dim : d.in_dim;
   c.stat_bytes = apr_bn_stats_scratch_bytes(nmax + 256 * (int64_t)(d.nseg > 0 ? d.nseg : 1), cmax);
+  const size_t fused = apr_dense_gemm_bf3_norm_scratch_bytes(nmax, cmax, d.nseg > 0 ? d.nseg : 1);
+  if (fused > c.stat_bytes) c.stat_bytes = fused;
   c.stat = take(c.stat_bytes);
   c.total = (size_t)(p - p0) + 256;
   return c;
@@ -50,6 +52,20 @@ int kp_norm(const apr_kp_resnet_desc& d, const KpCarve& c, const float* x, int64
     return apr_instance_norm_act_seg(x, ch, n, ch, d.eps, residual, ldr, mode, d.slope, y, ldy, seg, d.nseg, c.stat, c.stat_bytes,
                                      stream);
   return apr_instance_norm_act(x, ch, n, ch, d.eps, residual, ldr, mode, d.slope, y, ldy, c.stat, c.stat_bytes, stream);
+}
+
+// Linear + InstanceNorm (+ shortcut) (+ LeakyReLU): two launches -- the GEMM leaves the column sums of its tiles behind
+// (apr_dense_gemm_bf3_norm_act) -- instead of GEMM, statistics, apply.  APR_KP_FUSED_NORM=0: the three launches (A/B).
+int kp_linear_norm(const apr_kp_resnet_desc& d, const KpCarve& c, const float* x, int64_t ldx, int64_t n, int32_t cin,
+                   int32_t cout, const void* w, const float* residual, int64_t ldr, bool act, float* y, int64_t ldy,
+                   const int64_t* seg, void* stream) {
+  static const int fused = env_int("APR_KP_FUSED_NORM", 1);
+  if (fused)
+    return apr_dense_gemm_bf3_norm_act(x, ldx, n, cin, cout, w, d.eps, residual, ldr, act ? 2 : 0, d.slope, y, ldy, seg,
+                                       d.nseg > 1 ? d.nseg : 0, c.stat, c.stat_bytes, stream);
+  int rc = apr_dense_gemm_bf3(x, ldx, n, cin, cout, w, nullptr, nullptr, nullptr, 0, 0, y, ldy, stream);
+  if (rc != APR_OK) return rc;
+  return kp_norm(d, c, y, n, cout, residual, ldr, act, y, ldy, seg, stream);
 }
 }  // namespace
 
@@ -82,8 +98,7 @@ APR_API int apr_kp_resnet_block(const apr_kp_resnet_desc* dp, void* stream) {
   const float* x1 = d.x;
   int64_t ldx1 = d.ldx;
   if (d.w_unary1) {
-    KP_TRY(apr_dense_gemm_bf3(d.x, d.ldx, d.n_in, d.in_dim, d.mid, d.w_unary1, nullptr, nullptr, nullptr, 0, 0, c.u1, d.mid, stream));
-    KP_TRY(kp_norm(d, c, c.u1, d.n_in, d.mid, nullptr, 0, true, c.u1, d.mid, d.seg_in, stream));
+    KP_TRY(kp_linear_norm(d, c, d.x, d.ldx, d.n_in, d.in_dim, d.mid, d.w_unary1, nullptr, 0, true, c.u1, d.mid, d.seg_in, stream));
     x1 = c.u1;
     ldx1 = d.mid;
   }
@@ -92,9 +107,8 @@ APR_API int apr_kp_resnet_block(const apr_kp_resnet_desc* dp, void* stream) {
   KP_TRY(apr_row_sums(x1, ldx1, d.n_in, d.mid, c.rs, stream));
   KP_TRY(apr_kpconv_weighted(d.q_pts, d.n_out, d.s_pts, d.n_in, d.nbr, d.H, x1, ldx1, d.mid, d.kernel_points, d.n_kp, d.extent,
                              c.rs, c.wf, kk, stream));
-  KP_TRY(apr_dense_gemm_bf3(c.wf, kk, d.n_out, kk, d.mid, d.w_kpconv, nullptr, nullptr, nullptr, 0, 0, c.kp, d.mid, stream));
-  // 3. InstanceNorm + LeakyReLU
-  KP_TRY(kp_norm(d, c, c.kp, d.n_out, d.mid, nullptr, 0, true, c.kp, d.mid, d.seg_out, stream));
+  // 3. ... + InstanceNorm + LeakyReLU
+  KP_TRY(kp_linear_norm(d, c, c.wf, kk, d.n_out, kk, d.mid, d.w_kpconv, nullptr, 0, true, c.kp, d.mid, d.seg_out, stream));
   // 4. shortcut: max-pool over the pooling table when strided, Linear + InstanceNorm when the widths differ
   const float* sc = d.x;
   int64_t ldsc = d.ldx;
@@ -104,16 +118,13 @@ APR_API int apr_kp_resnet_block(const apr_kp_resnet_desc* dp, void* stream) {
     ldsc = d.in_dim;
   }
   if (d.w_shortcut) {
-    KP_TRY(apr_dense_gemm_bf3(sc, ldsc, d.n_out, d.in_dim, d.out_dim, d.w_shortcut, nullptr, nullptr, nullptr, 0, 0, c.sc,
-                              d.out_dim, stream));
-    KP_TRY(kp_norm(d, c, c.sc, d.n_out, d.out_dim, nullptr, 0, false, c.sc, d.out_dim, d.seg_out, stream));
+    KP_TRY(kp_linear_norm(d, c, sc, ldsc, d.n_out, d.in_dim, d.out_dim, d.w_shortcut, nullptr, 0, false, c.sc, d.out_dim, d.seg_out,
+                          stream));
     sc = c.sc;
     ldsc = d.out_dim;
   }
   // 5. unary2 (no ReLU) + InstanceNorm + shortcut + LeakyReLU
-  KP_TRY(apr_dense_gemm_bf3(c.kp, d.mid, d.n_out, d.mid, d.out_dim, d.w_unary2, nullptr, nullptr, nullptr, 0, 0, c.y, d.out_dim,
-                            stream));
-  KP_TRY(kp_norm(d, c, c.y, d.n_out, d.out_dim, sc, ldsc, true, d.out, d.ldo, d.seg_out, stream));
+  KP_TRY(kp_linear_norm(d, c, c.kp, d.mid, d.n_out, d.mid, d.out_dim, d.w_unary2, sc, ldsc, true, d.out, d.ldo, d.seg_out, stream));
 #undef KP_TRY
   return APR_OK;
 }

@@ -698,6 +698,23 @@ __global__ __launch_bounds__(256) void k_bn_train_bwd_apply(const float* __restr
 
 }  // namespace
 
+int apr_internal_norm_apply_partials(const float* x, int64_t ldx, int32_t c, const int64_t* seg_row0, const int* seg_blk0,
+                                     int32_t nseg, const double* partial, float eps, const float* residual, int64_t ldr,
+                                     int32_t act_mode, float negative_slope, float* y, int64_t ldy, hipStream_t st) {
+  APR_CHECK_ARG(nseg >= 1 && nseg <= kMaxSeg, "norm_apply_partials: 1 .. %d segments", kMaxSeg);
+  Segs sg;
+  int64_t max_rows = 0;
+  for (int i = 0; i <= nseg; ++i) {
+    sg.row0[i] = seg_row0[i];
+    sg.blk0[i] = seg_blk0[i];
+    if (i && seg_row0[i] - seg_row0[i - 1] > max_rows) max_rows = seg_row0[i] - seg_row0[i - 1];
+  }
+  hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)cdiv64(max_rows, kApplyRows), (c + 63) / 64, nseg), dim3(256), 0, st, x, ldx, c,
+                     sg, partial, eps, residual, ldr, act_mode, negative_slope, y, ldy);
+  APR_LAUNCH_CHECK();
+  return APR_OK;
+}
+
 APR_API size_t apr_norm_backward_scratch_bytes(int64_t n, int32_t c) {
   return (size_t)cdiv64(n > 0 ? n : 1, kRowsPerBlock) * 2 * (size_t)c * sizeof(double) + (size_t)2 * c * sizeof(float) + 512;
 }

@@ -82,6 +82,34 @@ def linear(x, wp_info, shift=None, relu=False, out=None):
     return y
 
 
+def linear_norm_act(x, wp_info, eps=1e-5, leaky=None, relu=False, residual=None, segments=None, out=None):
+    """act(instance_norm(x @ W) (+ residual)) in two launches (apr_dense_gemm_bf3_norm_act: the GEMM leaves its tiles'
+    column sums behind, the apply kernel normalises in place) when both widths are multiples of 64; `linear` +
+    `instance_norm_act` (three launches) otherwise.  `segments`: row offsets of the stacked scan pairs."""
+    wp, cin, cout, cin_p, cout_p, w_bf3 = wp_info
+    ok = (w_bf3 is not None and DENSE_BF3 and cin_p == cin and cout_p == cout and x.dim() == 2 and x.is_contiguous()
+          and x.data_ptr() % 16 == 0 and not tracking(x, residual))
+    if not ok:
+        y = linear(x, wp_info)
+        return instance_norm_act(y, eps=eps, leaky=leaky, relu=relu, residual=residual, out=out, segments=segments)
+    n = x.shape[0]
+    if out is None:
+        out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    out, ldo = ops._rows(out, "linear_norm_act.out")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = ops._rows(residual, "linear_norm_act.residual")
+    nseg = 0 if segments is None or len(segments) <= 2 else len(segments) - 1
+    offs = (C.c_int64 * (nseg + 1))(*[int(v) for v in segments]) if nseg else None
+    lib = _lib.load()
+    sb = int(lib.apr_dense_gemm_bf3_norm_scratch_bytes(n, cout, max(nseg, 1)))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+    mode = 2 if leaky is not None else int(bool(relu))
+    check(lib.apr_dense_gemm_bf3_norm_act(ptr(x), x.stride(0), n, cin, cout, ptr(w_bf3), float(eps), ptr(residual), ldr, mode,
+                                          float(leaky or 0.0), ptr(out), ldo, offs, nseg, ptr(scratch), sb, stream()))
+    return out
+
+
 class LinearFunction(torch.autograd.Function):
     """y = x @ W^T (nn.Linear without bias; KPFCNN's unary / bottleneck layers, Predator_APR/models/blocks.py:499-504) with
     forward, d x and d W on the HIP kernels: y and d x = dy @ W through the dense GEMM (`linear`), d W = dy^T x through

@@ -682,6 +682,19 @@ int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t*
 int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const void* w_bf3,
                        const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
                        float* out, int64_t ldo, void* stream);
+/* out = act(instance_norm(in @ W) (+ residual)) -- the Linear + InstanceNorm1d (+ shortcut) (+ LeakyReLU) every unary /
+ * bottleneck layer of KPFCNN is (Predator_APR/models/blocks.py:451-468, 499-504, 653-681) -- in TWO launches: the GEMM leaves
+ * the raw product in `out` and the per-tile column sums (fp64, rows in order) in scratch, the apply kernel rebuilds mean /
+ * rstd from them and normalises in place.  act_mode 0 none, 1 ReLU, 2 LeakyReLU(negative_slope).  seg_offsets_host (int64
+ * [nseg + 1], 0 .. M; NULL / nseg <= 1: one segment): the scan pairs stacked into one forward, each normalised on its own;
+ * row tiles never straddle a segment.  Same operator as apr_dense_gemm_bf3 followed by apr_instance_norm_act[_seg]; the
+ * statistics group their fp64 partial sums by GEMM tile instead of by 256 rows (results agree to the last bits, not bit for
+ * bit).  `out` may not alias `in`; residual may alias neither. */
+size_t apr_dense_gemm_bf3_norm_scratch_bytes(int64_t M, int32_t cout, int32_t nseg);
+int apr_dense_gemm_bf3_norm_act(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const void* w_bf3,
+                                float eps, const float* residual, int64_t ldr, int32_t act_mode, float negative_slope,
+                                float* out, int64_t ldo, const int64_t* seg_offsets_host, int32_t nseg, void* scratch,
+                                size_t scratch_bytes, void* stream);
 
 /* One ResnetBottleneckBlock of the KPConv encoder (Predator_APR/models/blocks.py:596-681; eval mode, use_batch_norm, rigid
  * KPConv, widths multiples of 64) enqueued by ONE call: unary1 (Linear + InstanceNorm + LeakyReLU; absent when in_dim ==
