@@ -85,6 +85,60 @@ __global__ void k_nn_prep(const float* __restrict__ f, int64_t n, float len_scal
   }
 }
 
+// Both sides of a search in ONE launch (round 5: one launch less per pair): threads [0, n0 * LPR) prepare the queries
+// (scaled by -2, eps factor, U / best initialised), the rest the targets -- the same arithmetic per row as k_nn_prep
+template <int C>
+__global__ void k_nn_prep2(const float* __restrict__ f0, int64_t n0, const float* __restrict__ f1, int64_t n1,
+                           unsigned short* __restrict__ qb, unsigned short* __restrict__ ql, f32x4* __restrict__ qmeta,
+                           unsigned short* __restrict__ tb, unsigned short* __restrict__ tl, f32x4* __restrict__ tmeta,
+                           unsigned* __restrict__ u_init, unsigned long long* __restrict__ best_init,
+                           unsigned* __restrict__ zero_me) {
+  constexpr int LPR = C / 4;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row_all = t / LPR;
+  const int g = (int)(t - row_all * LPR);
+  if (t == 0) {
+    zero_me[0] = 0u;
+    zero_me[1] = 0u;
+    zero_me[2] = 0u;
+  }
+  // n0 * LPR is a multiple of LPR: the shuffle groups of LPR lanes never mix the two sides
+  const bool is_q = row_all < n0;
+  const int64_t row = is_q ? row_all : row_all - n0;
+  const int64_t n = is_q ? n0 : n1;
+  const float* f = is_q ? f0 : f1;
+  const float row_scale = is_q ? -2.0f : 1.0f, len_scale = is_q ? kEpsRel : 1.0f;
+  unsigned short* fb = is_q ? qb : tb;
+  unsigned short* fl = is_q ? ql : tl;
+  f32x4* meta = is_q ? qmeta : tmeta;
+  float s = 0.f;
+  if (row < n) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(f + row * C + g * 4);
+    s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    v *= row_scale;
+    ushort4 o, ol;
+    o.x = to_bf16_rne(v[0]); o.y = to_bf16_rne(v[1]); o.z = to_bf16_rne(v[2]); o.w = to_bf16_rne(v[3]);
+    ol.x = to_bf16_rne(v[0] - __uint_as_float((unsigned)o.x << 16));
+    ol.y = to_bf16_rne(v[1] - __uint_as_float((unsigned)o.y << 16));
+    ol.z = to_bf16_rne(v[2] - __uint_as_float((unsigned)o.z << 16));
+    ol.w = to_bf16_rne(v[3] - __uint_as_float((unsigned)o.w << 16));
+    *reinterpret_cast<ushort4*>(fb + row * C + g * 4) = o;
+    *reinterpret_cast<ushort4*>(fl + row * C + g * 4) = ol;
+  }
+#pragma unroll
+  for (int d = 1; d < LPR; d <<= 1) s += __shfl_xor(s, d);
+  if (row < n && g == 0) {
+    const float nn = s;
+    const float sl = kEpsAbs * nn;
+    const float len = sqrtf(nn);
+    meta[row] = (f32x4){len_scale * len, nn + sl, nn - sl, 0.f};
+    if (is_q) {
+      u_init[row] = 0x7F800000u;
+      best_init[row] = ~0ull;
+    }
+  }
+}
+
 // REFINE = false: U_i = min_j (approx + eps).  REFINE = true: every pair with approx - eps <= U_i is appended to the
 // candidate list (exact evaluation happens densely in k_nn_exact).
 // Workgroup = 4 waves x 64 queries; a wave holds its 4 query tiles (16 rows each, hi + lo) as MFMA A operands in
@@ -545,10 +599,8 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
   unsigned* dense_list = (unsigned*)p;                        // ids of the flagged blocks (k_nn_dense_compact)
   const unsigned shared_cap = (unsigned)shared_capacity(n0);
   constexpr int LPR = C / 4;
-  hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n0 * LPR, 256)), dim3(256), 0, st, f0, n0, kEpsRel, -2.0f, qb,
-                     ql, qmeta, U, best, overflow);
-  hipLaunchKernelGGL((k_nn_prep<C>), dim3((unsigned)cdiv64(n1 * LPR, 256)), dim3(256), 0, st, f1, n1, 1.0f, 1.0f, tb, tl,
-                     tmeta, (unsigned*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr);
+  hipLaunchKernelGGL((k_nn_prep2<C>), dim3((unsigned)cdiv64((n0 + n1) * LPR, 256)), dim3(256), 0, st, f0, n0, f1, n1, qb, ql,
+                     qmeta, tb, tl, tmeta, U, best, overflow);
   static const int s_dense_min = env_int("APR_NN_DENSE_MIN", kDenseMin);
   static const int s_bound_div = env_int("APR_NN_BOUND_DIV", 4);   // bound pass over 1/div of every target chunk
   const dim3 grid((unsigned)qblocks, (unsigned)nchunk);

@@ -155,13 +155,20 @@ __device__ inline void kabsch4(const double s[4][3], const double t[4][3], doubl
 constexpr int kMini = 32;                        // rows of rec2 (= 64 correspondences) per mini-chunk
 __host__ __device__ inline int64_t rec2_rows(int64_t n0) { return ((n0 + 1) / 2 + kMini - 1) / kMini * kMini; }
 
+// corr_out (nullable): `corr` holds the NN search's PACKED results (bits(d^2) << 32 | j) and the plain indices are written
+// here on the way -- the batch path's former apr_nn_unpack launch (round 5)
 __global__ void k_pack_pairs(const float* __restrict__ xyz0, const float* __restrict__ xyz1, int64_t n1,
                              const long long* __restrict__ corr, int64_t n0, float4* __restrict__ rec,
-                             float* __restrict__ rec2, unsigned* __restrict__ maxn2, float* __restrict__ rec2_live) {
+                             float* __restrict__ rec2, unsigned* __restrict__ maxn2, float* __restrict__ rec2_live,
+                             long long* __restrict__ corr_out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float sx = 0.f, sy = 0.f, sz = 0.f, tx = 3e18f, ty = 3e18f, tz = 3e18f, m = 0.f;
   if (i < n0) {
     long long j = corr[i];
+    if (corr_out) {
+      j &= 0xFFFFFFFFll;
+      corr_out[i] = j;
+    }
     if (j < 0 || j >= n1) j = 0;
     sx = xyz0[3 * i]; sy = xyz0[3 * i + 1]; sz = xyz0[3 * i + 2];
     tx = xyz1[3 * j]; ty = xyz1[3 * j + 1]; tz = xyz1[3 * j + 2];
@@ -1378,9 +1385,9 @@ static RansacScratch carve_ransac(void* scratch, int64_t n0, int64_t max_iter) {
 
 // correspondences -> records (both layouts) + the norm bound of k_count (cleared by k_init_best, which runs first)
 static void launch_pack(const RansacScratch& r, const float* xyz0, const float* xyz1, int64_t n1, const int64_t* corr,
-                        int64_t n0, hipStream_t st) {
+                        int64_t n0, hipStream_t st, int64_t* unpack_to = nullptr) {
   hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)cdiv64(2 * rec2_rows(n0), 256)), dim3(256), 0, st, xyz0, xyz1, n1,
-                     (const long long*)corr, n0, r.rec, r.rec2, r.maxn2, r.rec2_live);
+                     (const long long*)corr, n0, r.rec, r.rec2, r.maxn2, r.rec2_live, (long long*)unpack_to);
   if (n0 <= kScreenMaxN0)      // the 8-byte records of k_sample_screen (needs the finished norm bound: its own launch)
     hipLaunchKernelGGL(k_pack_small, dim3((unsigned)cdiv64(n0 + 32, 256)), dim3(256), 0, st, r.rec, n0, r.maxn2, r.rec8);
 }
@@ -1793,15 +1800,13 @@ APR_API int apr_match_pose_batch_enqueue(const apr_pair_desc* pairs, int32_t B, 
     rc = fast_nn ? apr_feature_nn_fast(d.f0, d.n0, d.f1, d.n1, c, best, nn_scratch, L.nn_scratch, ls)
                  : apr_feature_nn(d.f0, d.n0, d.f1, d.n1, c, best, ls);
     if (rc != APR_OK) break;
-    int64_t* corr = (int64_t*)(corr_base + (size_t)i * L.corr_each);
-    rc = apr_nn_unpack(best, d.n0, corr, nullptr, ls);
-    if (rc != APR_OK) break;
+    int64_t* corr = (int64_t*)(corr_base + (size_t)i * L.corr_each);     // plain indices: written by k_pack_pairs below
     // single-round RANSAC into this pair's result slot
     RansacScratch r = carve_ransac(ransac_scratch, d.n0, max_iter);
     r.best = (Hyp*)(slots + (size_t)i * (sizeof(Hyp) + 64));
     r.total_valid = (long long*)((char*)r.best + sizeof(Hyp));
     hipLaunchKernelGGL(k_init_best, dim3(1), dim3(128), 0, ls, r.best, r.total_valid, r.maxn2, r.n_valid, counter_words(r));
-    launch_pack(r, d.xyz0, d.xyz1, d.n1, corr, d.n0, ls);
+    launch_pack(r, d.xyz0, d.xyz1, d.n1, (const int64_t*)best, d.n0, ls, corr);
     launch_hypotheses(r, d.n0, max_dist, edge_ratio, 0, max_iter, d.seed, (int)cap, ls, true);
     launch_scoring(r, d.n0, thr_lt, (int)cap, ls);
   }
