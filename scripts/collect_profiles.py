@@ -3,7 +3,7 @@ usage: python scripts/collect_profiles.py <tag> [prefix=r01]"""
 import csv, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-prefix = sys.argv[2] if len(sys.argv) > 2 else "r04"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r05"
 src = os.path.join(root, "gpurun_out", f"profile_{tag}")
 dst = os.path.join(root, "profiles")
 pairs = [("bench.json", f"{prefix}_bench.json"), ("bench_s1.json", f"{prefix}_bench_streams1.json"),
@@ -22,6 +22,8 @@ pairs += [("selflaunch_gloo2.json", f"{prefix}_selflaunch_gloo2.json"),
           ("match_load.log", f"{prefix}_matching_0_30pct.log")]
 pairs += [("one_pair_split.log", f"{prefix}_one_pair_split.log"),
           ("one_pair_split_python_plan.log", f"{prefix}_one_pair_split_python_plan.log")]
+pairs += [("train_step.json", f"{prefix}_train_step.json"), ("train_step.log", f"{prefix}_train_step.log"),
+          ("train_stats/t_kernel_stats.csv", f"{prefix}_train_step_kernel_stats.csv")]
 pairs += [(f"driver_cmd_{i}.json", f"{prefix}_driver_cmd_{i}.json") for i in (1, 2, 3)]
 pairs += [(f"driver_cmd_{i}.log", f"{prefix}_driver_cmd_{i}.log") for i in (1, 2, 3)]
 for a, b in pairs:

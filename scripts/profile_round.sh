@@ -5,11 +5,13 @@
 #   gpurun -- scripts/profile_round.sh r02        -> gpurun_out/profile_r02/*  (scripts/collect_profiles.py copies
 #   what is judged into profiles/)
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+PART=${PART:-all}      # a: the plain runs, b: the rocprof / PMC passes (gpurun limits a call to 20 minutes)
+if [ "$PART" != b ]; then
 for i in 1 2 3; do
   echo "[profile] driver command, run $i"
   APR_BENCH_STEPLOG=1 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-workloads > $OUT/driver_cmd_$i.json 2> $OUT/driver_cmd_$i.log </dev/null || { echo "driver cmd failed"; tail -5 $OUT/driver_cmd_$i.log; exit 1; }
@@ -28,6 +30,8 @@ APR_FETCH_WAIT=sync python3 $R/scripts/host_cpu_split.py 150 > $OUT/host_cpu_spl
 echo "[profile] one pair per call: host time between the fetches against time blocked on the GPU"
 python3 $R/scripts/one_pair_split.py > $OUT/one_pair_split.log 2>&1 </dev/null || { echo "one pair split failed"; exit 1; }
 APR_ENCODE_PLAN=0 APR_FRONT_END_CALL=0 python3 $R/scripts/one_pair_split.py > $OUT/one_pair_split_python_plan.log 2>&1 </dev/null || { echo "one pair split (python plan) failed"; exit 1; }
+fi
+if [ "$PART" = a ]; then echo "[profile] part a done"; exit 0; fi
 echo "[profile] matching at 0 / 30 % true matches under rocprof (the regime a trained checkpoint puts the matcher in)"
 SHARES=0.0,0.3 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/match_stats -o m -- python3 $R/scripts/match_load_bench.py > $OUT/match_load.log 2>&1 </dev/null || { echo "match stats failed"; exit 1; }
 echo "[profile] rocprof stats, default run"
@@ -44,6 +48,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "[profile] predator kpconv pmc $C"
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pred_pmc_$C -o p -- python3 $R/scripts/kpconv_bench.py > $OUT/pred_pmc_$C.log 2>&1 </dev/null || { echo "kpconv pmc $C failed"; exit 1; }
 done
+echo "[profile] APR training iteration: stage split + kernel stats"
+ITERS=10 python3 $R/scripts/apr_train_step.py > $OUT/train_step.json 2> $OUT/train_step.log </dev/null || { echo "train step failed"; tail -5 $OUT/train_step.log; exit 1; }
+ITERS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o t -- python3 $R/scripts/apr_train_step.py > $OUT/train_step_prof.json 2> $OUT/train_step_prof.log </dev/null || { echo "train step rocprof failed"; exit 1; }
 python3 $R/scripts/pmc_summary.py $OUT > $OUT/pmc_spconv_summary.json && head -40 $OUT/pmc_spconv_summary.json
 # keep the merge small: traces are large, the stats and counter tables are what is judged
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
