@@ -82,8 +82,8 @@ class HardestContrastiveLoss:
         counts N0 / N1 are known from the coordinates, so a trainer can call this BEFORE the encoder runs."""
         dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
         if not isinstance(positive_pairs, np.ndarray):
-            positive_pairs = np.array(positive_pairs.cpu() if torch.is_tensor(positive_pairs) else positive_pairs,
-                                      dtype=np.int64)
+            positive_pairs = (positive_pairs.detach().cpu().numpy() if torch.is_tensor(positive_pairs)
+                              else np.asarray(positive_pairs)).astype(np.int64)
         positive_pairs = positive_pairs.astype(np.int64)
         N_pos_pairs = len(positive_pairs)
         hash_seed = max(N0, N1)
