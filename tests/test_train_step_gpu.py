@@ -65,3 +65,31 @@ def test_train_step_runs_learns_and_both_encoder_call_forms_agree(dev):
     assert all(int(v) == 12 for v in na.values()) and all(int(v) == 12 for v in nb.values())   # 6 iterations x 2 calls
     assert abs(la[0] - lb[0]) < 1e-4 * abs(lb[0])                               # first iteration: the same numbers
     assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-2 * abs(lb[0])          # then two fp32 trajectories of the same run
+
+
+def test_train_step_with_a_batch_of_two_pairs(dev):
+    """batch_size 2 (scripts/train_apr_kitti.sh trains with 4): each frame tensor holds two clouds (BatchNorm statistics over
+    both, as MinkowskiBatchNorm does), correspondences carry the collate's row offsets (complement_data_loader.py:1240-1256),
+    the NPR loss loops over the clouds (complement_trainer.py:424-449).  Stacked and separate encoder calls agree."""
+    b0, b1 = _batch(dev, seed=3), _batch(dev, seed=5)
+    n00, n01 = b0["sinput0_C"].shape[0], b0["sinput1_C"].shape[0]
+    shift = lambda C, k: torch.cat((C[:, :1] + k, C[:, 1:]), 1)
+    batch = {}
+    for tag in ("0", "1"):
+        batch[f"sinput{tag}_C"] = torch.cat((b0[f"sinput{tag}_C"], shift(b1[f"sinput{tag}_C"], 1)), 0).contiguous()
+        batch[f"sinput{tag}_F"] = torch.cat((b0[f"sinput{tag}_F"], b1[f"sinput{tag}_F"]), 0)
+        batch[f"pcd_nghb{tag}"] = b0[f"pcd_nghb{tag}"] + b1[f"pcd_nghb{tag}"]
+    off = torch.tensor([[n00, n01]])
+    batch["correspondences"] = torch.cat((b0["correspondences"], b1["correspondences"] + off), 0)
+    batch["len_batch"] = b0["len_batch"] + b1["len_batch"]
+    res = {}
+    for stack in (True, False):
+        st, enc, gen = _step(dev, stack)
+        np.random.seed(0)
+        r = st(batch)
+        res[stack] = (float(r["loss"]), float(r["pos_loss"]), float(r["neg_loss"]),
+                      {k: v.clone() for k, v in enc.state_dict().items() if k.endswith("running_mean")})
+    assert np.isfinite(res[True][0]) and abs(res[True][0] - res[False][0]) < 1e-4 * abs(res[False][0])
+    assert abs(res[True][1] - res[False][1]) < 1e-4 and abs(res[True][2] - res[False][2]) < 1e-4
+    for k, v in res[True][3].items():
+        assert torch.allclose(v, res[False][3][k], rtol=1e-4, atol=1e-6), k
