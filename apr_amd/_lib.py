@@ -221,6 +221,7 @@ PROTOTYPES = {
     "apr_chamfer_sum": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _sz, _p]),
     "apr_nn3_scratch_bytes": (_sz, [_i64, _i64]),
     "apr_nn3": (C.c_int, [_p, _i64, _p, _i64, C.c_float, _p, _p, _p, _sz, _p]),
+    "apr_nn3_batch": (C.c_int, [_p, _p, _p, _p, _i32, C.c_float, _p, _p, _p, _p, _sz, _p]),
 }
 
 class KpResnetDesc(C.Structure):

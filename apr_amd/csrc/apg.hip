@@ -205,31 +205,48 @@ __device__ inline void better(float d, unsigned j, float& bd, unsigned& bj) {
   }
 }
 
+// several independent searches in one call: cloud s of the queries (rows a0[s] .. a0[s + 1]) is searched in cloud s of the
+// targets (rows b0[s] .. b0[s + 1]) only; the grid's cells carry the cloud index in their key
+constexpr int kNn3MaxSeg = 32;
+struct Nn3Segs {
+  int nb;
+  int a0[kNn3MaxSeg + 1];
+  int b0[kNn3MaxSeg + 1];
+  double scale[kNn3MaxSeg];      // the per-cloud sum is multiplied by this on the way out (1, or 1 / rows for a mean)
+};
+
+__device__ inline int seg_of(const Nn3Segs& sg, int64_t i) {
+  int s = 0;
+  while (s + 1 < sg.nb && i >= sg.a0[s + 1]) ++s;
+  return s;
+}
+
 // cells [base - (ring - 1), base + ring]^3 minus the cube of the previous ring; base = floor(u - 0.5), u = (p - min) / cell
-__device__ inline void cell_base(const AprSearchGrid& g, float x, float y, float z, int* base) {
-  base[0] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(x, g.mins[0]), g.cell), 0.5f));
-  base[1] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(y, g.mins[1]), g.cell), 0.5f));
-  base[2] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(z, g.mins[2]), g.cell), 0.5f));
+__device__ inline void cell_base(const AprSearchGrid& g, int seg, float x, float y, float z, int* base) {
+  base[0] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(x, g.mins[3 * seg]), g.cell), 0.5f));
+  base[1] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(y, g.mins[3 * seg + 1]), g.cell), 0.5f));
+  base[2] = (int)floorf(__fsub_rn(__fdiv_rn(__fsub_rn(z, g.mins[3 * seg + 2]), g.cell), 0.5f));
 }
 
 __global__ __launch_bounds__(256) void k_nn3_grid_thread(const float* __restrict__ a, int64_t n, const float* __restrict__ b,
-                                                         AprSearchGrid g, unsigned long long* __restrict__ best,
+                                                         AprSearchGrid g, Nn3Segs sg, unsigned long long* __restrict__ best,
                                                          int* __restrict__ list, int* __restrict__ list_n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < n;
   bool unresolved = false;
   if (live) {
     const float x = a[3 * i], y = a[3 * i + 1], z = a[3 * i + 2];
+    const int seg = seg_of(sg, i);
     int base[3];
-    cell_base(g, x, y, z, base);
+    cell_base(g, seg, x, y, z, base);
     float bd = __builtin_inff();
     unsigned bj = 0xFFFFFFFFu;
     bool done = false;
 #pragma unroll
     for (int o = 0; o < 8; ++o) {                               // ring 1: the 2^3 cells around the query
       const int X = base[0] + (o & 1), Y = base[1] + ((o >> 1) & 1), Z = base[2] + (o >> 2);
-      if (!apr_key_in_range(0, X, Y, Z)) continue;
-      const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+      if (!apr_key_in_range(seg, X, Y, Z)) continue;
+      const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(seg, X, Y, Z));
       if (id < 0) continue;
       const int e1 = g.start[id + 1];
       for (int e = g.start[id]; e < e1; ++e) {
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256) void k_nn3_grid_thread(const float* __restrict
 // ring; what is still open after the last ring -- or when the grid is absent (g.cell == 0) -- takes every target
 constexpr int kMaxRing = 6;
 __global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__ a, const float* __restrict__ b, int64_t m,
-                                                       AprSearchGrid g, const int* __restrict__ list_in,
+                                                       AprSearchGrid g, Nn3Segs sg, const int* __restrict__ list_in,
                                                        const int* __restrict__ list_in_n, unsigned long long* __restrict__ best,
                                                        int* __restrict__ list_out, int* __restrict__ list_out_n) {
   const int lane = threadIdx.x & 63;
@@ -267,17 +284,18 @@ __global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__
   if (q >= *list_in_n) return;                               // wave-uniform
   const int64_t i = list_in[q];
   const float x = a[3 * i], y = a[3 * i + 1], z = a[3 * i + 2];
+  const int seg = seg_of(sg, i);
   float bd = __builtin_inff();
   unsigned bj = 0xFFFFFFFFu;
   bool done = false;
   if (g.cell > 0.f) {
     int base[3];
-    cell_base(g, x, y, z, base);
+    cell_base(g, seg, x, y, z, base);
     // ring 1 again (the thread pass does not hand its candidate over): 8 cells, lanes over the cells' points
     for (int o = 0; o < 8; ++o) {
       const int X = base[0] + (o & 1), Y = base[1] + ((o >> 1) & 1), Z = base[2] + (o >> 2);
-      if (!apr_key_in_range(0, X, Y, Z)) continue;
-      const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+      if (!apr_key_in_range(seg, X, Y, Z)) continue;
+      const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(seg, X, Y, Z));
       if (id < 0) continue;
       const int e1 = g.start[id + 1];
       for (int e = g.start[id] + lane; e < e1; e += 64) {
@@ -291,8 +309,8 @@ __global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__
         const int cx = lo + t % L, cy = lo + (t / L) % L, cz = lo + t / (L * L);
         if (cx > lo && cx < ring && cy > lo && cy < ring && cz > lo && cz < ring) continue;      // the previous rings' cube
         const int X = base[0] + cx, Y = base[1] + cy, Z = base[2] + cz;
-        if (!apr_key_in_range(0, X, Y, Z)) continue;
-        const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(0, X, Y, Z));
+        if (!apr_key_in_range(seg, X, Y, Z)) continue;
+        const int id = apr_table_lookup(g.keys, g.vals, g.mask, apr_pack_key(seg, X, Y, Z));
         if (id < 0) continue;
         const int e1 = g.start[id + 1];
         for (int e = g.start[id]; e < e1; ++e) {
@@ -306,12 +324,18 @@ __global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__
       done = wd <= r * r;
     }
   }
-  if (!done) {                                               // the tiled full search takes it (k_nn3_arg_list)
+  if (!done && list_out) {                                   // one cloud: the tiled full search takes it (k_nn3_arg_list)
     if (lane == 0) {
       best[i] = ~0ull;
       list_out[atomicAdd(list_out_n, 1)] = (int)i;
     }
     return;
+  }
+  if (!done) {                                               // several clouds: every target of the query's own cloud
+    bd = __builtin_inff();
+    bj = 0xFFFFFFFFu;
+    for (int64_t j = sg.b0[seg] + lane; j < sg.b0[seg + 1]; j += 64)
+      better(d2_rn(x, y, z, b[3 * j], b[3 * j + 1], b[3 * j + 2]), (unsigned)j, bd, bj);
   }
   for (int d = 32; d >= 1; d >>= 1) {
     const float od = __shfl_xor(bd, d);
@@ -334,6 +358,22 @@ __global__ __launch_bounds__(1024) void k_sum_packed(const unsigned long long* _
     __syncthreads();
   }
   if (threadIdx.x == 0) *out = part[0];
+}
+
+// the same per cloud: workgroup s sums the minima of rows a0[s] .. a0[s + 1]
+__global__ __launch_bounds__(1024) void k_sum_packed_seg(const unsigned long long* __restrict__ best, Nn3Segs sg,
+                                                         double* __restrict__ out) {
+  __shared__ double part[1024];
+  const int s0 = blockIdx.x;
+  double s = 0.0;
+  for (int64_t i = sg.a0[s0] + threadIdx.x; i < sg.a0[s0 + 1]; i += 1024) s += (double)__uint_as_float((unsigned)(best[i] >> 32));
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 512; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[s0] = part[0] * sg.scale[s0];
 }
 
 __global__ void k_sum_bits(const unsigned* __restrict__ bits, int64_t n, double* __restrict__ out) {
@@ -412,11 +452,19 @@ APR_API size_t apr_nn3_scratch_bytes(int64_t n, int64_t m) {
   return align256(apr_internal_grid_bytes(m)) + 2 * align256((size_t)(n > 0 ? n : 1) * 4) + 1024;
 }
 
-APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
-                    void* scratch, size_t scratch_bytes, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  APR_CHECK_ARG(n > 0 && m > 0 && m < (1ll << 31) - 1 && n < (1ll << 31), "apr_nn3: empty or oversized cloud");
+static int nn3_impl(const float* a, int64_t n, const int64_t* a_off, const float* b, int64_t m, const int64_t* b_off, int nb,
+                    float cell, uint64_t* out_packed, double* sums_dev, const double* sum_scale_host, void* scratch,
+                    size_t scratch_bytes, hipStream_t st) {
   unsigned long long* best = (unsigned long long*)out_packed;
+  Nn3Segs sg;
+  sg.nb = nb;
+  for (int i = 0; i < nb; ++i) sg.scale[i] = sum_scale_host ? sum_scale_host[i] : 1.0;
+  int32_t blen[kNn3MaxSeg];
+  for (int i = 0; i <= nb; ++i) {
+    sg.a0[i] = (int)a_off[i];
+    sg.b0[i] = (int)b_off[i];
+    if (i) blen[i - 1] = (int32_t)(b_off[i] - b_off[i - 1]);
+  }
   if (cell > 0.f) {
     APR_CHECK_ARG(scratch && scratch_bytes >= apr_nn3_scratch_bytes(n, m), "apr_nn3: scratch too small");
     char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
@@ -428,21 +476,25 @@ APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float 
     p += align256((size_t)n * 4);
     int* counts = (int*)p;                                     // [0] list1, [1] list2
     AprSearchGrid g1;
-    int rc = apr_internal_search_grid(b, m, cell, g1s, &g1, st);
+    int rc = apr_internal_search_grid_batch(b, m, blen, nb, cell, g1s, &g1, st);
     if (rc != APR_OK) return rc;
     APR_HIP(hipMemsetAsync(counts, 0, 8, st));
-    hipLaunchKernelGGL(k_nn3_grid_thread, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, a, n, b, g1, best, list1, counts);
-    hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, g1, list1, counts, best, list2,
-                       counts + 1);
-    {
+    hipLaunchKernelGGL(k_nn3_grid_thread, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, a, n, b, g1, sg, best, list1, counts);
+    if (nb == 1) {
+      hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, g1, sg, list1, counts, best,
+                         list2, counts + 1);
       const int64_t qb = cdiv64(n, 256);
       int64_t want = cdiv64(2048, qb);
       int64_t chunk = cdiv64(cdiv64(m, want), kTile) * kTile;
       if (chunk < kTile) chunk = kTile;
       hipLaunchKernelGGL(k_nn3_arg_list, dim3((unsigned)qb, (unsigned)cdiv64(m, chunk)), dim3(256), 0, st, a, list2, counts + 1, b,
                          m, (int)chunk, best);
+    } else {
+      hipLaunchKernelGGL(k_nn3_grid_wave, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, a, b, m, g1, sg, list1, counts, best,
+                         (int*)nullptr, (int*)nullptr);
     }
   } else {
+    APR_CHECK_ARG(nb == 1, "apr_nn3_batch: cell = 0 (brute force) searches one cloud at a time");
     APR_HIP(hipMemsetAsync(out_packed, 0xFF, (size_t)n * 8, st));
     const int64_t qb = cdiv64(n, 256);
     int64_t want = cdiv64(2048, qb);
@@ -450,7 +502,30 @@ APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float 
     if (chunk < kTile) chunk = kTile;
     hipLaunchKernelGGL(k_nn3_arg, dim3((unsigned)qb, (unsigned)cdiv64(m, chunk)), dim3(256), 0, st, a, n, b, m, (int)chunk, best);
   }
-  if (sum_dev) hipLaunchKernelGGL(k_sum_packed, dim3(1), dim3(1024), 0, st, (const unsigned long long*)best, n, sum_dev);
+  if (sums_dev) hipLaunchKernelGGL(k_sum_packed_seg, dim3((unsigned)nb), dim3(1024), 0, st, (const unsigned long long*)best, sg, sums_dev);
   APR_LAUNCH_CHECK();
   return APR_OK;
+}
+
+APR_API int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
+                    void* scratch, size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(n > 0 && m > 0 && m < (1ll << 31) - 1 && n < (1ll << 31), "apr_nn3: empty or oversized cloud");
+  const int64_t ao[2] = {0, n}, bo[2] = {0, m};
+  return nn3_impl(a, n, ao, b, m, bo, 1, cell, out_packed, sum_dev, nullptr, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+APR_API int apr_nn3_batch(const float* a, const int64_t* a_offsets_host, const float* b, const int64_t* b_offsets_host, int32_t nb,
+                          float cell, uint64_t* out_packed, double* sums_dev, const double* sum_scale_host, void* scratch,
+                          size_t scratch_bytes, void* stream) {
+  APR_CHECK_ARG(a && b && a_offsets_host && b_offsets_host && nb >= 1 && nb <= kNn3MaxSeg, "apr_nn3_batch: 1 .. %d clouds",
+                kNn3MaxSeg);
+  APR_CHECK_ARG(a_offsets_host[0] == 0 && b_offsets_host[0] == 0, "apr_nn3_batch: offsets start at 0");
+  for (int i = 0; i < nb; ++i)
+    APR_CHECK_ARG(a_offsets_host[i + 1] > a_offsets_host[i] && b_offsets_host[i + 1] > b_offsets_host[i],
+                  "apr_nn3_batch: empty cloud %d", i);
+  const int64_t n = a_offsets_host[nb], m = b_offsets_host[nb];
+  APR_CHECK_ARG(m < (1ll << 31) - 1 && n < (1ll << 31), "apr_nn3_batch: oversized clouds");
+  APR_CHECK_ARG(cell > 0.f || nb == 1, "apr_nn3_batch: several clouds need the grid (cell > 0)");
+  return nn3_impl(a, n, a_offsets_host, b, m, b_offsets_host, nb, cell, out_packed, sums_dev, sum_scale_host, scratch,
+                  scratch_bytes, (hipStream_t)stream);
 }

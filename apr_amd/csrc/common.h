@@ -122,6 +122,8 @@ struct AprSearchGrid {
 size_t apr_internal_grid_bytes(int64_t n);
 int apr_internal_search_grid(const float* pts, int64_t n, float cell, void* scratch, AprSearchGrid* out,
                              hipStream_t st);
+int apr_internal_search_grid_batch(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float cell, void* scratch,
+                                   AprSearchGrid* out, hipStream_t st);
 
 __device__ static inline int apr_table_lookup(const unsigned long long* __restrict__ keys,
                                               const int* __restrict__ vals, uint32_t mask,

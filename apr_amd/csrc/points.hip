@@ -823,6 +823,26 @@ int apr_internal_search_grid(const float* pts, int64_t n, float cell, void* scra
   return APR_OK;
 }
 
+// the same over a BATCH of clouds stacked in pts (lengths_host[nb]): cells are keyed (cloud, x, y, z), origins per cloud
+int apr_internal_search_grid_batch(const float* pts, int64_t n, const int32_t* lengths_host, int32_t nb, float cell, void* scratch,
+                                   AprSearchGrid* out, hipStream_t st) {
+  if (nb < 1 || nb > kMaxBatch) {
+    apr_set_error("search_grid_batch: 1 .. %d clouds", kMaxBatch);
+    return APR_EINVAL;
+  }
+  GridWork w = carve(scratch, n);
+  int rc = build_grid(pts, n, lengths_host, nb, cell, 1, w, st);
+  if (rc != APR_OK) return rc;
+  out->keys = w.keys;
+  out->vals = w.vals;
+  out->mask = (uint32_t)(w.cap - 1);
+  out->start = w.start;
+  out->sorted = w.sorted;
+  out->mins = w.mins;
+  out->cell = cell;
+  return APR_OK;
+}
+
 APR_API size_t apr_radius_scratch_bytes(int64_t nq, int64_t ns) {
   return grid_work_bytes(ns > 0 ? ns : 1) + align256((nq > 0 ? nq : 1) * 4) + align256((kMaxBatch + 1) * 4) + 512;
 }

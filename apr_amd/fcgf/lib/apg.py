@@ -100,8 +100,10 @@ class GenerativeMLP(nn.Module):
             nn.Linear(CH[1], CH[2]), nn.ReLU(), nn.BatchNorm1d(CH[2], momentum=bn_momentum),
             nn.Linear(CH[2], out_points * 3), nn.ReLU())
 
-    def forward(self, x):
-        return npr.run_stack(self.mlp, x)
+    def forward(self, x, segments=None):
+        """`segments` (row offsets, optional): x stacks the rows of several calls (the clouds of a batch, both frames) --
+        the BatchNorms keep one set of batch statistics per call, as separate calls would."""
+        return npr.run_stack(self.mlp, x, segments)
 
 
 class GenerativeMLP_98(GenerativeMLP):

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from ... import MinkowskiEngine as ME
-from ... import ops, synth
+from ... import npr, ops, synth
 from . import apg
 from .trainer import HardestContrastiveLoss
 
@@ -55,6 +55,32 @@ class GenerativePairTrainStep:
                                                       self.regularization_type, self.alpha) * self.loss_ratio
         return loss
 
+    def _recon_stacked(self, encs, Cs, clouds, rows):
+        """Both frames' per-cloud loops (:424-449, :455-481) in ONE pass: the generator runs once over all clouds (per-cloud
+        BatchNorm statistics through the segments, in the reference's call order: frame 0's clouds, then frame 1's), the
+        Chamfer term of every cloud in two batched searches (apr_nn3_batch).  Same numbers as `_recon` per frame."""
+        offs = [0]
+        for fr in rows:
+            for r in fr:
+                offs.append(offs[-1] + int(r))
+        F = torch.cat([e.F for e in encs], 0)
+        Cc = torch.cat([c[:, 1:] for c in Cs], 0)
+        generated = self.generator_model(F, segments=offs) * self.voxel_size
+        ratio = self.point_generation_ratio
+        mod = apg.npr_points(generated, Cc, self.voxel_size, ratio)
+        cl = [c for fr in clouds for c in fr]
+        cl = [c.to(F.device, dtype=torch.float32) if torch.is_tensor(c) else torch.as_tensor(c, dtype=torch.float32, device=F.device)
+              for c in cl]
+        b_offs = [0]
+        for c in cl:
+            b_offs.append(b_offs[-1] + int(c.shape[0]))
+        cham = npr.chamfer_distance_batch(mod, [o * ratio for o in offs], torch.cat(cl, 0), b_offs)
+        loss = 0
+        for i, (a, b) in enumerate(zip(offs[:-1], offs[1:])):
+            reg = apg.npr_regulariser(generated[a:b], self.regularization_type, self.alpha)
+            loss = loss + (cham[i] + reg * self.regularization_strength) * self.loss_ratio
+        return loss
+
     def __call__(self, input_dict, draws=None, timed=False):
         dev = torch.device('cuda', torch.cuda.current_device())
         marks = []
@@ -86,8 +112,13 @@ class GenerativePairTrainStep:
             enc[0].F, enc[1].F, None, num_pos=self.num_pos, num_hn_samples=self.num_hn, draws=prepared)
         loss = pos_loss + self.neg_weight * neg_loss
         mark()
-        loss = loss + self._recon(enc[0], input_dict['pcd_nghb0'], rows[0], input_dict['sinput0_C'].to(dev)) \
-            + self._recon(enc[1], input_dict['pcd_nghb1'], rows[1], input_dict['sinput1_C'].to(dev))
+        Cs = [input_dict['sinput0_C'].to(dev), input_dict['sinput1_C'].to(dev)]
+        if self.stack_frames and rows[0] is not None and all(sum(r) == e.F.shape[0] for r, e in zip(rows, enc)) \
+                and sum(len(r) for r in rows) <= 32 and all(v >= 2 for r in rows for v in r):
+            loss = loss + self._recon_stacked(enc, Cs, [input_dict['pcd_nghb0'], input_dict['pcd_nghb1']], rows)
+        else:
+            loss = loss + self._recon(enc[0], input_dict['pcd_nghb0'], rows[0], Cs[0]) \
+                + self._recon(enc[1], input_dict['pcd_nghb1'], rows[1], Cs[1])
         mark()
         loss.backward()
         mark()

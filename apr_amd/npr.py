@@ -9,6 +9,7 @@ runs in libapr_hip.so: the GEMMs with bias + ReLU in the epilogue (`kp_ops.Linea
 normalisation and its backward (`ops.NormFunction`), the exact 1-NN searches of the Chamfer term (`apr_nn3`) and the
 ordered scatter of its gradient (reverse table + `apr_reverse_gather`: no float atomics, same bits every run).
 """
+import ctypes as C
 import weakref
 
 import torch
@@ -42,6 +43,24 @@ def nn3(a, b, want_sum=True, cell=None):
     idx = packed & 0xFFFFFFFF
     d2 = (packed >> 32).to(torch.int32).view(torch.float32)
     return idx, d2, (total[0] if want_sum else None)
+
+
+def nn3_batch(a, a_offsets, b, b_offsets, cell=None, mean=False):
+    """nb independent exact 1-NN searches in one call (apr_nn3_batch): cloud s of a (rows a_offsets[s] .. [s+1]) among cloud s
+    of b -> (GLOBAL index into b int64 [n], d2 float32 [n], per-cloud f64 sums [nb]; `mean`: divided by the cloud's rows)."""
+    a, b = a.contiguous(), b.contiguous()
+    n, m, nb = a.shape[0], b.shape[0], len(a_offsets) - 1
+    cell = NN3_CELL if cell is None else float(cell)
+    lib = _lib.load()
+    packed = torch.empty(n, dtype=torch.int64, device=a.device)
+    sums = torch.empty(nb, dtype=torch.float64, device=a.device)
+    sb = int(lib.apr_nn3_scratch_bytes(n, m))
+    scratch = torch.empty(sb, dtype=torch.uint8, device=a.device)
+    ao = (C.c_int64 * (nb + 1))(*[int(v) for v in a_offsets])
+    bo = (C.c_int64 * (nb + 1))(*[int(v) for v in b_offsets])
+    sc = (C.c_double * nb)(*[1.0 / (int(a_offsets[s + 1]) - int(a_offsets[s])) for s in range(nb)]) if mean else None
+    check(lib.apr_nn3_batch(ptr(a), ao, ptr(b), bo, nb, cell, ptr(packed), ptr(sums), sc, ptr(scratch), sb, stream()))
+    return packed & 0xFFFFFFFF, (packed >> 32).to(torch.int32).view(torch.float32), sums
 
 
 def _scatter_rows(rows4, idx, n_out):
@@ -82,6 +101,44 @@ class ChamferFunction(torch.autograd.Function):
         return ga, gb
 
 
+class ChamferBatchFunction(torch.autograd.Function):
+    """ChamferFunction for nb cloud pairs at once -> the nb Chamfer values [nb] (float32).  a / b stack the clouds
+    (a_offsets / b_offsets: host row offsets); a point's neighbours are searched in its own cloud's partner only."""
+
+    @staticmethod
+    def forward(ctx, a, b, a_offsets, b_offsets):
+        a, b = a.contiguous(), b.contiguous()
+        i_ab, _, m_ab = nn3_batch(a, a_offsets, b, b_offsets, mean=True)
+        i_ba, _, m_ba = nn3_batch(b, b_offsets, a, a_offsets, mean=True)
+        ctx.save_for_backward(a, b, i_ab, i_ba)
+        ctx.offs = (list(a_offsets), list(b_offsets))
+        return (m_ab + m_ba).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, i_ab, i_ba = ctx.saved_tensors
+        ao, bo = ctx.offs
+        n, m = a.shape[0], b.shape[0]
+        g = g.to(torch.float32)
+        d_ab = a - b[i_ab]
+        d_ba = b - a[i_ba]
+        for s in range(len(ao) - 1):        # per cloud: 2 g_s / rows (sliced in place: no host -> device copy in the backward)
+            d_ab[ao[s]:ao[s + 1]] *= g[s] * (2.0 / (ao[s + 1] - ao[s]))
+            d_ba[bo[s]:bo[s + 1]] *= g[s] * (2.0 / (bo[s + 1] - bo[s]))
+        pad = lambda t: torch.nn.functional.pad(t, (0, 1)).contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = d_ab - _scatter_rows(pad(d_ba), i_ba, n)[:, :3]
+        if ctx.needs_input_grad[1]:
+            gb = d_ba - _scatter_rows(pad(d_ab), i_ab, m)[:, :3]
+        return ga, gb, None, None
+
+
+def chamfer_distance_batch(a, a_offsets, b, b_offsets):
+    """The Chamfer value of `chamfer_distance` for every cloud pair of a batch in one call -> float32 [nb], differentiable."""
+    return ChamferBatchFunction.apply(_f32_dev(a), _f32_dev(b), [int(v) for v in a_offsets], [int(v) for v in b_offsets])
+
+
 def chamfer_distance(array1, array2):
     """`chamfer_distance(array1, array2)` of both trainers: forward / n1 + backward / n2, 0-d float32 GPU tensor,
     differentiable in both clouds."""
@@ -116,9 +173,16 @@ def linear_relu(x, lin: nn.Linear, relu=True):
     return kp_ops.linear(x.contiguous(), wp, shift=None if lin.bias is None else lin.bias.detach(), relu=relu)
 
 
-def batch_norm_rows(x, bn: nn.BatchNorm1d):
-    """nn.BatchNorm1d on rows [n, c]: training = batch statistics + running-statistics update, eval = running statistics."""
+def batch_norm_rows(x, bn: nn.BatchNorm1d, segments=None):
+    """nn.BatchNorm1d on rows [n, c]: training = batch statistics + running-statistics update, eval = running statistics.
+    `segments` (row offsets, training only): the rows of several module calls stacked -- statistics per call."""
     use_batch = bn.training or not bn.track_running_stats
+    if segments is not None and len(segments) > 2 and use_batch:
+        if bn.weight is None or not bn.track_running_stats or bn.momentum is None:
+            raise NotImplementedError("stacked calls need an affine BatchNorm1d with running statistics and a fixed momentum")
+        if kp_ops.tracking(x, bn.weight, bn.bias):
+            return ops.BnTrainFunction.apply(x, bn.weight, bn.bias, bn, list(segments))
+        return ops.bn_train_fwd(x.contiguous(), bn, segments=list(segments))[0]
     if use_batch and x.shape[0] < 2:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
     if kp_ops.tracking(x, bn.weight, bn.bias):
@@ -149,8 +213,9 @@ def batch_norm_rows(x, bn: nn.BatchNorm1d):
     return ops.affine_act(x, scale=scale.contiguous(), shift=shift.contiguous())
 
 
-def run_stack(mods, x):
-    """A list of nn.Linear / nn.ReLU / nn.BatchNorm1d modules in the order the reference stacks them, on the HIP kernels."""
+def run_stack(mods, x, segments=None):
+    """A list of nn.Linear / nn.ReLU / nn.BatchNorm1d modules in the order the reference stacks them, on the HIP kernels.
+    `segments`: x stacks the rows of several calls of the module (row offsets): every BatchNorm keeps per-call statistics."""
     x = _f32_dev(x)
     if x.dim() != 2:
         raise ValueError("NPR decoder: expected rows [n, c]")
@@ -163,7 +228,7 @@ def run_stack(mods, x):
             x = linear_relu(x, m, relu)
             i += 2 if relu else 1
         elif isinstance(m, nn.BatchNorm1d):
-            x = batch_norm_rows(x, m)
+            x = batch_norm_rows(x, m, segments)
             i += 1
         elif isinstance(m, nn.ReLU):
             x = torch.relu(x)

@@ -839,6 +839,27 @@ def bn_train_bwd(z, y, dy, mean, rstd, gamma, relu, want_dres, segments=None):
     return dz, dres, dgb[0], dgb[1]
 
 
+class BnTrainFunction(torch.autograd.Function):
+    """Training-mode BatchNorm1d on rows (apr_bn_train_fwd / _bwd), optionally per row SEGMENT: the rows of several module
+    calls stacked into one (each call's own statistics; running statistics updated call after call).  The NPR decoder's
+    norms when its per-cloud calls (FCGF_APR/lib/complement_trainer.py:424-431) ride in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, segments):
+        x = x.contiguous()
+        y, mean, rstd = bn_train_fwd(x, bn, segments=segments)
+        ctx.save_for_backward(x, mean, rstd, weight)
+        ctx.segs = segments
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, weight = ctx.saved_tensors
+        dz, _, dg, db = bn_train_bwd(x, None, dy.contiguous(), mean, rstd, weight.detach() if weight is not None else None, False,
+                                     False, segments=ctx.segs)
+        return dz, (dg.reshape(weight.shape) if weight is not None else None), db, None, None
+
+
 class ConvBnActFunction(torch.autograd.Function):
     """One unit of a training encode -- sparse convolution -> training-mode BatchNorm -> (+ residual) -> ReLU
     (FCGF_APR/model/resunet.py:142-193, model/residual_block.py:37-53 under lib/complement_trainer.py:350-512) -- as ONE

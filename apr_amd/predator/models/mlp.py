@@ -27,8 +27,8 @@ class GenerativeMLP(nn.Module):
                           nn.BatchNorm1d(channels[i + 1], momentum=bn_momentum))
             for i in range(len(channels) - 1))
 
-    def forward(self, x):
-        x = npr.run_stack([m for block in self.list_modules for m in block], x)
+    def forward(self, x, segments=None):
+        x = npr.run_stack([m for block in self.list_modules for m in block], x, segments)
         if self.radius is None:
             return x
         return x, self.radius

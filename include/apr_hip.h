@@ -889,6 +889,15 @@ int apr_chamfer_sum(const float* a, int64_t n, const float* b, int64_t m, double
 size_t apr_nn3_scratch_bytes(int64_t n, int64_t m);
 int apr_nn3(const float* a, int64_t n, const float* b, int64_t m, float cell, uint64_t* out_packed, double* sum_dev,
             void* scratch, size_t scratch_bytes, void* stream);
+/* nb independent searches in ONE call (the clouds of a training batch: FCGF_APR/lib/complement_trainer.py:424-449 runs the
+ * Chamfer term cloud by cloud): rows a_offsets_host[s] .. [s + 1] of a are searched among rows b_offsets_host[s] .. [s + 1] of
+ * b only (the grid's cells carry the cloud index).  out_packed[i] = (bits(d^2) << 32) | j with j the GLOBAL row of b;
+ * sums_dev[nb]: per-cloud sums of the minima (fixed order), multiplied by sum_scale_host[s] when that is given (1 / rows: the
+ * mean the Chamfer term divides by, without a host->device copy).  Same bits per cloud as apr_nn3 on that cloud alone.
+ * scratch: apr_nn3_scratch_bytes(total rows of a, total rows of b); cell > 0. */
+int apr_nn3_batch(const float* a, const int64_t* a_offsets_host, const float* b, const int64_t* b_offsets_host, int32_t nb,
+                  float cell, uint64_t* out_packed, double* sums_dev, const double* sum_scale_host, void* scratch,
+                  size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -140,3 +140,39 @@ def test_grid_nn3_is_bit_identical_to_brute_force(dev):
     assert torch.equal(i2, i3) and torch.equal(d2, d3)
     i4, _, _ = npr.nn3(A[:100], B[:1])
     assert int(i4.max()) == 0
+
+
+def test_batched_chamfer_equals_cloud_by_cloud(dev):
+    """npr.chamfer_distance_batch (apr_nn3_batch: the clouds of a batch in two searches) against chamfer_distance per cloud:
+    the same values (same bits per cloud from the searches), the same gradients; clouds of very different sizes and one far
+    away from its partner (the full-search fall-through inside a batch)."""
+    from apr_amd import npr
+    rng = np.random.default_rng(33)
+    sizes = [(3000, 4000), (50, 7000), (6000, 300), (2500, 2500)]
+    As, Bs = [], []
+    for k, (n, m) in enumerate(sizes):
+        b = rng.uniform(-30, 30, (m, 3)).astype(np.float32)
+        b[:, 2] *= 0.05
+        a = b[rng.integers(0, m, n)] + rng.normal(0, 0.3, (n, 3)).astype(np.float32)
+        if k == 1:
+            a += np.array([0, 0, 40], np.float32)              # every query tens of metres from its cloud
+        As.append(torch.from_numpy(a).to(dev))
+        Bs.append(torch.from_numpy(b).to(dev))
+    ao = np.concatenate([[0], np.cumsum([len(a) for a in As])]).tolist()
+    bo = np.concatenate([[0], np.cumsum([len(b) for b in Bs])]).tolist()
+    A = torch.cat(As).requires_grad_(True)
+    B = torch.cat(Bs).requires_grad_(True)
+    vals = npr.chamfer_distance_batch(A, ao, B, bo)
+    w = torch.tensor([1.0, 0.5, 2.0, -1.0], device=dev)
+    (vals * w).sum().backward()
+    for k in range(4):
+        a = As[k].clone().requires_grad_(True)
+        b = Bs[k].clone().requires_grad_(True)
+        v = npr.chamfer_distance(a, b)
+        (v * w[k]).backward()
+        assert abs(float(v) - float(vals[k])) <= 1e-6 * abs(float(v)), k
+        assert torch.allclose(A.grad[ao[k]:ao[k + 1]], a.grad, rtol=1e-5, atol=1e-7), k
+        assert torch.allclose(B.grad[bo[k]:bo[k + 1]], b.grad, rtol=1e-5, atol=1e-7), k
+        i1, d1, _ = npr.nn3(As[k], Bs[k])
+        ib, db, _ = npr.nn3_batch(torch.cat(As), ao, torch.cat(Bs), bo)
+        assert torch.equal(ib[ao[k]:ao[k + 1]] - bo[k], i1) and torch.equal(db[ao[k]:ao[k + 1]], d1), k
