@@ -97,6 +97,7 @@ PROTOTYPES = {
     "apr_device_count": (C.c_int, []),
     "apr_struct_sizes": (_i32, [_p, _i32]),
     "apr_ransac_set_screen": (C.c_int, [_i32]),
+    "apr_ransac_set_option": (C.c_int, [_i32, _i32]),
     "apr_ransac_sampling_launches": (C.c_int, [_p]),
     "apr_event_wait": (C.c_int, [_p, _i32]),
     "apr_event_wait_timeout": (C.c_int, [_p, _i32, _i64]),

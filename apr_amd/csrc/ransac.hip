@@ -1395,9 +1395,22 @@ static void launch_pack(const RansacScratch& r, const float* xyz0, const float* 
 // Which sampling kernel: k_sample_screen (default) takes the first edge out of a 112 KB table in LDS; it owns a CU's whole
 // LDS while it runs.  Whether that costs a pipelined caller more than it saves could not be settled on this repo's
 // benchmark (three same-box A/Bs: +0.8 %, -5 %, 0 %; with true matches in the set the screen is 6 % ahead), so the choice
-// is the caller's: apr_ransac_set_screen; -1 = APR_RANSAC_SCREEN from the environment (default 1, read per call: the A/B
+// is the caller's: apr_ransac_set_screen; -1 = APR_RANSAC_SCREEN from the environment (default 1, read once: the A/B
 // and test hook).
 static std::atomic<int> g_ransac_screen{-1};
+
+// A/B and test switches: set through apr_ransac_set_option (an atomic each), defaults from the environment read ONCE per
+// process (round-4 advice: a getenv on every call from threads that run without the interpreter lock races with any
+// setenv / putenv of the host application, and Python's os.environ assignments are putenv calls)
+enum { kOptScreen = 0, kOptCount = 1, kOptPrune = 2, kOptForceRounds = 3, kOptN = 4 };
+static std::atomic<int> g_ransac_opt[kOptN] = {{-1}, {-1}, {-1}, {-1}};
+static int ransac_opt(int which) {
+  const int v = g_ransac_opt[which].load(std::memory_order_relaxed);
+  if (v >= 0) return v;
+  static const int s_env[kOptN] = {env_int("APR_RANSAC_SCREEN", 1), env_int("APR_RANSAC_COUNT", 1),
+                                   env_int("APR_RANSAC_PRUNE", 1), env_int("APR_RANSAC_FORCE_ROUNDS", 0)};
+  return s_env[which];
+}
 
 // k_sample_screen's dynamic LDS (up to 160 KB) needs the per-device opt-in, once, under a lock (several host threads call in)
 static bool screen_ready() {
@@ -1417,10 +1430,10 @@ static bool screen_ready() {
 // inlier counts + squared errors of the hypothesis list, then the running best (see the comment above k_count)
 static void launch_scoring(const RansacScratch& r, int64_t n0, double thr_lt, int cap, hipStream_t st) {
   const int nwords = band_words(n0), nmini = (int)(rec2_rows(n0) / kMini);
-  // up to `few` survivors everything is scored in fp64 (APR_RANSAC_COUNT=0, read per call: always -- the A/B and test hook)
-  const int few = env_int("APR_RANSAC_COUNT", 1) ? kGeoGrid : 0x7fffffff;
+  // up to `few` survivors everything is scored in fp64 (option "count" = 0: always -- the A/B and test hook)
+  const int few = ransac_opt(kOptCount) ? kGeoGrid : 0x7fffffff;
   // the survivors sorted into NEAR the first one (counted over the correspondences within reach of it) and FAR (over all)
-  const int prune = env_int("APR_RANSAC_PRUNE", 1);      // read per call: A/B and test hook
+  const int prune = ransac_opt(kOptPrune);               // A/B and test hook (apr_ransac_set_option)
   const double m_up = sqrt(thr_lt) * (1.0 + 1e-12);
   const int n_live_blocks = (int)cdiv64(n0, 256);
   hipLaunchKernelGGL(k_prune, dim3((unsigned)(n_live_blocks + 512)), dim3(256), 0, st, r.rec, n0, m_up, r.hyps, r.n_valid, cap, few,
@@ -1452,10 +1465,10 @@ static void launch_hypotheses(const RansacScratch& r, int64_t n0, double max_dis
   int sub_cap = (int)(cdiv64(nwg, kCandLists) * 256);
   if (!counters_cleared) (void)hipMemsetAsync(r.n_valid, 0, (size_t)counter_words(r) * 4, st);
   // many iterations over a table that fits the LDS: the first edge is screened there (k_sample_screen; same candidates).
-  // APR_RANSAC_SCREEN=0 (read per call: the A/B and test hook) keeps the plain kernel.
+  // APR_RANSAC_SCREEN=0 / apr_ransac_set_screen(0) keeps the plain kernel.
   const int64_t niter = it1 - it0;
   const int screen_set = g_ransac_screen.load(std::memory_order_relaxed);
-  const int want_screen = screen_set >= 0 ? screen_set : env_int("APR_RANSAC_SCREEN", 1);
+  const int want_screen = screen_set >= 0 ? screen_set : ransac_opt(kOptScreen);
   const bool screened = niter >= 64 * kScreenRound && n0 <= kScreenMaxN0 && want_screen && screen_ready();
   g_sampling_launches[screened ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
   if (screened) {
@@ -1598,7 +1611,7 @@ APR_API int apr_ransac_pose(const float* xyz0, int64_t n0, const float* xyz1, in
   // Fast path: ALL iterations in one round.  The hypothesis list holds kChunk entries; only if more than that
   // survive both checkers (near-perfect correspondences) the rounds are replayed kChunk iterations at a time,
   // where the list cannot overflow.  total_valid tells which case it was.
-  const int s_force_rounds = env_int("APR_RANSAC_FORCE_ROUNDS", 0);   // test hook (read per call): skip the fast path
+  const int s_force_rounds = ransac_opt(kOptForceRounds);   // test hook (apr_ransac_set_option): skip the fast path
   bool packed_fresh = true;      // the pruned list of the count path must start out as all padding for EVERY scoring round
   for (int pass = s_force_rounds ? 1 : 0; pass < 2; ++pass) {
     const int64_t step = pass == 0 ? max_iter : cap;
@@ -1725,6 +1738,16 @@ APR_API int apr_ransac_set_screen(int32_t mode) {
 // The sampling kernel that actually RAN: launch counts since load, out[0] = k_sample_check, out[1] = k_sample_screen (the
 // library falls back to the former when the table does not fit the LDS, the call has few iterations, or the 160 KB opt-in
 // failed -- whatever apr_ransac_set_screen / APR_RANSAC_SCREEN asked for).
+// option: 0 = screen (as apr_ransac_set_screen), 1 = count (0: score every survivor in fp64), 2 = prune (0: count over all
+// correspondences), 3 = force_rounds (1: skip the single-round fast path).  value -1: back to the environment's default
+// (APR_RANSAC_SCREEN / _COUNT / _PRUNE / _FORCE_ROUNDS, read once per process).  Same results whatever the settings.
+APR_API int apr_ransac_set_option(int32_t option, int32_t value) {
+  APR_CHECK_ARG(option >= 0 && option < kOptN && value >= -1 && value <= 1, "apr_ransac_set_option: option 0 .. 3, value -1, 0 or 1");
+  if (option == kOptScreen) g_ransac_screen.store(value, std::memory_order_relaxed);
+  g_ransac_opt[option].store(value, std::memory_order_relaxed);
+  return APR_OK;
+}
+
 APR_API int apr_ransac_sampling_launches(int64_t* out2) {
   APR_CHECK_ARG(out2 != nullptr, "apr_ransac_sampling_launches: NULL output");
   out2[0] = g_sampling_launches[0].load(std::memory_order_relaxed);

@@ -1341,6 +1341,30 @@ def set_ransac_screen(mode):
     check(_lib_().apr_ransac_set_screen(-1 if mode is None else int(bool(mode))))
 
 
+_RANSAC_OPTIONS = {"screen": 0, "count": 1, "prune": 2, "force_rounds": 3}
+
+
+def set_ransac_option(name, value):
+    """A/B / test switch of the matcher (apr_ransac_set_option): name in screen / count / prune / force_rounds, value 0, 1 or
+    None (= the environment's default, which the library reads once per process).  Results never depend on them."""
+    check(_lib_().apr_ransac_set_option(_RANSAC_OPTIONS[name], -1 if value is None else int(bool(value))))
+
+
+class ransac_options:
+    """with ops.ransac_options(count=0, prune=0): ... -- set, then restore the defaults."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_ransac_option(k, v)
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_ransac_option(k, None)
+
+
 def ransac_sampling_launches():
     """(k_sample_check launches, k_sample_screen launches) since the library was loaded."""
     out = (C.c_int64 * 2)()

@@ -584,6 +584,11 @@ int apr_ransac_set_screen(int32_t mode);
  * k_sample_screen.  The library silently takes the former when the correspondence table does not fit the LDS, a call has
  * fewer than 2^17 iterations or the 160 KB LDS opt-in failed: a measurement reports the difference of two readings, not
  * the switch it asked for (bench.py `config.ransac_sampling_kernel`). */
+int apr_ransac_set_option(int32_t option, int32_t value);
+/* ^ A/B and test switches of the matcher without touching the environment (the library reads APR_RANSAC_* once per process;
+ * a getenv per call from GIL-free threads would race with the host application's setenv): option 0 screen, 1 count (0 = every
+ * survivor scored in fp64), 2 prune (0 = counts over all correspondences), 3 force_rounds (1 = no single-round fast path);
+ * value -1 restores the environment's default.  Results do not depend on any of them. */
 int apr_ransac_sampling_launches(int64_t* out2);
 
 /* Deal the pairs of a batch over `lanes` streams (1 .. 4): lane 0 is the caller's stream, the others are library-owned

@@ -164,8 +164,8 @@ def test_ransac_single_round_and_chunked_rounds_agree(dev, monkeypatch):
     xyz0, xyz1, F0, F1, _ = _synthetic_pair(3, n=4000, inlier=0.3)
     args = dict(ransac_n=4, edge_length=0.9, max_iteration=2500000, seed=9, return_info=True)
     T_a, info_a = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, **args)
-    monkeypatch.setenv("APR_RANSAC_FORCE_ROUNDS", "1")
-    T_b, info_b = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, **args)
+    with ops.ransac_options(force_rounds=1):       # the library reads APR_RANSAC_* once per process: switches go through the API
+        T_b, info_b = registration.ransac_feature_matching(xyz0, xyz1, F0, F1, 0.3, **args)
     assert info_a == info_b and np.array_equal(T_a, T_b)
 
 
@@ -367,11 +367,8 @@ def test_many_survivors_count_path_equals_full_fp64_scoring(dev, share, iters):
                                                    dim=1)
     res = {}
     for mode in ("1", "0"):
-        os.environ["APR_RANSAC_COUNT"] = mode
-        try:
+        with ops.ransac_options(count=int(mode)):
             (T, info), = ops.match_pose_batch([F0], [F1], [pts0], [pts1], 0.3, 0.9, iters, seeds=[7])
-        finally:
-            os.environ.pop("APR_RANSAC_COUNT", None)
         res[mode] = (T, info)
     (T1, i1), (T0, i0) = res["1"], res["0"]
     assert i1["n_valid"] == i0["n_valid"] > 2048
@@ -400,12 +397,9 @@ def test_count_path_edge_cases_equal_full_fp64_scoring(dev, n, scale, noise):
     thr = 0.3 * scale
     res = {}
     for mode in ("1", "0"):
-        os.environ["APR_RANSAC_COUNT"] = mode
-        try:
+        with ops.ransac_options(count=int(mode)):
             res[mode] = ops.ransac_pose(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev),
                                         torch.from_numpy(corr).to(dev), thr, 0.9, 60000, 3)
-        finally:
-            os.environ.pop("APR_RANSAC_COUNT", None)
     (T1, i1), (T0, i0) = res["1"], res["0"]
     assert i1["n_valid"] == i0["n_valid"] > 2048, i1
     assert i1["inliers"] == i0["inliers"] and i1["rmse"] == i0["rmse"] and i1["best_iteration"] == i0["best_iteration"]
@@ -436,12 +430,9 @@ def test_count_path_pruning_with_far_hypotheses_equals_full_scoring(dev, n, seco
     corr[bad] = rng.integers(0, n, int(bad.sum()))
     args = (torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), torch.from_numpy(corr).to(dev), 0.3, 0.9, 200000, 5)
     res = {}
-    for name, env in (("pruned", {}), ("unpruned", {"APR_RANSAC_PRUNE": "0"}), ("fp64", {"APR_RANSAC_COUNT": "0"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        res[name] = ops.ransac_pose(*args)
-        for k in env:
-            monkeypatch.delenv(k)
+    for name, opts in (("pruned", {}), ("unpruned", {"prune": 0}), ("fp64", {"count": 0})):
+        with ops.ransac_options(**opts):
+            res[name] = ops.ransac_pose(*args)
     T0, i0 = res["fp64"]
     assert i0["n_valid"] > 2048, i0
     for name in ("pruned", "unpruned"):
@@ -451,15 +442,11 @@ def test_count_path_pruning_with_far_hypotheses_equals_full_scoring(dev, n, seco
 
 
 def _screen_ab(fn):
-    """fn() under APR_RANSAC_SCREEN = 1 (LDS-screened sampling kernel, the default) and 0 (plain kernel)."""
-    import os
+    """fn() with the LDS-screened sampling kernel (the default) and with the plain kernel."""
     out = {}
     for mode in ("1", "0"):
-        os.environ["APR_RANSAC_SCREEN"] = mode
-        try:
+        with ops.ransac_options(screen=int(mode)):
             out[mode] = fn()
-        finally:
-            os.environ.pop("APR_RANSAC_SCREEN", None)
     return out["1"], out["0"]
 
 
