@@ -148,6 +148,9 @@ PROTOTYPES = {
                                    _p, _i32, _p, _sz, _p]),
     "apr_weights_flip_transpose": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_dense_gemm_bf3": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "apr_dense_rows_bf3_ok": (_i32, [_i32, _i32]),
+    "apr_dense_rows_bf3_route": (_i32, [_i64, _i32, _i32]),
+    "apr_dense_rows_bf3": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p]),
     "apr_dense_gemm_bf3_norm_scratch_bytes": (_sz, [_i64, _i32, _i32]),
     "apr_dense_gemm_bf3_norm_act": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _f32, _p, _i64, _i32, _f32, _p, _i64, _p, _i32, _p,
                                               _sz, _p]),

@@ -48,6 +48,7 @@ int apr_internal_fill(void* ptr, int32_t byte_value, size_t bytes, hipStream_t s
 
 // dense.hip: [M, cin] x [cin, cout] with the sparse conv's epilogue (identity kernel map); _ok = shape is supported
 bool apr_internal_dense_ok(int64_t M, int32_t cin, int32_t cout);
+bool apr_internal_dense_rows_route(int64_t M, int32_t cin, int32_t cout);      // dense_rows.hip
 int apr_internal_dense_gemm(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const float* wp,
                             const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
                             float* out, int64_t ldo, hipStream_t st);

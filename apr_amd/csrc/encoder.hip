@@ -207,10 +207,11 @@ struct Enc {
         d.plist_bytes = (int64_t)list->bytes;
         list->built = true;
       }
-    } else if (m < 0 && L.K == 1 && L.w_bf3 && L.cin % 64 == 0 && L.cout % 64 == 0 && ldi % 4 == 0 && ldo % 4 == 0 &&
+    } else if (m < 0 && L.K == 1 && L.w_bf3 && ((L.cin % 64 == 0 && L.cout % 64 == 0) || apr_dense_rows_bf3_ok(L.cin, L.cout)) &&
+               ldi % 4 == 0 && ldo % 4 == 0 &&
                (dry || (((uintptr_t)in | (uintptr_t)out) % 16 == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
                         (!L.scale || (uintptr_t)L.scale % 16 == 0) && (!L.shift || (uintptr_t)L.shift % 16 == 0)))) {
-      d.w_bf3 = L.w_bf3;          // identity map, 64-multiple widths: the dense GEMM on the bf16 split
+      d.w_bf3 = L.w_bf3;          // identity map: the dense GEMMs on the bf16 split (dense.hip / dense_rows.hip)
     }
     if (!dry) descs[ndesc++] = d;
   }

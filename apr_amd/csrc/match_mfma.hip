@@ -144,7 +144,10 @@ __global__ void k_nn_prep2(const float* __restrict__ f0, int64_t n0, const float
 // Workgroup = 4 waves x 64 queries; a wave holds its 4 query tiles (16 rows each, hi + lo) as MFMA A operands in
 // registers.  Targets stream through LDS in chunks of 64 rows (hi, lo, meta), double buffered: the next chunk's
 // global loads are in flight while the current one feeds the MFMAs, one barrier per chunk; B fragments are
-// conflict-free ds_read_b128 (16 rows x 64 B contiguous per k-slice).
+// conflict-free ds_read_b128: the stage is laid out k-slice major, [k-slice][row 64][quad 4][16 B], so the 16 rows of a
+// fragment are 16 x 64 B contiguous for every C (row-major [row][C] puts them C * 2 bytes apart: at C = 128 all 16 rows
+// of a quad fall on the same banks, a 16-way conflict on every read -- APR's 128-d features ran the refine pass at a
+// fifth of the rate of the 32-d ones per FLOP).
 // Candidates: per-lane 16-bit masks, ranked by a DPP wave prefix sum into a wave-private LDS buffer (4-byte
 // entries), flushed with coalesced stores into the wave's OWN region of the global list (kCandWave slots) — no
 // global atomics at all (4000 waves bumping one counter at the end of the kernel cost ~15 us); the wave's count is
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
                                                  unsigned char* __restrict__ dense_flag, int dense_min) {
   // eps(i,j) <= kEpsRel |a_i| max_j|b_j| + s_i + s_j (max over THIS workgroup's target chunk) keeps the bound rigorous
   // and makes its |a||b| part a per-query constant, so the per-element epilogue is one min / one compare
-  constexpr int KS = C / 32, QT = 4, TR = 64;          // TR target rows per LDS stage
+  constexpr int KS = C / 32, QT = 4, TR = C >= 128 ? 32 : 64;   // TR target rows per LDS stage (wide rows: half the stage, two workgroups per CU)
   constexpr int LPT = (TR * C * 2) / 16 / 256;         // 16-B loads per thread per array and stage (C=32: 1)
   __shared__ __attribute__((aligned(16))) unsigned short s_h[2][TR * C];
   __shared__ __attribute__((aligned(16))) unsigned short s_l[2][TR * C];
@@ -271,8 +274,10 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
       const int e = u * 256 + tid;
-      *reinterpret_cast<uint4*>(&s_h[buf][e * 8]) = rh[u];
-      *reinterpret_cast<uint4*>(&s_l[buf][e * 8]) = rl[u];
+      const int row = (e * 8) / C, kc = ((e * 8) % C) / 8;      // 16-B piece kc of the row: k-slice kc >> 2, quad kc & 3
+      const int at = (((kc >> 2) * TR + row) * 4 + (kc & 3)) * 8;
+      *reinterpret_cast<uint4*>(&s_h[buf][at]) = rh[u];
+      *reinterpret_cast<uint4*>(&s_l[buf][at]) = rl[u];
     }
     if (tid < TR) s_m[buf][tid] = rm;
   };
@@ -297,8 +302,8 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
         bf16x8 b[KS], bl[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          b[ks] = *reinterpret_cast<const bf16x8*>(&s_h[buf][(tt * 16 + l16) * C + ks * 32 + lq * 8]);
-          bl[ks] = *reinterpret_cast<const bf16x8*>(&s_l[buf][(tt * 16 + l16) * C + ks * 32 + lq * 8]);
+          b[ks] = *reinterpret_cast<const bf16x8*>(&s_h[buf][((ks * TR + tt * 16 + l16) * 4 + lq) * 8]);
+          bl[ks] = *reinterpret_cast<const bf16x8*>(&s_l[buf][((ks * TR + tt * 16 + l16) * 4 + lq) * 8]);
         }
         const f32x4 tm = s_m[buf][tt * 16 + l16];
         // C operand = |b_j|^2 (+ s_j for the bound, - s_j for the refine test), the same for the lane's 4 rows; the
@@ -560,10 +565,13 @@ int64_t shared_capacity(int64_t n0) {   // shared overflow list: 64 candidates p
   return c < (1ll << 31) ? c : (1ll << 31) - 1;
 }
 
-// refine grid: query blocks of 256 x target chunks (multiples of 64 rows) so that ~768 workgroups exist
-void nn_grid(int64_t n0, int64_t n1, int64_t* qblocks, int64_t* chunk, int64_t* nchunk) {
+// refine grid: query blocks of 256 x target chunks (multiples of 64 rows) so that about one resident round of workgroups
+// exists: 768 at C = 32 (three workgroups per CU), 512 at C = 64 / 128 (two per CU: 176 / 244 registers) -- a workgroup
+// reloads its 256 queries' fragments (C x 1 KB) per chunk, so at C = 128 fewer, longer chunks also halve that traffic
+void nn_grid(int64_t n0, int64_t n1, int feat_c, int64_t* qblocks, int64_t* chunk, int64_t* nchunk) {
+  static const int s_wgs = env_int("APR_NN_GRID_WGS", 0);      // A/B switch: resident-round size whatever C is
   *qblocks = cdiv64(n0, 256);
-  const int64_t want = cdiv64(768, *qblocks);
+  const int64_t want = cdiv64(s_wgs > 0 ? (s_wgs > 768 ? 768 : s_wgs) : (feat_c >= 64 ? 512 : 768), *qblocks);
   int64_t c = cdiv64(cdiv64(n1, want), 64) * 64;
   if (c < 256) c = 256;
   if (c >= (1 << 24)) c = (1 << 24) - 64;
@@ -581,7 +589,7 @@ template <int C>
 int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best, char* p,
              hipStream_t st) {
   int64_t qblocks, chunk, nchunk;
-  nn_grid(n0, n1, &qblocks, &chunk, &nchunk);
+  nn_grid(n0, n1, C, &qblocks, &chunk, &nchunk);
   const int64_t nwaves = qblocks * nchunk * 4;
   unsigned short* qb = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);
   unsigned short* ql = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);

@@ -709,7 +709,7 @@ static int spconv_fwd_plain(const float* in, int64_t ldi, const int32_t* nbr, in
 
 static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e0, hipEvent_t e1) {
   hipStream_t st = (hipStream_t)stream;
-  bool dense_bf3 = false;
+  bool dense_bf3 = false, rows_bf3 = false;
   if (d.os_pairs && d.w_bf3) {   // output-stationary path (spconv_os.hip): tile lists built on first use of the map
     if (d.os_build_bytes > 0) {
       int rcb = apr_spconv_os_pairs_build(d.nbr, d.n_out, d.os_n_in, d.K, (int32_t)d.os_rows, d.os_pairs,
@@ -738,6 +738,14 @@ static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e
     int rcw = apr_spconv_ws_fwd_bf3(d.in, d.ldi, d.counters, d.plist, d.n_out, d.K, d.cin, d.cout, d.w_packed, d.w_bf3,
                                     d.scale, d.shift, d.residual, d.ldr, d.relu, d.out, d.ldo, d.prod_scratch, stream);
     if (rcw != APR_OK) return rcw;
+  } else if (!d.nbr && d.K == 1 && d.w_bf3 && apr_internal_dense_rows_route(d.n_out, d.cin, d.cout)) {
+    // K = 1 layer with few input channels over many rows (conv1_tr / final on the finest level, resunet.py:126-140): the
+    // weight-resident row stream (dense_rows.hip), the row normalisation in its epilogue
+    rows_bf3 = true;
+    if (e0) APR_HIP(hipEventRecord(e0, st));
+    int rcd = apr_dense_rows_bf3(d.in, d.ldi, d.n_out, d.cin, d.cout, d.w_bf3, d.scale, d.shift, d.residual, d.ldr, d.relu,
+                                 d.l2norm, d.out, d.ldo, stream);
+    if (rcd != APR_OK) return rcd;
   } else if (!d.nbr && d.K == 1 && d.w_bf3 && d.cin % 64 == 0 && d.cout % 64 == 0 && d.n_out > 0) {
     // K = 1 layer with 64-multiple widths and split weights (the wide variants' conv1_tr / final, resunet.py:224-251): the
     // dense GEMM on the bf16 split (dense.hip), 1.5-1.7x the exact-fp32 MFMA kernel
@@ -752,7 +760,7 @@ static int spconv_batch_one(const apr_spconv_desc& d, void* stream, hipEvent_t e
                              d.ldr, d.relu, d.out, d.ldo, stream, d.l2norm);
     if (rc != APR_OK) return rc;
   }
-  if (d.l2norm && (d.plist || (d.os_pairs && d.w_bf3) || dense_bf3) && d.n_out > 0) {   // other conv families: a second launch
+  if (d.l2norm && !rows_bf3 && (d.plist || (d.os_pairs && d.w_bf3) || dense_bf3) && d.n_out > 0) {   // other conv families: a second launch
     int rcn = apr_l2_normalize(d.out, d.ldo, d.n_out, d.cout, d.out, d.ldo, stream);
     if (rcn != APR_OK) return rcn;
   }

@@ -303,7 +303,7 @@ __global__ void k_pack_weights_bf3(const float* __restrict__ w, int K, int cin, 
   const int qs = (col & 8) ? (q ^ 3) : q;
   const int nstep = cin >> 5;
   const int64_t slice = (int64_t)3 * nstep * 64 * 32;                  // bf16 elements of one (k, column block)
-  const int64_t base = ((int64_t)k * (cout >> 6) + cbk) * slice + ((int64_t)s * 64 + col) * 32 + qs * 8 + e;
+  const int64_t base = ((int64_t)k * ((cout + 63) >> 6) + cbk) * slice + ((int64_t)s * 64 + col) * 32 + qs * 8 + e;
   const int64_t plane = (int64_t)nstep * 64 * 32;
   wp3[base] = h;
   wp3[base + plane] = m;
@@ -767,14 +767,24 @@ __global__ __launch_bounds__(256) void k_ws_reduce(const float* __restrict__ pro
 
 }  // namespace
 
+// K = 1 (dense layers, dense.hip / dense_rows.hip) also takes cin % 32 == 0 and cout % 16 == 0: the image is laid out per
+// 32-channel step and 64-column block, the columns past cout are zeros.
+static bool bf3_shape_ok(int32_t K, int32_t cin, int32_t cout) {
+  if (K < 1 || cin < 32 || cout < 16) return false;
+  if (K == 1) return cin % 32 == 0 && cout % 16 == 0;
+  return cin % 64 == 0 && cout % 64 == 0;
+}
+
 APR_API int64_t apr_spconv_packed_bf3_bytes(int32_t K, int32_t cin, int32_t cout) {
-  return (K >= 1 && cin % 64 == 0 && cout % 64 == 0) ? (int64_t)K * cin * cout * 6 : 0;
+  return bf3_shape_ok(K, cin, cout) ? (int64_t)K * cin * ((cout + 63) / 64 * 64) * 6 : 0;
 }
 
 APR_API int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream) {
-  APR_CHECK_ARG(w && w_bf3 && K >= 1 && cin % 64 == 0 && cin >= 64 && cout % 64 == 0 && cout >= 64,
-                "apr_spconv_pack_weights_bf3: needs cin %% 64 == 0 and cout %% 64 == 0");
+  APR_CHECK_ARG(w && w_bf3 && bf3_shape_ok(K, cin, cout),
+                "apr_spconv_pack_weights_bf3: needs cin %% 64 == 0 and cout %% 64 == 0 (K = 1: cin %% 32 == 0, cout %% 16 == 0)");
   const int64_t total = (int64_t)K * cin * cout;
+  if (cout % 64 != 0)
+    APR_HIP(hipMemsetAsync(w_bf3, 0, (size_t)apr_spconv_packed_bf3_bytes(K, cin, cout), (hipStream_t)stream));
   hipLaunchKernelGGL(k_pack_weights_bf3, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin,
                      cout, (__bf16*)w_bf3);
   APR_LAUNCH_CHECK();

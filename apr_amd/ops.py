@@ -449,15 +449,18 @@ def pack_weights(w: torch.Tensor) -> torch.Tensor:
 
 def pack_weights_bf3(w: torch.Tensor):
     """[K,cin,cout] fp32 kernel -> the 3-way bf16 split image of apr_spconv_ws_fwd_bf3 (uint8 blob), or None when the
-    shape is not covered (sparse kernels: cin not in 64/128/192/256/384; the dense K = 1 form takes any cin % 64 == 0;
-    cout % 64 != 0)."""
+    shape is not covered (sparse kernels: cin not in 64/128/192/256/384 or cout % 64 != 0; the dense K = 1 forms take any
+    64-multiples, and cin 64..192 step 32 with cout 32 / 64 / 128)."""
     w = _f32(w.detach(), "pack_weights_bf3.w")
     if w.dim() != 3:
         return None
     K, cin, cout = w.shape
-    if (cin not in (64, 128, 192, 256, 384) and not (K == 1 and cin % 64 == 0 and cin >= 64)) or cout % 64 != 0 or cout < 64:
-        return None
     lib = _lib_()
+    if K == 1:      # dense layers: 64-multiples (apr_dense_gemm_bf3) or the row-stream kernel's shapes (apr_dense_rows_bf3)
+        if not ((cin % 64 == 0 and cin >= 64 and cout % 64 == 0 and cout >= 64) or lib.apr_dense_rows_bf3_ok(cin, cout)):
+            return None
+    elif cin not in (64, 128, 192, 256, 384) or cout % 64 != 0 or cout < 64:
+        return None
     blob = torch.empty(int(lib.apr_spconv_packed_bf3_bytes(K, cin, cout)), dtype=torch.uint8, device=w.device)
     check(lib.apr_spconv_pack_weights_bf3(ptr(w.contiguous()), K, cin, cout, ptr(blob), stream()))
     return blob
@@ -683,14 +686,21 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         residual, ldr = _rows(residual, "spconv.residual")
         if residual.shape[0] != n_out or residual.shape[1] != cout:
             raise _lib.AprHipError("spconv: residual shape mismatch")
-    if (nbr is None and K == 1 and w_bf3 is not None and PROFILE is None and cin % 64 == 0 and cout % 64 == 0 and ldi % 4 == 0
+    if (nbr is None and K == 1 and w_bf3 is not None and PROFILE is None and n_out > 0 and ldi % 4 == 0
             and ldo % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
             and (residual is None or (ldr % 4 == 0 and residual.data_ptr() % 16 == 0))
             and (scale is None or scale.data_ptr() % 16 == 0) and (shift is None or shift.data_ptr() % 16 == 0)):
-        # identity map, 64-multiple widths: the dense GEMM on the bf16 split (what a batched launch picks as well)
-        check(_lib_().apr_dense_gemm_bf3(ptr(x), ldi, n_out, cin, cout, ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr,
+        # identity map: the dense GEMMs on the bf16 split (what a batched launch picks as well) -- few input channels over
+        # many rows stream past LDS-resident weights, the other 64-multiple widths take the tiled kernel
+        lib = _lib_()
+        if lib.apr_dense_rows_bf3_route(n_out, cin, cout):
+            check(lib.apr_dense_rows_bf3(ptr(x), ldi, n_out, cin, cout, ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr,
+                                         int(bool(relu)), 0, ptr(out), ldo, stream()))
+            return out
+        if cin % 64 == 0 and cout % 64 == 0:
+            check(lib.apr_dense_gemm_bf3(ptr(x), ldi, n_out, cin, cout, ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr,
                                          int(bool(relu)), ptr(out), ldo, stream()))
-        return out
+            return out
     use_ws = plist is not None and nbr is not None and ws_supported(K, cin, cout)
     use_ws3 = use_ws and isinstance(plist, PairList3)
     if use_ws3 and (w_bf3 is None or not ws3_supported(K, cin, cout)):
@@ -719,6 +729,30 @@ def spconv(x, nbr, K, cin, cout, wp, scale=None, shift=None, residual=None, relu
         e1.record()
         prof.records.append((P, cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0, e0, e1,
                              "ws" if use_ws else "tile"))
+    return out
+
+
+def dense_rows_bf3(x, w_bf3, cin, cout, scale=None, shift=None, residual=None, relu=False, l2norm=False, out=None):
+    """act((x @ W) * scale + shift + residual) [then rows / |row|_2] through apr_dense_rows_bf3 (weights resident in LDS, the
+    rows streamed once): cin 64..192 step 32, cout 32 / 64 / 128; `w_bf3` from pack_weights_bf3(W[None])."""
+    x, ldi = _rows(x, "dense_rows_bf3.x")
+    if x.shape[1] != cin:
+        raise _lib.AprHipError(f"dense_rows_bf3: input has {x.shape[1]} channels, weight expects {cin}")
+    n = x.shape[0]
+    if out is None:
+        out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    out, ldo = _rows(out, "dense_rows_bf3.out")
+    if out.shape[0] != n or out.shape[1] != cout:
+        raise _lib.AprHipError("dense_rows_bf3: output shape mismatch")
+    ldr = 0
+    if residual is not None:
+        residual, ldr = _rows(residual, "dense_rows_bf3.residual")
+        if residual.shape[0] != n or residual.shape[1] != cout:
+            raise _lib.AprHipError("dense_rows_bf3: residual shape mismatch")
+    if n == 0:
+        return out
+    check(_lib_().apr_dense_rows_bf3(ptr(x), ldi, n, cin, cout, ptr(w_bf3), ptr(scale), ptr(shift), ptr(residual), ldr,
+                                     int(bool(relu)), int(bool(l2norm)), ptr(out), ldo, stream()))
     return out
 
 
@@ -1008,11 +1042,12 @@ class SpconvBatch:
             if not plist.built and not plist.queued:
                 d.plist_bytes, plist.queued = plist.blob.numel(), True
                 self.pending.append(plist)
-        elif nbr is None and K == 1 and w_bf3 is not None and cin % 64 == 0 and cout % 64 == 0 and ldi % 4 == 0 \
+        elif nbr is None and K == 1 and w_bf3 is not None and ldi % 4 == 0 \
+                and ((cin % 64 == 0 and cout % 64 == 0) or _lib_().apr_dense_rows_bf3_ok(cin, cout)) \
                 and ldo % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 \
                 and (residual is None or (ldr % 4 == 0 and residual.data_ptr() % 16 == 0)) \
                 and (scale is None or scale.data_ptr() % 16 == 0) and (shift is None or shift.data_ptr() % 16 == 0):
-            d.w_bf3 = w_bf3.data_ptr()          # identity map, 64-multiple widths: the dense GEMM on the bf16 split
+            d.w_bf3 = w_bf3.data_ptr()          # identity map: the dense GEMMs on the bf16 split (the library routes by shape)
         self.descs.append(d)
         if PROFILE is not None:
             self.meta.append((PROFILE.pairs(nbr, n_out), cin, cout, K <= 32 and cin % 32 == 0 and cout % 32 == 0,

@@ -238,7 +238,8 @@ int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, con
  * operand, 6 of the 9 cross terms: fp32-equivalent accuracy, ~2e-24 relative per product) - 2.7x fewer MFMA cycles
  * than the exact-fp32 form, which runs at 1/16 of the bf16 rate on gfx950.  w_bf3: apr_spconv_pack_weights_bf3 of the
  * layer's [K, cin, cout] kernel (apr_spconv_packed_bf3_bytes bytes; cin in {64, 128, 256}); NULL or another cin falls
- * back to w_packed / the fp32 form. */
+ * back to w_packed / the fp32 form.  Packing takes cin % 64 == 0 and cout % 64 == 0; K = 1 (the dense layers'
+ * images) also cin % 32 == 0 and cout % 16 == 0. */
 int64_t apr_spconv_packed_bf3_bytes(int32_t K, int32_t cin, int32_t cout);
 int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream);
 int apr_spconv_ws_fwd_bf3(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
@@ -687,6 +688,20 @@ int apr_knn(const float* pts, int32_t n, int32_t k, int32_t skip_first, int32_t*
 int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const void* w_bf3,
                        const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
                        float* out, int64_t ldo, void* stream);
+/* The same operator for FEW input channels over MANY rows -- the K = 1 layers at the end of the encoders
+ * (FCGF_APR/model/resunet.py:126-142: conv1_tr 96 -> 64 / 160 -> 128 and `final` 64 -> 32 / 128 -> 128 on the finest level) --
+ * as a row stream past weights that stay in LDS for the life of a workgroup: every row is read once, a wave owns whole rows,
+ * so the row normalisation of `normalize_feature` (l2norm != 0: out[j] /= |out[j]|_2, same bits as apr_l2_normalize behind
+ * the plain call) is part of the epilogue.  cin in {64, 96, 128, 160, 192}, cout in {32, 64, 128}
+ * (apr_dense_rows_bf3_ok); w_bf3 = apr_spconv_pack_weights_bf3(w, 1, cin, cout), which for K = 1 takes cin % 32 == 0 and
+ * cout % 16 == 0 (columns padded with zeros to a multiple of 64 inside the image).  Same bits as apr_dense_gemm_bf3 where
+ * both take the shape.  apr_dense_rows_bf3_route: what apr_spconv_fwd_batch / apr_resunet_encode do with a K = 1 layer of M
+ * rows -- 1: this kernel (an instantiated shape and M >= APR_DENSE_ROWS_MIN, default 32768 rows). */
+int32_t apr_dense_rows_bf3_ok(int32_t cin, int32_t cout);
+int32_t apr_dense_rows_bf3_route(int64_t M, int32_t cin, int32_t cout);
+int apr_dense_rows_bf3(const float* in, int64_t ldi, int64_t M, int32_t cin, int32_t cout, const void* w_bf3,
+                       const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,
+                       int32_t l2norm, float* out, int64_t ldo, void* stream);
 /* out = act(instance_norm(in @ W) (+ residual)) -- the Linear + InstanceNorm1d (+ shortcut) (+ LeakyReLU) every unary /
  * bottleneck layer of KPFCNN is (Predator_APR/models/blocks.py:451-468, 499-504, 653-681) -- in TWO launches: the GEMM leaves
  * the raw product in `out` and the per-tile column sums (fp64, rows in order) in scratch, the apply kernel rebuilds mean /
