@@ -158,6 +158,8 @@ __global__ void k_nn_prep2(const float* __restrict__ f0, int64_t n0, const float
 constexpr int kCandBuf = 1280;    // LDS entries per wave (flushed above 256); a 16-target tile adds <= 64 x 16 = 1024
 constexpr int kCandWave = 2048;   // global slots per wave
 constexpr int kDenseMin = 16;     // candidates in one 64 x 16 block from which the block is evaluated densely
+constexpr int kDlBuf = 64;        // dense-block ids a wave keeps in LDS before it has to flush on its own
+constexpr unsigned kDenseListCap = 1u << 20;
 
 template <int C, bool REFINE>
 __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restrict__ qb,
@@ -169,7 +171,8 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
                                                  unsigned* __restrict__ U, unsigned long long* __restrict__ cand,
                                                  unsigned* __restrict__ cand_count, unsigned* __restrict__ overflow,
                                                  unsigned long long* __restrict__ shared_list, unsigned shared_cap,
-                                                 unsigned char* __restrict__ dense_flag, int dense_min) {
+                                                 unsigned* __restrict__ dense_list, unsigned* __restrict__ dense_count,
+                                                 int dense_min) {
   // eps(i,j) <= kEpsRel |a_i| max_j|b_j| + s_i + s_j (max over THIS workgroup's target chunk) keeps the bound rigorous
   // and makes its |a||b| part a per-query constant, so the per-element epilogue is one min / one compare
   constexpr int KS = C / 32, QT = 4, TR = C >= 128 ? 32 : 64;   // TR target rows per LDS stage (wide rows: half the stage, two workgroups per CU)
@@ -178,6 +181,8 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
   __shared__ __attribute__((aligned(16))) unsigned short s_l[2][TR * C];
   __shared__ f32x4 s_m[2][TR];
   __shared__ unsigned s_cand[REFINE ? 4 * kCandBuf : 1];   // (query within the workgroup) << 24 | (target - t0)
+  __shared__ unsigned s_dl[REFINE ? 4 * kDlBuf : 1];       // ids of this workgroup's dense blocks, per wave
+  __shared__ unsigned s_dn[4], s_dbase;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lq = lane >> 4;
   const int64_t q0 = (int64_t)blockIdx.x * 256 + wave * 64;
@@ -218,6 +223,8 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
     }
   }
   int ncand = 0;                         // entries in this wave's LDS buffer (wave-uniform)
+  int ndl = 0;                           // dense-block ids in this wave's LDS buffer (wave-uniform)
+  unsigned* my_dl = s_dl + (REFINE ? wave * kDlBuf : 0);
   unsigned* my_cand = s_cand + (REFINE ? wave * kCandBuf : 0);
 
   const unsigned wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
@@ -346,7 +353,6 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (acc[qt][r] <= thr[qt][r]) cmask |= 1u << (qt * 4 + r);
-          if (lane == 0) dense_flag[(size_t)wave_id * (chunk >> 4) + ((jt - t0) >> 4) + tt] = 0;
           if (__any(cmask != 0)) {
             if (ncand > kCandBuf - 1024) flush();
             // wave prefix sum of the per-lane candidate counts -> ranks in the wave-private buffer
@@ -356,8 +362,20 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
             if (total >= dense_min) {
               // a cluster of near-identical features: listing (and atomically reducing) dozens of pairs of this
               // 64-query x 16-target block costs more than evaluating the whole block once -> k_nn_dense.
-              // One flag byte per wave-tile, no atomics (a shared counter stalled every dense tile ~1 us).
-              if (lane == 0) dense_flag[(size_t)wave_id * (chunk >> 4) + ((jt - t0) >> 4) + tt] = 1;
+              // The block's id goes to the wave's LDS buffer; the WORKGROUP appends its ids to the global list with one
+              // atomic at the end of the kernel (a counter bumped per dense tile stalled every one of them ~1 us; flag
+              // bytes + a compaction kernel were a store per tile and one more launch).
+              if (ndl == kDlBuf) {       // only with more than kDlBuf dense tiles in one wave's chunk: flush alone
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(dense_count, (unsigned)ndl);
+                base = __builtin_amdgcn_readfirstlane(base);
+                for (int e = lane; e < ndl; e += 64) {
+                  if (base + e < kDenseListCap) dense_list[base + e] = my_dl[e]; else overflow[0] = 1u;
+                }
+                ndl = 0;
+              }
+              if (lane == 0) my_dl[ndl] = wave_id * (unsigned)(chunk >> 4) + (unsigned)((jt - t0) >> 4) + tt;
+              ++ndl;
               continue;
             }
             int pos = ncand + incl - c;
@@ -378,7 +396,21 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
   }
   if (REFINE) {
     flush();
-    if (lane == 0) cand_count[wave_id] = flushed;
+    if (lane == 0) {
+      cand_count[wave_id] = flushed;
+      s_dn[wave] = (unsigned)ndl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned total = s_dn[0] + s_dn[1] + s_dn[2] + s_dn[3];
+      s_dbase = total ? atomicAdd(dense_count, total) : 0u;
+    }
+    __syncthreads();
+    unsigned base = s_dbase;
+    for (int w = 0; w < wave; ++w) base += s_dn[w];
+    for (int e = lane; e < ndl; e += 64) {
+      if (base + e < kDenseListCap) dense_list[base + e] = my_dl[e]; else overflow[0] = 1u;   // the fallback redoes the search
+    }
   }
   if (!REFINE && wave_live) {
 #pragma unroll
@@ -400,138 +432,99 @@ __global__ __launch_bounds__(256) void k_nn_mfma(const unsigned short* __restric
   }
 }
 
-// Dense blocks: the refine pass left one flag byte per wave-tile (64 queries x 16 targets).  k_nn_dense_compact turns
-// the flags into a list of block ids (16 flags per thread, wave-aggregated append: ~200 atomics in all); the waves of
-// k_nn_dense_list then take the listed blocks in turn (grid stride), so a cluster of flagged blocks is spread over the
-// whole chip instead of being walked by the one wave that owns their 64 flags.  Per block: lane = query with its row
-// in registers; the 16 target rows go through LDS ONCE (one vector load per lane instead of 16 dependent scalar
-// fetches, ~0.5 us each) and are read back as broadcasts; the oracle's direct form for all 1024 pairs, a running
-// strict-< minimum per lane (ascending j: ties keep the smaller index), ONE atomicMin per query and block.
-constexpr unsigned kDenseListCap = 1u << 20;
-
-__global__ __launch_bounds__(256) void k_nn_dense_compact(const unsigned char* __restrict__ dense_flag, int chunk,
-                                                          unsigned qwaves, unsigned nchunk, int64_t n0, int64_t n1,
-                                                          unsigned* __restrict__ list, unsigned* __restrict__ count,
-                                                          unsigned* __restrict__ overflow) {
-  const int lane = threadIdx.x & 63;
-  const unsigned tpc = (unsigned)chunk >> 4;                        // tiles per chunk (a multiple of 4: chunk % 64 == 0)
-  const unsigned nflag = qwaves * nchunk * tpc;                     // < 2^32 (checked on the host)
-  const unsigned f0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
-  unsigned mask = 0;   // bit b: flag f0 + b is set and belongs to a slot the refine pass wrote
-  if (f0 < nflag) {
-    const uint4 v = *reinterpret_cast<const uint4*>(dense_flag + f0);
-    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+// k_nn_resolve: everything behind the refine pass in ONE launch (round 5: the candidate kernel, the flag compaction, the
+// dense-block kernel and the predicated brute-force launch were four).  Roles by block index:
+//   blocks [0, nwg)            the 4 wave regions of refine workgroup b: one thread per candidate pair, the exact direct
+//                              form in the oracle's order, 64-bit atomicMin like the brute-force kernel;
+//   blocks [nwg, nexact)       the shared overflow list, the same way;
+//   blocks [nexact, gridDim)   the dense blocks (64 queries x 16 targets the refine pass listed instead of >= 16 single
+//                              pairs): the waves take the listed blocks in turn (grid stride), so a cluster of blocks is
+//                              spread over the whole chip.  Per block: lane = query with its row in registers; the 16 target
+//                              rows go through LDS ONCE (one vector load per lane instead of 16 dependent scalar fetches)
+//                              and are read back as broadcasts; the direct form for all 1024 pairs, a running strict-<
+//                              minimum per lane (ascending j: ties keep the smaller index), ONE atomicMin per query.
+// If a list overflowed (overflow[0], final when the refine pass has ended) every wave of the grid turns to the fallback
+// instead: query tile x slice of the targets through the same tile evaluator -- exact for ANY input, about twice the time
+// of the dedicated brute-force kernel, and it has never been taken on encoder features.
+template <int C>
+__device__ inline void nn_tile_eval(float* my_t, const f32x4* xv, const float* __restrict__ f1, int64_t j0, int64_t j1,
+                                    int lane, float& bd, int& bj) {
+  // targets -> LDS (rows past j1 repeat row j1 - 1: a re-read never wins the strict <)
+  constexpr int VPR = C / 4;   // 16-B vectors per row
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const unsigned f = f0 + b;
-      if (f < nflag && ((w[b >> 2] >> ((b & 3) * 8)) & 0xffu)) {
-        const unsigned wave_id = f / tpc, tile = f % tpc;
-        const int64_t q0 = (int64_t)(wave_id % qwaves) * 64;
-        const int64_t t0 = (int64_t)(wave_id / qwaves) * chunk;
-        const int64_t j0 = t0 + (int64_t)tile * 16;
-        if (q0 < n0 && j0 < min((long long)(t0 + chunk), (long long)n1)) mask |= 1u << b;
-      }
-    }
+  for (int v = lane; v < 16 * VPR; v += 64) {
+    const int r = v / VPR, g = v - r * VPR;
+    const int64_t row = (j0 + r < j1) ? j0 + r : j1 - 1;
+    *reinterpret_cast<f32x4*>(my_t + r * C + g * 4) = *reinterpret_cast<const f32x4*>(f1 + row * C + g * 4);
   }
-  const int c = __popc(mask);
-  const int incl = apr_wave_incl_scan(c);
-  const int total = __builtin_amdgcn_readlane(incl, 63);
-  if (total == 0) return;
-  unsigned base = 0;
-  if (lane == 0) base = atomicAdd(count, (unsigned)total);
-  base = __builtin_amdgcn_readfirstlane(base);
-  unsigned pos = base + (unsigned)(incl - c);
-  while (mask) {
-    const int b = __ffs((int)mask) - 1;
-    mask &= mask - 1;
-    if (pos < kDenseListCap) list[pos] = f0 + (unsigned)b; else overflow[0] = 1u;   // brute force redoes the search
-    ++pos;
+  // the wave's own LDS writes are visible to its reads in program order (one wave, LDS ops complete in order)
+#pragma unroll 2
+  for (int jj = 0; jj < 16; ++jj) {
+    // plain v_sub_f32 + (compiler-packed) fma: packed adds (y + (-x)) measured SLOWER here (23 -> 30 us), packed
+    // fp32 issues at the same lane rate and the pairing costs registers
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int g = 0; g < C / 4; ++g) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(my_t + jj * C + g * 4);   // broadcast read
+      const float d0 = xv[g][0] - yv[0], d1 = xv[g][1] - yv[1];
+      const float d2 = xv[g][2] - yv[2], d3 = xv[g][3] - yv[3];
+      s0 = fmaf(d0, d0, s0);
+      s1 = fmaf(d1, d1, s1);
+      s2 = fmaf(d2, d2, s2);
+      s3 = fmaf(d3, d3, s3);
+    }
+    const float dd = (s0 + s1) + (s2 + s3);
+    const int64_t j = (j0 + jj < j1) ? j0 + jj : j1 - 1;
+    if (dd < bd) {
+      bd = dd;
+      bj = (int)j;
+    }
   }
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_nn_dense_list(const unsigned* __restrict__ list,
-                                                       const unsigned* __restrict__ count, int chunk, unsigned qwaves,
-                                                       const float* __restrict__ f0, int64_t n0,
-                                                       const float* __restrict__ f1, int64_t n1,
-                                                       unsigned long long* __restrict__ best) {
-  __shared__ __attribute__((aligned(16))) float s_t[4][16 * C];   // per wave: the block's 16 target rows
+__global__ __launch_bounds__(256) void k_nn_resolve(const unsigned long long* __restrict__ cand,
+                                                    const unsigned* __restrict__ cand_count, unsigned nwg, unsigned nexact,
+                                                    const unsigned long long* __restrict__ shared_list,
+                                                    const unsigned* __restrict__ overflow, unsigned shared_cap,
+                                                    const unsigned* __restrict__ dense_list, int chunk, unsigned qwaves,
+                                                    const float* __restrict__ f0, int64_t n0,
+                                                    const float* __restrict__ f1, int64_t n1,
+                                                    unsigned long long* __restrict__ best) {
+  __shared__ __attribute__((aligned(16))) float s_t[4][16 * C];   // per wave: a block's 16 target rows
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* my_t = s_t[wave];
-  const unsigned tpc = (unsigned)chunk >> 4;
-  const unsigned n = min(*count, kDenseListCap);
-  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (unsigned e = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; e < n; e += nwaves) {
-    const unsigned fb = __builtin_amdgcn_readfirstlane(list[e]);
-    const unsigned wave_id = fb / tpc, tile = fb % tpc;
-    const unsigned dq = (wave_id % qwaves) * 64u;
-    const unsigned t0 = (wave_id / qwaves) * (unsigned)chunk;
-    const int64_t q = (int64_t)dq + lane;
-    const int64_t j0 = (int64_t)t0 + (int64_t)tile * 16;
-    const int64_t j1 = min(min((long long)(j0 + 16), (long long)((int64_t)t0 + chunk)), (long long)n1);
-    // targets -> LDS (rows past j1 repeat row j1 - 1: a re-read never wins the strict <)
-    constexpr int VPR = C / 4;   // 16-B vectors per row
+  if (overflow[0] != 0u) {
+    // fallback: wave = (query tile, slice of the 16-target tiles), running minimum in registers, one atomicMin per query
+    const int64_t nqt = (n0 + 63) >> 6, ntt = (n1 + 15) >> 4;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t slices = nw / nqt > 0 ? nw / nqt : 1;
+    const int64_t tps = (ntt + slices - 1) / slices;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < nqt * slices; w += nw) {
+      const int64_t q = (w % nqt) * 64 + lane;
+      const int64_t tt0 = (w / nqt) * tps, tt1 = min((long long)(tt0 + tps), (long long)ntt);
+      const float* x = f0 + (q < n0 ? q : n0 - 1) * C;
+      f32x4 xv[C / 4];
 #pragma unroll
-    for (int v = lane; v < 16 * VPR; v += 64) {
-      const int r = v / VPR, g = v - r * VPR;
-      const int64_t row = (j0 + r < j1) ? j0 + r : j1 - 1;
-      *reinterpret_cast<f32x4*>(my_t + r * C + g * 4) = *reinterpret_cast<const f32x4*>(f1 + row * C + g * 4);
-    }
-    const float* x = f0 + (q < n0 ? q : n0 - 1) * C;
-    f32x4 xv[C / 4];
-#pragma unroll
-    for (int g = 0; g < C / 4; ++g) xv[g] = *reinterpret_cast<const f32x4*>(x + g * 4);
-    float bd = __builtin_inff();
-    int bj = 0x7fffffff;
-    // the wave's own LDS writes are visible to its reads in program order (one wave, LDS ops complete in order)
-#pragma unroll 2
-    for (int jj = 0; jj < 16; ++jj) {
-      // plain v_sub_f32 + (compiler-packed) fma: packed adds (y + (-x)) measured SLOWER here (23 -> 30 us), packed
-      // fp32 issues at the same lane rate and the pairing costs registers
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-      for (int g = 0; g < C / 4; ++g) {
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(my_t + jj * C + g * 4);   // broadcast read
-        const float d0 = xv[g][0] - yv[0], d1 = xv[g][1] - yv[1];
-        const float d2 = xv[g][2] - yv[2], d3 = xv[g][3] - yv[3];
-        s0 = fmaf(d0, d0, s0);
-        s1 = fmaf(d1, d1, s1);
-        s2 = fmaf(d2, d2, s2);
-        s3 = fmaf(d3, d3, s3);
-      }
-      const float dd = (s0 + s1) + (s2 + s3);
-      const int64_t j = (j0 + jj < j1) ? j0 + jj : j1 - 1;
-      if (dd < bd) {
-        bd = dd;
-        bj = (int)j;
+      for (int g = 0; g < C / 4; ++g) xv[g] = *reinterpret_cast<const f32x4*>(x + g * 4);
+      float bd = __builtin_inff();
+      int bj = 0x7fffffff;
+      for (int64_t tt = tt0; tt < tt1; ++tt)
+        nn_tile_eval<C>(s_t[wave], xv, f1, tt * 16, min((long long)(tt * 16 + 16), (long long)n1), lane, bd, bj);
+      if (q < n0 && bj != 0x7fffffff) {
+        const unsigned long long mine = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
+        if (mine < __builtin_nontemporal_load(&best[q])) atomicMin(&best[q], mine);
       }
     }
-    if (q < n0 && bj != 0x7fffffff) {
-      const unsigned long long mine = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
-      if (mine < __builtin_nontemporal_load(&best[q])) atomicMin(&best[q], mine);
-    }
+    return;
   }
-}
-
-// One thread per candidate pair: the exact direct form in the oracle's order, 64-bit atomicMin like the brute-force
-// kernel.  Block b walks the regions of the 4 waves of refine workgroup b.
-template <int C>
-__global__ __launch_bounds__(256) void k_nn_exact(const unsigned long long* __restrict__ cand,
-                                                  const unsigned* __restrict__ cand_count, unsigned nwg,
-                                                  const unsigned long long* __restrict__ shared_list,
-                                                  const unsigned* __restrict__ overflow, unsigned shared_cap,
-                                                  const float* __restrict__ f0, const float* __restrict__ f1,
-                                                  unsigned long long* __restrict__ best) {
-  // blocks [0, nwg): the 4 wave regions of refine workgroup b, 64 threads each; blocks [nwg, gridDim.x): the shared
-  // overflow list
-  const bool shared = blockIdx.x >= nwg;
-  {
+  if (blockIdx.x < nexact) {
+    const bool shared = blockIdx.x >= nwg;
     const unsigned wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
     const unsigned n = shared ? min(overflow[1], shared_cap) : min(cand_count[wave_id], (unsigned)kCandWave);
     const unsigned long long* src = shared ? shared_list : cand + (size_t)wave_id * kCandWave;
     const unsigned first = shared ? (blockIdx.x - nwg) * 256u + threadIdx.x : (threadIdx.x & 63u);
-    const unsigned step = shared ? (gridDim.x - nwg) * 256u : 64u;
+    const unsigned step = shared ? (nexact - nwg) * 256u : 64u;
     for (unsigned t = first; t < n; t += step) {
       const unsigned long long ij = src[t];
       const int64_t i = (int64_t)(ij >> 32), j = (int64_t)(ij & 0xffffffffull);
@@ -554,6 +547,30 @@ __global__ __launch_bounds__(256) void k_nn_exact(const unsigned long long* __re
       const unsigned long long mine = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
       if (mine < __builtin_nontemporal_load(&best[i])) atomicMin(&best[i], mine);
     }
+    return;
+  }
+  const unsigned tpc = (unsigned)chunk >> 4;
+  const unsigned n = min(overflow[2], kDenseListCap);
+  const unsigned nwaves = (gridDim.x - nexact) * 4;
+  for (unsigned e = (blockIdx.x - nexact) * 4 + wave; e < n; e += nwaves) {
+    const unsigned fb = __builtin_amdgcn_readfirstlane(dense_list[e]);
+    const unsigned wave_id = fb / tpc, tile = fb % tpc;
+    const unsigned dq = (wave_id % qwaves) * 64u;
+    const unsigned t0 = (wave_id / qwaves) * (unsigned)chunk;
+    const int64_t q = (int64_t)dq + lane;
+    const int64_t j0 = (int64_t)t0 + (int64_t)tile * 16;
+    const int64_t j1 = min(min((long long)(j0 + 16), (long long)((int64_t)t0 + chunk)), (long long)n1);
+    const float* x = f0 + (q < n0 ? q : n0 - 1) * C;
+    f32x4 xv[C / 4];
+#pragma unroll
+    for (int g = 0; g < C / 4; ++g) xv[g] = *reinterpret_cast<const f32x4*>(x + g * 4);
+    float bd = __builtin_inff();
+    int bj = 0x7fffffff;
+    nn_tile_eval<C>(s_t[wave], xv, f1, j0, j1, lane, bd, bj);
+    if (q < n0 && bj != 0x7fffffff) {
+      const unsigned long long mine = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bj;
+      if (mine < __builtin_nontemporal_load(&best[q])) atomicMin(&best[q], mine);
+    }
   }
 }
 
@@ -565,13 +582,13 @@ int64_t shared_capacity(int64_t n0) {   // shared overflow list: 64 candidates p
   return c < (1ll << 31) ? c : (1ll << 31) - 1;
 }
 
-// refine grid: query blocks of 256 x target chunks (multiples of 64 rows) so that about one resident round of workgroups
-// exists: 768 at C = 32 (three workgroups per CU), 512 at C = 64 / 128 (two per CU: 176 / 244 registers) -- a workgroup
-// reloads its 256 queries' fragments (C x 1 KB) per chunk, so at C = 128 fewer, longer chunks also halve that traffic
-void nn_grid(int64_t n0, int64_t n1, int feat_c, int64_t* qblocks, int64_t* chunk, int64_t* nchunk) {
-  static const int s_wgs = env_int("APR_NN_GRID_WGS", 0);      // A/B switch: resident-round size whatever C is
+// refine grid: query blocks of 256 x target chunks (multiples of 64 rows) so that ~768 workgroups exist (three per CU at
+// C = 32; at C = 128 two are resident and a workgroup reloads its queries' fragments, C x 1 KB, per chunk -- fewer, longer
+// chunks were measured and lose all the same: 14 k x 14 k x 128 in 304 us with 768, 355 / 312 / 383 with 512 / 384 / 256)
+void nn_grid(int64_t n0, int64_t n1, int64_t* qblocks, int64_t* chunk, int64_t* nchunk) {
+  static const int s_wgs = env_int("APR_NN_GRID_WGS", 768);      // A/B switch
   *qblocks = cdiv64(n0, 256);
-  const int64_t want = cdiv64(s_wgs > 0 ? (s_wgs > 768 ? 768 : s_wgs) : (feat_c >= 64 ? 512 : 768), *qblocks);
+  const int64_t want = cdiv64(s_wgs > 0 && s_wgs < 768 ? s_wgs : 768, *qblocks);
   int64_t c = cdiv64(cdiv64(n1, want), 64) * 64;
   if (c < 256) c = 256;
   if (c >= (1 << 24)) c = (1 << 24) - 64;
@@ -589,7 +606,7 @@ template <int C>
 int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best, char* p,
              hipStream_t st) {
   int64_t qblocks, chunk, nchunk;
-  nn_grid(n0, n1, C, &qblocks, &chunk, &nchunk);
+  nn_grid(n0, n1, &qblocks, &chunk, &nchunk);
   const int64_t nwaves = qblocks * nchunk * 4;
   unsigned short* qb = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);
   unsigned short* ql = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);
@@ -602,38 +619,29 @@ int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned 
   unsigned* cand_count = (unsigned*)p;      p += al256((size_t)nwaves * 4);
   unsigned long long* cand = (unsigned long long*)p;   p += al256((size_t)nwaves * kCandWave * 8);
   unsigned long long* shared_list = (unsigned long long*)p;   p += al256((size_t)shared_capacity(n0) * 8);
-  unsigned char* dense_flag = (unsigned char*)p;              // one byte per (64 queries x 16 targets) wave-tile
+  // (the flag bytes of earlier rounds sat here; the scratch bound still counts them)
   p += al256((size_t)(qblocks * 4) * (size_t)nchunk * (size_t)(chunk / 16) + 64);
-  unsigned* dense_list = (unsigned*)p;                        // ids of the flagged blocks (k_nn_dense_compact)
+  unsigned* dense_list = (unsigned*)p;                        // ids of the dense blocks, appended by the refine pass
   const unsigned shared_cap = (unsigned)shared_capacity(n0);
   constexpr int LPR = C / 4;
+  if ((uint64_t)qblocks * 4 * (uint64_t)nchunk * (uint64_t)(chunk / 16) + 64 >= (1ull << 32)) {
+    apr_set_error("apr_feature_nn_fast: problem too large for the dense-block ids");
+    return APR_EINVAL;
+  }
   hipLaunchKernelGGL((k_nn_prep2<C>), dim3((unsigned)cdiv64((n0 + n1) * LPR, 256)), dim3(256), 0, st, f0, n0, f1, n1, qb, ql,
                      qmeta, tb, tl, tmeta, U, best, overflow);
   static const int s_dense_min = env_int("APR_NN_DENSE_MIN", kDenseMin);
   static const int s_bound_div = env_int("APR_NN_BOUND_DIV", 4);   // bound pass over 1/div of every target chunk
   const dim3 grid((unsigned)qblocks, (unsigned)nchunk);
   hipLaunchKernelGGL((k_nn_mfma<C, false>), grid, dim3(256), 0, st, qb, ql, qmeta, n0, tb, tl, tmeta, n1, (int)chunk, U,
-                     cand, cand_count, overflow, shared_list, shared_cap, dense_flag, s_bound_div);
+                     cand, cand_count, overflow, shared_list, shared_cap, dense_list, overflow + 2, s_bound_div);
   hipLaunchKernelGGL((k_nn_mfma<C, true>), grid, dim3(256), 0, st, qb, ql, qmeta, n0, tb, tl, tmeta, n1, (int)chunk, U,
-                     cand, cand_count, overflow, shared_list, shared_cap, dense_flag, s_dense_min);
+                     cand, cand_count, overflow, shared_list, shared_cap, dense_list, overflow + 2, s_dense_min);
+  // candidates, dense blocks and -- if a list overflowed -- the exact fallback, in one launch: exact for ANY input
   const unsigned nwg = (unsigned)(qblocks * nchunk);
-  hipLaunchKernelGGL((k_nn_exact<C>), dim3(nwg + 256), dim3(256), 0, st, cand, cand_count, nwg, shared_list, overflow,
-                     shared_cap, f0, f1, best);
-  if ((uint64_t)qblocks * 4 * (uint64_t)nchunk * (uint64_t)(chunk / 16) + 64 >= (1ull << 32)) {
-    apr_set_error("apr_feature_nn_fast: problem too large for the dense-block flags");
-    return APR_EINVAL;
-  }
-  {
-    const unsigned qwaves = (unsigned)(qblocks * 4);
-    const uint64_t nflag = (uint64_t)qwaves * (uint64_t)nchunk * (uint64_t)(chunk / 16);
-    hipLaunchKernelGGL(k_nn_dense_compact, dim3((unsigned)cdiv64((int64_t)cdiv64((int64_t)nflag, 16), 256)), dim3(256), 0, st,
-                       dense_flag, (int)chunk, qwaves, (unsigned)nchunk, n0, n1, dense_list, overflow + 2, overflow);
-    hipLaunchKernelGGL((k_nn_dense_list<C>), dim3(1024), dim3(256), 0, st, dense_list, overflow + 2, (int)chunk, qwaves, f0,
-                       n0, f1, n1, best);
-  }
-  // exact for ANY input: if the lists overflowed, the brute-force kernel (a no-op launch otherwise) redoes the search
-  int rc = apr_internal_nn_brute(f0, n0, f1, n1, C, (uint64_t*)best, overflow, st);
-  if (rc != APR_OK) return rc;
+  const unsigned nexact = nwg + 256;
+  hipLaunchKernelGGL((k_nn_resolve<C>), dim3(nexact + 1024), dim3(256), 0, st, cand, cand_count, nwg, nexact, shared_list,
+                     overflow, shared_cap, dense_list, (int)chunk, (unsigned)(qblocks * 4), f0, n0, f1, n1, best);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }

@@ -66,6 +66,44 @@ def test_feature_nn_filter_refine_equals_brute_force(dev, case):
     assert np.array_equal(d2.cpu().numpy().view(np.uint32), od.view(np.uint32))
 
 
+@pytest.mark.parametrize("c", [32, 64, 128])
+def test_feature_nn_collapsed_features_take_the_dense_blocks(dev, c):
+    """A collapsed encoder (every row within 1e-6 of one vector): every 64 x 16 block of the search is listed as a dense
+    block by the refine pass (appended per workgroup) and evaluated by k_nn_resolve's dense role.  Same bits as brute force
+    and as the oracle."""
+    rng = np.random.default_rng(c)
+    v = rng.standard_normal((1, c)).astype(np.float32)
+    v /= np.linalg.norm(v)
+    F0 = (v + 1e-6 * rng.standard_normal((1333, c))).astype(np.float32)
+    F1 = (v + 1e-6 * rng.standard_normal((2501, c))).astype(np.float32)
+    a, b = torch.from_numpy(F0).to(dev), torch.from_numpy(F1).to(dev)
+    idx, d2 = ops.feature_nn(a, b, return_distance=True, impl="fast")
+    idx_b, d2_b = ops.feature_nn(a, b, return_distance=True, impl="brute")
+    assert torch.equal(idx, idx_b)
+    assert torch.equal(d2.view(torch.int32), d2_b.view(torch.int32))
+    oi, od = MO.feature_nn(F0, F1)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("c", [32, 128])
+def test_feature_nn_list_overflow_takes_the_exact_fallback(dev, c):
+    """More dense blocks than the 2^20-entry list holds (20 k x 60 k identical rows: 1.17 M blocks): the overflow flag is up
+    when the refine pass ends and every wave of k_nn_resolve redoes the search exactly.  Copies tie at d2 = 0: index 0."""
+    rng = np.random.default_rng(c + 1)
+    v = rng.standard_normal((1, c)).astype(np.float32)
+    a = torch.from_numpy(np.repeat(v, 20000, axis=0)).to(dev)
+    t = np.repeat(v, 60000, axis=0)
+    t[7::1000] += 0.5          # a few distinct rows, never the nearest
+    b = torch.from_numpy(t).to(dev)
+    a[123] = b[7]              # one query whose copy sits at index 7, 1007, ...: smallest index wins
+    idx, d2 = ops.feature_nn(a, b, return_distance=True, impl="fast")
+    idx_b, d2_b = ops.feature_nn(a, b, return_distance=True, impl="brute")
+    assert torch.equal(idx, idx_b)
+    assert torch.equal(d2.view(torch.int32), d2_b.view(torch.int32))
+    assert int(idx[0]) == 0 and int(idx[123]) == 7 and float(d2.max()) == 0.0
+
+
 def test_find_nn_gpu_reference_api(dev):
     """find_nn_gpu(F0, F1, nn_max_n=500) as called by find_corr (scripts/test_apr.py:52)."""
     rng = np.random.default_rng(0)
