@@ -22,9 +22,10 @@
 //   refine  the same MFMA pass again; only pairs with approx - eps <= U_i can be the arg-min (or tie with it): for
 //           those — a handful per query — d is evaluated EXACTLY, in the oracle's order, and meets the others in the
 //           same 64-bit atomicMin on (bits(d) << 32 | j) as the brute-force kernel.
-// Candidates go to a list (wave-private LDS buffers, one global atomic per ~1000 entries) and are evaluated densely
-// by k_nn_exact; if a wave's region of the list (2048 entries per 64 queries x one target chunk) overflows — near-
-// identical features everywhere — a predicated brute-force kernel takes over: the result is exact for ANY input.
+// Candidates go to a list (wave-private LDS buffers, the wave's OWN region of the global list; a 64 x 16 block with 16 or
+// more of them is listed as ONE dense block instead) and k_nn_resolve evaluates both kinds; if a list overflows — near-
+// identical features everywhere — the same launch redoes the search exactly: the result is exact for ANY input.
+// Four launches per search: prep (both sides), bound, refine, resolve.
 #include "common.h"
 
 namespace {
@@ -140,7 +141,7 @@ __global__ void k_nn_prep2(const float* __restrict__ f0, int64_t n0, const float
 }
 
 // REFINE = false: U_i = min_j (approx + eps).  REFINE = true: every pair with approx - eps <= U_i is appended to the
-// candidate list (exact evaluation happens densely in k_nn_exact).
+// candidate list (exact evaluation happens in k_nn_resolve).
 // Workgroup = 4 waves x 64 queries; a wave holds its 4 query tiles (16 rows each, hi + lo) as MFMA A operands in
 // registers.  Targets stream through LDS in chunks of 64 rows (hi, lo, meta), double buffered: the next chunk's
 // global loads are in flight while the current one feeds the MFMAs, one barrier per chunk; B fragments are

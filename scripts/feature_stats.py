@@ -48,18 +48,5 @@ cnt = scratch[off + 256:off + 256 + 4 * nwaves].view(torch.int32).cpu().numpy()
 shared = int(scratch[off + 4:off + 8].view(torch.int32).cpu()[0])
 print("fast path: candidates", int(cnt.sum()) + shared, "=", (cnt.sum() + shared) / n0, "per query; per-wave regions", int(cnt.sum()), "(max", int(cnt.max()), "of 2048), shared list", shared, "; fallback flag", ovf)
 
-import numpy as np
-shared_cap = max(65536, 64 * n0)
-nchunk = (n1 + chunk - 1) // chunk
-foff = off + 256 + al(nwaves * 4) + al(nwaves * 2048 * 8) + al(shared_cap * 8)
-nflag = nwaves * (chunk // 16)
-flags = scratch[foff:foff + nflag].cpu().numpy().reshape(nwaves, chunk // 16)
-# only slots the refine pass wrote (live query waves, tiles inside the chunk)
-qw = qblocks * 4
-valid = np.zeros_like(flags, dtype=bool)
-for w in range(nwaves):
-    q0 = (w % qw) * 64; t0 = (w // qw) * chunk
-    if q0 < n0:
-        nt = (min(t0 + chunk, n1) - t0 + 15) // 16
-        valid[w, :max(nt, 0)] = True
-print("dense tiles:", int((flags[valid] != 0).sum()), "of", int(valid.sum()), "; flag values seen:", np.unique(flags[valid])[:8])
+dl = int(scratch[off + 8:off + 12].view(torch.int32).cpu()[0])
+print("dense blocks listed by the refine pass:", dl)
