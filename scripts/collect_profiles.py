@@ -33,7 +33,7 @@ cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_
         "Counter_Value"]
 for c, name in (("FETCH_SIZE", "fetch_size"), ("WRITE_SIZE", "write_size")):
     rows = list(csv.DictReader(open(os.path.join(src, f"pmc_{c}", "p_counter_collection.csv"))))
-    keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_spconv", "k_ws_", "k_os_"))]   # the sparse-conv kernels
+    keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_spconv", "k_ws_", "k_os_", "k_dense_rows"))]   # the sparse-conv kernels
     prows = list(csv.DictReader(open(os.path.join(src, f"pred_pmc_{c}", "p_counter_collection.csv"))))
     keep += [r for r in prows if "k_kpconv" in r["Kernel_Name"]]
     with open(os.path.join(dst, f"{prefix}_pmc_{name}_spconv.csv"), "w", newline="") as f:

@@ -18,7 +18,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) * 1000 / n
 
 
-M = 189191
+M = int(os.environ.get("ROWS", "189191"))
 for cin, cout in [(128, 128), (192, 128), (160, 128), (64, 64), (96, 64), (64, 32), (128, 64)]:
     x = torch.randn(M, cin, device=dev)
     W = torch.randn(1, cin, cout, device=dev) * 0.05

@@ -8,7 +8,7 @@ full-size launch (round 1's figure was diluted 2.8x by 180 small priming launche
 import csv, glob, json, os, sys
 out = sys.argv[1]
 KERNELS = ("k_spconv_pairs", "k_ws_gemm", "k_ws3_gemm", "k_ws_reduce", "k_os_conv", "k_os_build", "k_pairs_build",
-           "k_pairs3_build", "k_dense_gemm", "k_spconv_smallcin")
+           "k_pairs3_build", "k_dense_gemm", "k_dense_rows", "k_spconv_smallcin")
 
 
 def per_kernel(counter, sub, names):
