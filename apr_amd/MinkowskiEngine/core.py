@@ -449,14 +449,15 @@ class _ConvBase(nn.Module):
             self._packT_key = k
         c = self._packT
         if (tile and "tile" not in c) or (bf3 and "bf3" not in c):
-            if "wt" not in c:
-                w = self.kernel.detach()
-                c["wt"] = ops.weights_flip_transpose(w if w.dim() == 3 else w.unsqueeze(0), flip)
+            w = self.kernel.detach()
+            w = w if w.dim() == 3 else w.unsqueeze(0)
             if tile and "tile" not in c:
+                if "wt" not in c:
+                    c["wt"] = ops.weights_flip_transpose(w, flip)
                 c["tile"] = ops.pack_weights(c["wt"])
-            if bf3 and "bf3" not in c:
+            if bf3 and "bf3" not in c:      # split image straight from the parameter: no [K, cout, cin] copy in between
                 import os
-                c["bf3"] = None if os.environ.get("APR_WS_BF3", "1") == "0" else ops.pack_weights_bf3(c["wt"])
+                c["bf3"] = None if os.environ.get("APR_WS_BF3", "1") == "0" else ops.pack_weights_bf3(w, flip=flip, transposed=True)
         return c.get("tile"), c.get("bf3")
 
     def _maps(self, x: SparseTensor):

@@ -123,6 +123,7 @@ PROTOTYPES = {
     "apr_spconv_ws_fwd": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "apr_spconv_packed_bf3_bytes": (_i64, [_i32, _i32, _i32]),
     "apr_spconv_pack_weights_bf3": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "apr_spconv_pack_weights_bf3_ex": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "apr_spconv_ws_fwd_bf3": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64,
                                         _p, _p]),
     "apr_spconv_wgrad_scratch_bytes": (_sz, [_i64, _i32, _i32, _i32]),

@@ -286,28 +286,45 @@ __global__ __launch_bounds__(256, 2) void k_ws_gemm(const float* __restrict__ in
 // conflict-free ds_read_b128 (the 16 lanes of every hardware lane group land in 16 different 16-B slots).
 // The input rows are split in registers after the gather (lane (pair r16, quad q) loads 8 consecutive channels per
 // 32-channel step: two 16-B loads).
-// w f32 [K, cin, cout] -> wp3 (layout above), one thread per (k, ci, co)
-__global__ void k_pack_weights_bf3(const float* __restrict__ w, int K, int cin, int cout, __bf16* __restrict__ wp3) {
+// w f32 -> wp3 (layout above).  One thread per 16-byte piece of the image (k, column block, step, column, quad): three
+// coalesced 16-B stores (a thread per ELEMENT wrote 2 bytes at a 64-B stride: 15 us for a 27 x 128 x 128 kernel, and the
+// training step re-packs ~40 kernels after every optimizer step).  `tr`: w is stored [K, cout, cin] and the image is that of
+// its transpose -- with `flip` (offsets mirrored) the kernel of a convolution's INPUT GRADIENT straight from the parameter,
+// no [K, cout, cin] copy in between.  Columns past cout (K = 1 images padded to 64) are zeros.
+__global__ void k_pack_weights_bf3(const float* __restrict__ w, int K, int cin, int cout, int flip, int tr,
+                                   __bf16* __restrict__ wp3) {
+  const int nstep = cin >> 5, ncb = (cout + 63) >> 6;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)K * cin * cout;
+  const int64_t total = (int64_t)K * ncb * nstep * 64 * 4;
   if (t >= total) return;
-  const int co = (int)(t % cout);
-  const int ci = (int)((t / cout) % cin);
-  const int k = (int)(t / ((int64_t)cout * cin));
-  const float x = w[t];
-  const __bf16 h = (__bf16)x;
-  const float r = x - (float)h;
-  const __bf16 m = (__bf16)r;
-  const __bf16 l = (__bf16)(r - (float)m);
-  const int cbk = co >> 6, col = co & 63, s = ci >> 5, q = (ci >> 3) & 3, e = ci & 7;
-  const int qs = (col & 8) ? (q ^ 3) : q;
-  const int nstep = cin >> 5;
+  const int qs = (int)(t & 3), col = (int)((t >> 2) & 63);
+  const int s = (int)((t >> 8) % nstep);
+  const int cbk = (int)((t / ((int64_t)256 * nstep)) % ncb);
+  const int k = (int)(t / ((int64_t)256 * nstep * ncb));
+  const int q = (col & 8) ? (qs ^ 3) : qs;
+  const int co = cbk * 64 + col, ci0 = s * 32 + q * 8;
+  const int ks = flip ? K - 1 - k : k;
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  u16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, m = h, l = h;
+  if (co < cout) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = tr ? w[((int64_t)ks * cout + co) * cin + ci0 + e] : w[((int64_t)ks * cin + ci0 + e) * cout + co];
+      const __bf16 hb = (__bf16)x;
+      const float r = x - (float)hb;
+      const __bf16 mb = (__bf16)r;
+      const __bf16 lb = (__bf16)(r - (float)mb);
+      h[e] = __builtin_bit_cast(unsigned short, hb);
+      m[e] = __builtin_bit_cast(unsigned short, mb);
+      l[e] = __builtin_bit_cast(unsigned short, lb);
+    }
+  }
   const int64_t slice = (int64_t)3 * nstep * 64 * 32;                  // bf16 elements of one (k, column block)
-  const int64_t base = ((int64_t)k * ((cout + 63) >> 6) + cbk) * slice + ((int64_t)s * 64 + col) * 32 + qs * 8 + e;
   const int64_t plane = (int64_t)nstep * 64 * 32;
-  wp3[base] = h;
-  wp3[base + plane] = m;
-  wp3[base + 2 * plane] = l;
+  const int64_t base = ((int64_t)k * ncb + cbk) * slice + ((int64_t)s * 64 + col) * 32 + qs * 8;
+  *reinterpret_cast<u16x8*>(wp3 + base) = h;
+  *reinterpret_cast<u16x8*>(wp3 + base + plane) = m;
+  *reinterpret_cast<u16x8*>(wp3 + base + 2 * plane) = l;
 }
 
 // NW waves per workgroup: 4, or 8 for the 256-channel slice (96 KB: ONE workgroup per CU whatever its size -- with 4
@@ -779,16 +796,22 @@ APR_API int64_t apr_spconv_packed_bf3_bytes(int32_t K, int32_t cin, int32_t cout
   return bf3_shape_ok(K, cin, cout) ? (int64_t)K * cin * ((cout + 63) / 64 * 64) * 6 : 0;
 }
 
-APR_API int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream) {
+// flip / transposed: the image of w'[k'][ci][co] = w[k][co][ci] (k' = K - 1 - k when flip) for w stored f32 [K, cout, cin] --
+// the kernel of the convolution's input gradient (apr_weights_flip_transpose + apr_spconv_pack_weights_bf3 in one pass).
+APR_API int apr_spconv_pack_weights_bf3_ex(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t flip,
+                                           int32_t transposed, void* w_bf3, void* stream) {
   APR_CHECK_ARG(w && w_bf3 && bf3_shape_ok(K, cin, cout),
                 "apr_spconv_pack_weights_bf3: needs cin %% 64 == 0 and cout %% 64 == 0 (K = 1: cin %% 32 == 0, cout %% 16 == 0)");
-  const int64_t total = (int64_t)K * cin * cout;
-  if (cout % 64 != 0)
-    APR_HIP(hipMemsetAsync(w_bf3, 0, (size_t)apr_spconv_packed_bf3_bytes(K, cin, cout), (hipStream_t)stream));
+  APR_CHECK_ARG(((uintptr_t)w_bf3 & 15) == 0, "apr_spconv_pack_weights_bf3: the image must be 16-byte aligned");
+  const int64_t total = (int64_t)K * ((cout + 63) / 64) * (cin / 32) * 256;
   hipLaunchKernelGGL(k_pack_weights_bf3, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin,
-                     cout, (__bf16*)w_bf3);
+                     cout, flip ? 1 : 0, transposed ? 1 : 0, (__bf16*)w_bf3);
   APR_LAUNCH_CHECK();
   return APR_OK;
+}
+
+APR_API int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream) {
+  return apr_spconv_pack_weights_bf3_ex(w, K, cin, cout, 0, 0, w_bf3, stream);
 }
 
 APR_API int32_t apr_pairlist_counter_ints(void) { return 32 * kCntStride; }

@@ -447,14 +447,17 @@ def pack_weights(w: torch.Tensor) -> torch.Tensor:
     return wp
 
 
-def pack_weights_bf3(w: torch.Tensor):
+def pack_weights_bf3(w: torch.Tensor, flip=False, transposed=False):
     """[K,cin,cout] fp32 kernel -> the 3-way bf16 split image of apr_spconv_ws_fwd_bf3 (uint8 blob), or None when the
     shape is not covered (sparse kernels: cin not in 64/128/192/256/384 or cout % 64 != 0; the dense K = 1 forms take any
-    64-multiples, and cin 64..192 step 32 with cout 32 / 64 / 128)."""
+    64-multiples, and cin 64..192 step 32 with cout 32 / 64 / 128).  `transposed` (with `flip`: offsets mirrored): the
+    image of the input gradient's kernel [K, cout, cin] straight from the parameter (apr_spconv_pack_weights_bf3_ex)."""
     w = _f32(w.detach(), "pack_weights_bf3.w")
     if w.dim() != 3:
         return None
     K, cin, cout = w.shape
+    if transposed:
+        cin, cout = cout, cin
     lib = _lib_()
     if K == 1:      # dense layers: 64-multiples (apr_dense_gemm_bf3) or the row-stream kernel's shapes (apr_dense_rows_bf3)
         if not ((cin % 64 == 0 and cin >= 64 and cout % 64 == 0 and cout >= 64) or lib.apr_dense_rows_bf3_ok(cin, cout)):
@@ -462,7 +465,8 @@ def pack_weights_bf3(w: torch.Tensor):
     elif cin not in (64, 128, 192, 256, 384) or cout % 64 != 0 or cout < 64:
         return None
     blob = torch.empty(int(lib.apr_spconv_packed_bf3_bytes(K, cin, cout)), dtype=torch.uint8, device=w.device)
-    check(lib.apr_spconv_pack_weights_bf3(ptr(w.contiguous()), K, cin, cout, ptr(blob), stream()))
+    check(lib.apr_spconv_pack_weights_bf3_ex(ptr(w.contiguous()), K, cin, cout, int(bool(flip)), int(bool(transposed)), ptr(blob),
+                                             stream()))
     return blob
 
 

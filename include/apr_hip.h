@@ -242,6 +242,12 @@ int apr_spconv_ws_fwd(const float* in, int64_t ldi, const int32_t* counters, con
  * images) also cin % 32 == 0 and cout % 16 == 0. */
 int64_t apr_spconv_packed_bf3_bytes(int32_t K, int32_t cin, int32_t cout);
 int apr_spconv_pack_weights_bf3(const float* w, int32_t K, int32_t cin, int32_t cout, void* w_bf3, void* stream);
+/* The same image for the kernel of the INPUT GRADIENT, straight from the parameter: transposed != 0 reads w as f32
+ * [K, cout, cin] (the image is that of its transpose), flip != 0 mirrors the offsets (k' = K - 1 - k: a same-level map's
+ * reverse map) -- apr_weights_flip_transpose + apr_spconv_pack_weights_bf3 in one pass (the training step re-packs every
+ * kernel after every optimizer step, FCGF_APR/lib/trainer.py:454-527).  w_bf3 16-byte aligned. */
+int apr_spconv_pack_weights_bf3_ex(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t flip, int32_t transposed,
+                                   void* w_bf3, void* stream);
 int apr_spconv_ws_fwd_bf3(const float* in, int64_t ldi, const int32_t* counters, const void* plist, int64_t n_out,
                           int32_t K, int32_t cin, int32_t cout, const float* w_packed, const void* w_bf3,
                           const float* scale, const float* shift, const float* residual, int64_t ldr, int32_t relu,

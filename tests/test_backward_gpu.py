@@ -288,3 +288,18 @@ def test_stacked_frames_equal_separate_calls(dev):
             assert int(ba[n]) == int(bb[n]) == 2, n
         else:
             assert torch.allclose(ba[n], bb[n], rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.parametrize("K,cin,cout", [(27, 64, 128), (27, 128, 128), (27, 256, 64), (8, 128, 64), (1, 128, 64), (1, 64, 64)])
+@pytest.mark.parametrize("flip", [False, True])
+def test_input_gradient_kernel_image_packs_straight_from_the_parameter(K, cin, cout, flip):
+    """apr_spconv_pack_weights_bf3_ex(flip, transposed) writes the same bytes as apr_weights_flip_transpose followed by the
+    plain pack: the training step's re-pack after every optimizer step needs no [K, cout, cin] copy."""
+    from apr_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(K * 1000 + cin + cout)
+    w = torch.randn(K, cin, cout, generator=g).to(dev)
+    direct = ops.pack_weights_bf3(w, flip=flip, transposed=True)
+    two_step = ops.pack_weights_bf3(ops.weights_flip_transpose(w, flip))
+    assert direct is not None and two_step is not None
+    assert torch.equal(direct, two_step)
