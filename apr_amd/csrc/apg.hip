@@ -331,7 +331,59 @@ __global__ __launch_bounds__(256) void k_nn3_grid_wave(const float* __restrict__
     }
     return;
   }
-  if (!done) {                                               // several clouds: every target of the query's own cloud
+  if (!done && g.cell > 0.f) {
+    // several clouds, nothing proven within kMaxRing rings (a complement cloud reaches far beyond the frame it is compared
+    // with: 11-18 % of its points are > 9 m from every generated point): the OCCUPIED CELLS of the query's own cloud, lanes
+    // over the cells -- a box's distance first, its points only if the box can hold a point at least as near as the best
+    // so far.  ~10 k box tests instead of ~56 k point tests per query (the wave used to walk every target of the cloud).
+    // The box is widened by 1 % of a cell on every side: a point sits in its cell up to the rounding of (p - min) / cell.
+    const int nc = *g.n_cells;
+    const float ox = g.mins[3 * seg], oy = g.mins[3 * seg + 1], oz = g.mins[3 * seg + 2];
+    const float m = 0.01f * g.cell;
+    auto box_d2 = [&](const int4 cc) {
+      const float lx = ox + (float)cc.y * g.cell - m, ly = oy + (float)cc.z * g.cell - m, lz = oz + (float)cc.w * g.cell - m;
+      const float hx = lx + g.cell + 2.f * m, hy = ly + g.cell + 2.f * m, hz = lz + g.cell + 2.f * m;
+      const float dx = fmaxf(fmaxf(lx - x, x - hx), 0.f), dy = fmaxf(fmaxf(ly - y, y - hy), 0.f);
+      const float dz = fmaxf(fmaxf(lz - z, z - hz), 0.f);
+      return dx * dx + dy * dy + dz * dz;
+    };
+    float T = bd;                                            // what the rings found (not proven minimal), wave-wide
+    for (int d = 32; d >= 1; d >>= 1) T = fminf(T, __shfl_xor(T, d));
+    if (T == __builtin_inff()) {                             // nothing yet: the nearest box's points give the first bound
+      float nd = __builtin_inff();
+      int nid = -1;
+      for (int id = lane; id < nc; id += 64) {
+        const int4 cc = g.cell_coords[id];
+        if (cc.x != seg) continue;
+        const float d2 = box_d2(cc);
+        if (d2 < nd) { nd = d2; nid = id; }
+      }
+      for (int d = 32; d >= 1; d >>= 1) {
+        const float od = __shfl_xor(nd, d);
+        const int oi = __shfl_xor(nid, d);
+        if (od < nd || (od == nd && oi >= 0 && (nid < 0 || oi < nid))) { nd = od; nid = oi; }
+      }
+      if (nid >= 0) {
+        const int e1 = g.start[nid + 1];
+        for (int e = g.start[nid] + lane; e < e1; e += 64) {
+          const unsigned j = (unsigned)g.sorted[e];
+          better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
+        }
+        T = bd;
+        for (int d = 32; d >= 1; d >>= 1) T = fminf(T, __shfl_xor(T, d));
+      }
+    }
+    for (int id = lane; id < nc; id += 64) {
+      const int4 cc = g.cell_coords[id];
+      if (cc.x != seg) continue;
+      if (box_d2(cc) > fminf(T, bd)) continue;               // <=: a tie with a smaller index may sit in this box
+      const int e1 = g.start[id + 1];
+      for (int e = g.start[id]; e < e1; ++e) {
+        const unsigned j = (unsigned)g.sorted[e];
+        better(d2_rn(x, y, z, b[3 * (int64_t)j], b[3 * (int64_t)j + 1], b[3 * (int64_t)j + 2]), j, bd, bj);
+      }
+    }
+  } else if (!done) {                                        // no grid: every target of the query's own cloud
     bd = __builtin_inff();
     bj = 0xFFFFFFFFu;
     for (int64_t j = sg.b0[seg] + lane; j < sg.b0[seg + 1]; j += 64)

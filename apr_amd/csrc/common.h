@@ -119,6 +119,8 @@ struct AprSearchGrid {
   const int* sorted;  // point indices bucketed by cell
   const float* mins;  // [3] cloud minimum = grid origin
   float cell;
+  const int4* cell_coords;   // [n_cells] (cloud, cx, cy, cz) of every occupied cell, by cell id
+  const int* n_cells;        // device-side count of occupied cells
 };
 size_t apr_internal_grid_bytes(int64_t n);
 int apr_internal_search_grid(const float* pts, int64_t n, float cell, void* scratch, AprSearchGrid* out,

@@ -820,6 +820,8 @@ int apr_internal_search_grid(const float* pts, int64_t n, float cell, void* scra
   out->sorted = w.sorted;
   out->mins = w.mins;
   out->cell = cell;
+  out->cell_coords = w.cell_coords;
+  out->n_cells = w.n_cells;
   return APR_OK;
 }
 
@@ -840,6 +842,8 @@ int apr_internal_search_grid_batch(const float* pts, int64_t n, const int32_t* l
   out->sorted = w.sorted;
   out->mins = w.mins;
   out->cell = cell;
+  out->cell_coords = w.cell_coords;
+  out->n_cells = w.n_cells;
   return APR_OK;
 }
 

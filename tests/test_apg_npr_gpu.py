@@ -176,3 +176,31 @@ def test_batched_chamfer_equals_cloud_by_cloud(dev):
         i1, d1, _ = npr.nn3(As[k], Bs[k])
         ib, db, _ = npr.nn3_batch(torch.cat(As), ao, torch.cat(Bs), bo)
         assert torch.equal(ib[ao[k]:ao[k + 1]] - bo[k], i1) and torch.equal(db[ao[k]:ao[k + 1]], d1), k
+
+
+def test_far_queries_of_a_batch_prune_by_cell_and_keep_the_tie_rule(dev):
+    """Queries tens of metres from their partner cloud (a complement cloud's far points against the generated points) take the
+    cell-pruned search of k_nn3_grid_wave: same indices and distances as the brute-force search of each cloud, and of two
+    targets at EXACTLY the same distance in different cells the smaller index wins."""
+    from apr_amd import npr
+    rng = np.random.default_rng(5)
+    clouds = []
+    for k in range(3):
+        b = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
+        b[:, 2] *= 0.1
+        a = rng.uniform(-150, 150, (3000, 3)).astype(np.float32)          # most of them far outside the target's extent
+        a[:, 2] = rng.uniform(-3, 60, 3000)
+        if k == 1:                                                          # exact ties across cells
+            b[100], b[4000] = (7.0, 0.0, 3.0), (-7.0, 0.0, 3.0)             # above every other target (|z| <= 2)
+            a[0] = (0.0, 0.0, 90.0)
+            a[1] = (0.0, -2.0, 55.0)
+        clouds.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    ao = np.concatenate([[0], np.cumsum([len(a) for a, _ in clouds])]).tolist()
+    bo = np.concatenate([[0], np.cumsum([len(b) for _, b in clouds])]).tolist()
+    A, B = torch.cat([a for a, _ in clouds]), torch.cat([b for _, b in clouds])
+    ib, db, _ = npr.nn3_batch(A, ao, B, bo)
+    for k, (a, b) in enumerate(clouds):
+        i0, d0, _ = npr.nn3(a, b, cell=0.0)                                 # brute force
+        assert torch.equal(ib[ao[k]:ao[k + 1]] - bo[k], i0), k
+        assert torch.equal(db[ao[k]:ao[k + 1]], d0), k
+    assert int(ib[ao[1]] - bo[1]) == 100 and int(ib[ao[1] + 1] - bo[1]) == 100
