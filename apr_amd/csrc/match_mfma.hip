@@ -583,13 +583,20 @@ int64_t shared_capacity(int64_t n0) {   // shared overflow list: 64 candidates p
   return c < (1ll << 31) ? c : (1ll << 31) - 1;
 }
 
-// refine grid: query blocks of 256 x target chunks (multiples of 64 rows) so that ~768 workgroups exist (three per CU at
-// C = 32; at C = 128 two are resident and a workgroup reloads its queries' fragments, C x 1 KB, per chunk -- fewer, longer
-// chunks were measured and lose all the same: 14 k x 14 k x 128 in 304 us with 768, 355 / 312 / 383 with 512 / 384 / 256)
-void nn_grid(int64_t n0, int64_t n1, int64_t* qblocks, int64_t* chunk, int64_t* nchunk) {
-  static const int s_wgs = env_int("APR_NN_GRID_WGS", 768);      // A/B switch
+// refine grid: query blocks of 256 x target chunks (multiples of 64 rows) so that ONE resident round of workgroups exists:
+// at C = 32 three workgroups fit a CU (~768: the count of earlier rounds, kept), at C = 64 / 128 two (176 / 244 registers),
+// and there the chunk count is the largest that still fits 512 -- 14 k x 14 k x 128: 9 chunks (495 workgroups) 310 us,
+// 14 (770: a second, half-empty round) 356, 11-13 354-360, 7 348; at C = 32 9 / 13 / 14 chunks are within 1 us of each other.
+void nn_grid(int64_t n0, int64_t n1, int feat_c, int64_t* qblocks, int64_t* chunk, int64_t* nchunk) {
+  static const int s_wgs = env_int("APR_NN_GRID_WGS", 768);      // A/B switches
+  static const int s_want = env_int("APR_NN_WANT", 0);
   *qblocks = cdiv64(n0, 256);
-  const int64_t want = cdiv64(s_wgs > 0 && s_wgs < 768 ? s_wgs : 768, *qblocks);
+  int64_t want = cdiv64(s_wgs > 0 && s_wgs < 768 ? s_wgs : 768, *qblocks);
+  if (feat_c >= 64) {
+    const int64_t fit = 512 / *qblocks;
+    if (fit >= 1 && fit < want) want = fit;
+  }
+  if (s_want > 0 && s_want <= want) want = s_want;
   int64_t c = cdiv64(cdiv64(n1, want), 64) * 64;
   if (c < 256) c = 256;
   if (c >= (1 << 24)) c = (1 << 24) - 64;
@@ -607,7 +614,7 @@ template <int C>
 int run_fast(const float* f0, int64_t n0, const float* f1, int64_t n1, unsigned long long* best, char* p,
              hipStream_t st) {
   int64_t qblocks, chunk, nchunk;
-  nn_grid(n0, n1, &qblocks, &chunk, &nchunk);
+  nn_grid(n0, n1, C, &qblocks, &chunk, &nchunk);
   const int64_t nwaves = qblocks * nchunk * 4;
   unsigned short* qb = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);
   unsigned short* ql = (unsigned short*)p;  p += al256((size_t)n0 * C * 2);
