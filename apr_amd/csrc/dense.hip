@@ -14,6 +14,7 @@
 // row pieces.  Exact fp32 (v_mfma_f32_16x16x4_f32, D^T form: a lane ends with 4 consecutive channels of one row).
 #include "common.h"
 #include "bf3.h"
+#include <mutex>
 
 namespace {
 
@@ -148,7 +149,14 @@ struct DenseSegs {
   int tile0[33];
 };
 
-template <int G, bool STATS>
+// ASTG (round 5): the rows reach the MFMA operands THROUGH LDS.  By ablation (16 KPFCNN shapes, 1427 us in all) the
+// fragment-shaped row loads are the largest single cost of this kernel -- without them 972 us, without the split 1341, without
+// the weight staging 1259, without the barrier 1289: a lane's two 16-B pieces per 32-channel step make every instruction touch
+// 16 cache lines for 1 KB, every line twice.  Here a wave copies ITS 16 G rows of the chunk (256 B each) into its own LDS region
+// by LDS-DMA in full lines (4 rows x 256 B per instruction, the 16-B pieces XOR-swizzled by row through the per-lane SOURCE
+// address so that the fragment reads are conflict-free), reads its fragments back at the top of the chunk and then sends for
+// the next chunk's rows into the same region: wave-private, no extra barrier, one register set.
+template <int G, bool STATS, bool ASTG = false>
 __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restrict__ in, int64_t ldi, int M, int cin,
                                                            int cout, const unsigned char* __restrict__ wp3,
                                                            const float* __restrict__ scale,
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restri
                                                            float* __restrict__ out, int64_t ldo, DenseSegs sg,
                                                            double* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) unsigned char s_w[2][3 * 8192];   // [buf][plane][step 2][col 64][quad 4][16 B]
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_a[];       // ASTG: [wave 4][row 16 G][piece 16 (swizzled)][16 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, q = lane >> 4;
@@ -205,17 +214,49 @@ __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restri
         (const __attribute__((address_space(1))) void*)(wsrc + (int64_t)(c) * 8192 + (u >> 1) * plane_bytes +      \
                                                          (u & 1) * 4096),                                          \
         (__attribute__((address_space(3))) void*)&s_w[buf][(u >> 1) * 8192 + (u & 1) * 4096 + wave * 1024], 16, 0, 0);
+  // ASTG: instruction u of a wave brings rows 4 u .. 4 u + 3 of its 16 G rows; lane l -> row 4 u + l / 16, LDS slot l % 16,
+  // which holds the row's 16-B piece (l % 16) ^ (row % 16)
+  const float* asrc[ASTG ? 4 * G : 1];
+  unsigned char* my_a = s_a + (ASTG ? wave * (G * 4096) : 0);
+  if (ASTG) {
+#pragma unroll
+    for (int u = 0; u < 4 * G; ++u) {
+      const int rloc = 4 * u + (lane >> 4);
+      const int r = row0 + rloc;
+      asrc[u] = in + (int64_t)(r < row_end ? r : row_end - 1) * ldi + (((lane & 15) ^ (rloc & 15)) << 2);
+    }
+  }
+#define APR_DENSE3_ASTAGE(c)                                                                                       \
+  _Pragma("unroll") for (int u = 0; u < 4 * G; ++u)                                                                \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[u] + (int64_t)(c) * 64),  \
+                                     (__attribute__((address_space(3))) void*)(my_a + u * 1024), 16, 0, 0);
+  // this lane's fragments of the staged chunk: piece (j >> 1) * 8 + 2 q + (j & 1) of row gi * 16 + r16, in slot piece ^ r16
+#define APR_DENSE3_AREAD(buf)                                                                                      \
+  _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                  \
+      abuf[buf][gi][j] = *reinterpret_cast<const f32x4*>(my_a + (gi * 16 + r16) * 256 +                            \
+                                                         ((((j >> 1) * 8 + 2 * q + (j & 1)) ^ r16) << 4));
   APR_DENSE3_STAGE(0, 0)
+  if (ASTG) {
+    APR_DENSE3_ASTAGE(0)
+  } else {
 #pragma unroll
-  for (int gi = 0; gi < G; ++gi)
+    for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) abuf[0][gi][j] = *reinterpret_cast<const f32x4*>(arow[gi] + (j >> 1) * 32 + (j & 1) * 4);
+      for (int j = 0; j < 4; ++j) abuf[0][gi][j] = *reinterpret_cast<const f32x4*>(arow[gi] + (j >> 1) * 32 + (j & 1) * 4);
+  }
   __syncthreads();
 
-#define APR_DENSE3_CHUNK(cur, nxt, c)                                                                              \
+#define APR_DENSE3_CHUNK(cur_, nxt, c)                                                                             \
   {                                                                                                                \
     const bool more = (c) + 1 < nchunk;                                                                            \
-    if (more) {                                                                                                    \
+    constexpr int cur = ASTG ? 0 : cur_;                                                                           \
+    if (ASTG) {                                                                                                    \
+      APR_DENSE3_AREAD(0)                                                                                          \
+      if (more) { APR_DENSE3_STAGE(((c) + 1) & 1, (c) + 1) }                                                       \
+      __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0): the fragments are in registers, the region is free */   \
+      if (more) { APR_DENSE3_ASTAGE((c) + 1) }                                                                     \
+    } else if (more) {                                                                                             \
       APR_DENSE3_STAGE(((c) + 1) & 1, (c) + 1)                                                                     \
       _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                              \
@@ -267,6 +308,8 @@ __global__ __launch_bounds__(256, 2) void k_dense_gemm_bf3(const float* __restri
   if (c < nchunk) APR_DENSE3_CHUNK(0, 1, c)
 #undef APR_DENSE3_CHUNK
 #undef APR_DENSE3_STAGE
+#undef APR_DENSE3_ASTAGE
+#undef APR_DENSE3_AREAD
 
   if (STATS) {
     // the tile's image [64 G rows][64 columns] fp32 through the weight buffers (free: the last chunk ended in a barrier),
@@ -347,6 +390,27 @@ int apr_internal_dense_gemm(const float* in, int64_t ldi, int64_t M, int32_t cin
   return APR_OK;
 }
 
+// rows through LDS (k_dense_gemm_bf3<.., ASTG>): APR_DENSE_ASTG=0 is the A/B switch back to fragment-shaped loads
+static bool dense_astg(int32_t cin) {
+  static const int s_on = env_int("APR_DENSE_ASTG", 1);
+  return s_on != 0 && cin >= 128;
+}
+static int dense_astg_attr() {      // 48 KB static + 16 G KB dynamic LDS: above 64 KB needs the opt-in, once per device
+  static std::mutex s_mu;
+  static bool s_attr[64] = {};
+  int dev = 0;
+  APR_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(s_mu);
+  if (dev >= 0 && dev < 64 && !s_attr[dev]) {
+    APR_HIP(hipFuncSetAttribute((const void*)k_dense_gemm_bf3<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+    APR_HIP(hipFuncSetAttribute((const void*)k_dense_gemm_bf3<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+    APR_HIP(hipFuncSetAttribute((const void*)k_dense_gemm_bf3<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384));
+    APR_HIP(hipFuncSetAttribute((const void*)k_dense_gemm_bf3<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384));
+    s_attr[dev] = true;
+  }
+  return APR_OK;
+}
+
 // The same contraction on the bf16 3-way split (k_dense_gemm_bf3): out = act((in @ W) * scale + shift + residual) for
 // an identity map.  w_bf3: apr_spconv_pack_weights_bf3(w, K = 1, cin, cout).  cin % 64 == 0, cout % 64 == 0, rows of
 // in / out / residual 16-B aligned (ld % 4 == 0).
@@ -366,14 +430,17 @@ APR_API int apr_dense_gemm_bf3(const float* in, int64_t ldi, int64_t M, int32_t 
   hipStream_t st = (hipStream_t)stream;
   const int64_t ncol = cout / 64;
   static const int s_g = env_int("APR_DENSE_G", 0);      // A/B switch: force 64-row (1) or 128-row (2) tiles
-  if (s_g == 2 || (s_g == 0 && cdiv64(M, 128) * ncol >= 512))
-    hipLaunchKernelGGL((k_dense_gemm_bf3<2, false>), dim3((unsigned)(cdiv64(M, 128) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
-                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, DenseSegs{},
-                       (double*)nullptr);
-  else
-    hipLaunchKernelGGL((k_dense_gemm_bf3<1, false>), dim3((unsigned)(cdiv64(M, 64) * ncol)), dim3(256), 0, st, in, ldi, (int)M,
-                       cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, DenseSegs{},
-                       (double*)nullptr);
+  const bool g2 = s_g == 2 || (s_g == 0 && cdiv64(M, 128) * ncol >= 512);
+  const bool astg = dense_astg(cin);
+  if (astg) {
+    int rca = dense_astg_attr();
+    if (rca != APR_OK) return rca;
+  }
+  auto kern = g2 ? (astg ? k_dense_gemm_bf3<2, false, true> : k_dense_gemm_bf3<2, false, false>)
+                 : (astg ? k_dense_gemm_bf3<1, false, true> : k_dense_gemm_bf3<1, false, false>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(cdiv64(M, g2 ? 128 : 64) * ncol)), dim3(256), astg ? (g2 ? 32768 : 16384) : 0, st, in,
+                     ldi, (int)M, cin, cout, (const unsigned char*)w_bf3, scale, shift, residual, ldr, relu, out, ldo, DenseSegs{},
+                     (double*)nullptr);
   APR_LAUNCH_CHECK();
   return APR_OK;
 }
@@ -416,14 +483,16 @@ APR_API int apr_dense_gemm_bf3_norm_act(const float* in, int64_t ldi, int64_t M,
   }
   const int ntile = sg.tile0[ns];
   double* partial = (double*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-  if (G == 2)
-    hipLaunchKernelGGL((k_dense_gemm_bf3<2, true>), dim3((unsigned)(ntile * ncol)), dim3(256), 0, st, in, ldi, (int)M, cin, cout,
-                       (const unsigned char*)w_bf3, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (int64_t)0, 0, out, ldo, sg, partial);
-  else
-    hipLaunchKernelGGL((k_dense_gemm_bf3<1, true>), dim3((unsigned)(ntile * ncol)), dim3(256), 0, st, in, ldi, (int)M, cin, cout,
-                       (const unsigned char*)w_bf3, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (int64_t)0, 0, out, ldo, sg, partial);
+  const bool astg = dense_astg(cin);
+  if (astg) {
+    int rca = dense_astg_attr();
+    if (rca != APR_OK) return rca;
+  }
+  auto kern = G == 2 ? (astg ? k_dense_gemm_bf3<2, true, true> : k_dense_gemm_bf3<2, true, false>)
+                     : (astg ? k_dense_gemm_bf3<1, true, true> : k_dense_gemm_bf3<1, true, false>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ntile * ncol)), dim3(256), astg ? (G == 2 ? 32768 : 16384) : 0, st, in, ldi, (int)M, cin,
+                     cout, (const unsigned char*)w_bf3, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (int64_t)0, 0, out, ldo, sg, partial);
   APR_LAUNCH_CHECK();
   return apr_internal_norm_apply_partials(out, ldo, cout, offs, sg.tile0, ns, partial, eps, residual, ldr, act_mode, negative_slope,
                                           out, ldo, st);
