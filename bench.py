@@ -267,7 +267,10 @@ def extra_workloads(dev, log, cpu_baselines=True):
     for sd in range(1, 8):
         pa, pb, _ = synth.make_pair(sd)
         pool.append((torch.from_numpy(pa).to(dev), torch.from_numpy(pb).to(dev)))
-    B, S, nbatch = 4, 8, 16      # 8 batches in flight: 318 vs 295 pairs/s with 4 (the path is GPU-bound; more streams fill its gaps)
+    # 8 batches in flight: 318 vs 295 pairs/s with 4 (the path is GPU-bound; more streams fill its gaps).  48 batches per run:
+    # with 16 (rounds 2-4) filling and draining the 8-deep pipeline was a third of the run -- 384 pairs/s against 393 / 395 with
+    # 48 / 96 batches on one box (scripts/predator_stacked_rate.py NBATCH=...)
+    B, S, nbatch = 4, 8, 48
     batches = [[pool[(i * B + j) % len(pool)] for j in range(B)] for i in range(nbatch)]
     pstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     mk = lambda i: pred.register_batch_phases(batches[i], seeds=range(i * B, i * B + B))
@@ -283,7 +286,7 @@ def extra_workloads(dev, log, cpu_baselines=True):
     out["predator_config3"] = {
         "workload": "Predator_APR KPConv encoder + overlap attention + score sampling + RANSAC(50000, 1000) on "
                     "2 x 118 k-point pairs (8 distinct synthetic pairs); 4 pairs stacked per forward, one host thread "
-                    "keeping 8 batches in flight on 8 streams; median of 3 runs of 64 pairs",
+                    "keeping 8 batches in flight on 8 streams; median of 3 runs of 192 pairs",
         "value": rates[1], "unit": "pairs/s", "ms_per_pair": 1e3 / rates[1], "runs_pairs_per_s": rates,
         "host_enqueue_ms_per_pair": sorted(host_ms)[1],
         "one_pair_at_a_time": {"value": reps / (t1 - t0), "unit": "pairs/s", "ms_per_pair": 1e3 * (t1 - t0) / reps},
