@@ -331,8 +331,9 @@ def extra_workloads(dev, log, cpu_baselines=True):
     pool6 = [(ta, tb)] + [tuple(torch.from_numpy(x).to(dev) for x in synth.make_pair(s)[:2]) for s in range(1, 6)]
     fstreams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 
-    def pipelined_rate(p, nsteps=24, B6=6):
-        """pairs/s of `p` over nsteps steps of B6 pairs, 3 steps in flight; median of 3 runs after a priming run."""
+    def pipelined_rate(p, nsteps=48, B6=6):
+        """pairs/s of `p` over nsteps steps of B6 pairs, 3 steps in flight; median of 3 runs after a priming run (48 steps: fill
+        and drain of the pipeline are ~3 % of a run; they were 5-6 % of the 24-step runs of rounds 2-4)."""
         mk6 = lambda i: p.register_batch_phases([pool6[(i * B6 + j) % len(pool6)] for j in range(B6)],
                                                 seeds=[i * B6 + j for j in range(B6)])
         rates6 = []
