@@ -258,7 +258,7 @@ def extra_workloads(dev, log, cpu_baselines=True):
     kr["kernel"] = ("KPConv layer = k_row_sums + k_kpconv_weighted_mfma (kernel-point correlation) + "
                     "k_dense_gemm_bf3 ([N, 15*cin] x [15*cin, cout], bf16 3-way split, fp32-equivalent); "
                     f"{ks['launches']} layers of one KPFCNN forward")
-    # the same pipeline the way a registration service runs it: 4 pairs stacked per collate / KPFCNN forward
+    # the same pipeline the way a registration service runs it: 8 pairs stacked per collate / KPFCNN forward
     # (per-pair InstanceNorm statistics and overlap attention: every pair gets its batch-of-one result), ONE host
     # thread keeping 4 batches in flight on 4 streams (register_batch_phases resumed when its fetches land), so that
     # one batch's host-RNG sampling and launch calls overlap the others' kernels
@@ -270,7 +270,8 @@ def extra_workloads(dev, log, cpu_baselines=True):
     # 8 batches in flight: 318 vs 295 pairs/s with 4 (the path is GPU-bound; more streams fill its gaps).  48 batches per run:
     # with 16 (rounds 2-4) filling and draining the 8-deep pipeline was a third of the run -- 384 pairs/s against 393 / 395 with
     # 48 / 96 batches on one box (scripts/predator_stacked_rate.py NBATCH=...)
-    B, S, nbatch = 4, 8, 48
+    # 8 pairs per forward (round 5; 4 before): same box 407 / 419 / 435 / 433 / 439 pairs/s with 4 / 6 / 8 / 12 / 16 pairs stacked
+    B, S, nbatch = 8, 8, 24
     batches = [[pool[(i * B + j) % len(pool)] for j in range(B)] for i in range(nbatch)]
     pstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     mk = lambda i: pred.register_batch_phases(batches[i], seeds=range(i * B, i * B + B))
@@ -285,7 +286,7 @@ def extra_workloads(dev, log, cpu_baselines=True):
     rates.sort()
     out["predator_config3"] = {
         "workload": "Predator_APR KPConv encoder + overlap attention + score sampling + RANSAC(50000, 1000) on "
-                    "2 x 118 k-point pairs (8 distinct synthetic pairs); 4 pairs stacked per forward, one host thread "
+                    "2 x 118 k-point pairs (8 distinct synthetic pairs); 8 pairs stacked per forward, one host thread "
                     "keeping 8 batches in flight on 8 streams; median of 3 runs of 192 pairs",
         "value": rates[1], "unit": "pairs/s", "ms_per_pair": 1e3 / rates[1], "runs_pairs_per_s": rates,
         "host_enqueue_ms_per_pair": sorted(host_ms)[1],

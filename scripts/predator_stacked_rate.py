@@ -1,4 +1,4 @@
-"""Predator config 3 the way bench.py's `workloads.predator_config3` measures it (4 pairs stacked per forward, one host thread
+"""Predator config 3 the way bench.py's `workloads.predator_config3` measures it (8 pairs stacked per forward, one host thread
 keeping 8 batches in flight on 8 streams; median of 3 runs of 192 pairs; NBATCH, STREAMS override) + one pair at a time.  For A/B runs of the kernels
 behind it (APR_KP_FUSED_NORM=0/1 ...)."""
 import json
@@ -39,7 +39,7 @@ t0 = sync()
 for i in range(10):
     pred(ta, tb, seed=i)
 one = (sync() - t0) / 10
-B, S, nbatch = 4, int(os.environ.get("STREAMS", "8")), int(os.environ.get("NBATCH", "48"))
+B, S, nbatch = int(os.environ.get("STACK", "8")), int(os.environ.get("STREAMS", "8")), int(os.environ.get("NBATCH", "24"))
 batches = [[pool[(i * B + j) % len(pool)] for j in range(B)] for i in range(nbatch)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 mk = lambda i: pred.register_batch_phases(batches[i], seeds=range(i * B, i * B + B))
